@@ -1,0 +1,184 @@
+/*
+ * mpqr.h -- C ABI of the MI355X-native mixed-precision block QR (libmpqr.so).
+ *
+ * Drop-in boundary for ONE path of jaidonlybbert/MixedPrecisionBlockQR: the block
+ * Householder QR  A -> (Q, R)  of Cuda/qr.cu (panel + WY + trailing update + Q
+ * accumulation) and its host block-loop driver.  The reference has no FFI layer;
+ * its "operator API" is a set of free C++ functions (Cuda/qr.cuh:68-137).  Every
+ * entry point below names the reference interface it replaces (file:line relative
+ * to the upstream repo).  include/mpqr_reference_api.hpp re-exports them under the
+ * reference's exact C++ names and signatures.
+ *
+ * Plain pointers and sizes only; no C++ or torch types.  All functions return an
+ * int status (MPQR_OK == 0) and never call exit() (the reference exits on CUDA
+ * errors, Cuda/helper_cuda.h:582-595).  There is NO CPU fallback: without a HIP
+ * device every compute entry point returns MPQR_ERR_NO_DEVICE.
+ *
+ * Storage conventions are the reference's (Cuda/qr.cu:198-293, :1866-1875):
+ *   A : float, row-major, (m+1) x n.  In: matrix in rows 0..m-1, row m zero.
+ *       Out: R in the upper triangle (i <= j); below it the unit-2-norm Householder
+ *       vectors shifted one row down (v_k[j] at row k+1+j), H_k = I - 2 v_k v_k^T,
+ *       sign rule sgn(0)=+1, R[k][k] = -sgn(u0)||u||, last column of a square matrix
+ *       IS reflected, exactly-zero columns are skipped.
+ *   Q : float, row-major, m x m.  In: ignored (reference requires identity, :1873).
+ *       Out: the full orthogonal factor, A_in = Q R.
+ */
+#ifndef MPQR_H
+#define MPQR_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MPQR_VERSION_MAJOR 0
+#define MPQR_VERSION_MINOR 1
+
+enum {
+    MPQR_OK = 0,
+    MPQR_ERR_INVALID = 1,     /* bad argument / shape */
+    MPQR_ERR_NO_DEVICE = 2,   /* no HIP device / HIP runtime unusable */
+    MPQR_ERR_HIP = 3,         /* a HIP call failed (see mpqr_last_error) */
+    MPQR_ERR_ALLOC = 4,
+    MPQR_ERR_IO = 5,
+    MPQR_ERR_STATE = 6        /* call order violated (e.g. factor before plan) */
+};
+
+/* operand precision of the trailing-update / Q GEMMs */
+enum {
+    MPQR_PREC_FP16 = 0,       /* fp16 operands, fp32 accumulate on MFMA (default; Cuda/qr.cu:1049 twin) */
+    MPQR_PREC_FP32 = 1        /* fp32 operands, exact-f32 MFMA (Cuda/qr.cu:958 dev_block_qr_wy twin) */
+};
+
+typedef struct mpqr_opts {
+    int precision;      /* MPQR_PREC_*                                                    */
+    int outer_block;    /* reflectors aggregated per far trailing update (0 = auto)       */
+    int form_q;         /* 1: form the full m x m Q (reference contract); 0: R + V only   */
+    int lookahead;      /* 1: factor the next block on a second stream (0 = off)          */
+    int reserved[12];
+} mpqr_opts;
+
+typedef struct mpqr_metrics {
+    double backward_error;      /* ||A - Q R||_F / ||A||_F            Cuda/qr.cu:115-135 */
+    double q_error_max_signed;  /* max_ij (Q^T Q - I)_ij (signed)     Cuda/qr.cu:137-171 */
+    double lower_trapezoid;     /* ||strict lower(R)||_F              Cuda/qr.cu:173-196 */
+    double q_error_fro;         /* ||Q^T Q - I||_F  (north-star metric)                  */
+    double a_norm;              /* ||A||_F                                               */
+} mpqr_metrics;
+
+typedef struct mpqr_timings {
+    float ms_total;       /* factor (+ form_q) on the device, HIP events                            */
+    float ms_factor;      /* panels + trailing updates                                              */
+    float ms_form_q;      /* backward accumulation of Q                                             */
+    float ms_trailing;    /* sum over the far trailing updates (3 GEMM launches each)               */
+    float ms_panel;       /* ms_factor - ms_trailing: leaves, in-block updates, T merges            */
+    float ms_far_tn;      /* sum over the far  X = A2^T V       launches (K = rows)                 */
+    float ms_far_nn;      /* sum over the far  A2 -= V Y^T      launches (K = outer_block)          */
+    int   n_far_launches; /* number of far updates (each = one tn + one small + one nn launch)      */
+    double flops_far_tn;  /* flops executed by the tn launches (2 M N K each)                       */
+    double flops_far_nn;  /* flops executed by the nn launches                                      */
+    int   reserved[8];
+} mpqr_timings;
+
+typedef struct mpqr_handle_s* mpqr_handle_t;
+
+/* ---------------- lifecycle ---------------- */
+const char* mpqr_version(void);
+void        mpqr_default_opts(mpqr_opts* o);
+int         mpqr_create(mpqr_handle_t* h, int device);          /* one handle per GPU; owns its streams */
+int         mpqr_destroy(mpqr_handle_t h);
+const char* mpqr_last_error(mpqr_handle_t h);                    /* h may be NULL: last error of a failed create */
+
+/* ---------------- the reference drivers ---------------- */
+/* replaces  void dev_mixed_precision_block_qr(float* A, float* Q, int m, int n, int r)
+ *           Cuda/qr.cuh:133, Cuda/qr.cu:1049-1226   (opts->precision = MPQR_PREC_FP16)
+ *      and  void dev_block_qr_wy(float* A, float* Q, int m, int n, int r)
+ *           Cuda/qr.cuh:131, Cuda/qr.cu:958-1047    (opts->precision = MPQR_PREC_FP32)
+ * Host pointers in/out; all device memory is owned by the handle and reused across calls. */
+int mpqr_block_qr_f32(mpqr_handle_t h, float* A, float* Q, int m, int n, int r, const mpqr_opts* opts);
+
+/* Same, on a process-wide default handle (device 0), for callers that keep the reference's
+ * handle-less call shape.  Status is returned instead of exiting. */
+int mpqr_dev_mixed_precision_block_qr(float* A, float* Q, int m, int n, int r);   /* qr.cuh:133 */
+int mpqr_dev_block_qr_wy(float* A, float* Q, int m, int n, int r);                /* qr.cuh:131 */
+
+/* ---------------- device-resident form of the same driver ---------------- */
+/* plan: allocate / reuse workspace for an m x n problem with panel width r */
+int mpqr_plan(mpqr_handle_t h, int m, int n, int r, const mpqr_opts* opts);
+/* load the input matrix (m x n, row-major, leading dimension ld) into HBM */
+int mpqr_set_matrix_host(mpqr_handle_t h, const float* A, long ld);
+int mpqr_set_matrix_device(mpqr_handle_t h, const float* dA, long ld);
+/* U[0,1) synthetic input generated on the device; bit-identical to the oracle's
+ * generator (replaces h_generate_random_matrix<float>, Cuda/mmult.cuh:38-64, with a fixed seed) */
+int mpqr_generate_matrix(mpqr_handle_t h, uint64_t seed);
+/* keep / restore a pristine device copy of the input (benchmark loops factor in place) */
+int mpqr_snapshot_input(mpqr_handle_t h);
+int mpqr_restore_input(mpqr_handle_t h);
+/* A -> R,V in place then (if form_q) Q; asynchronous on the handle's streams */
+int mpqr_factor(mpqr_handle_t h);
+int mpqr_sync(mpqr_handle_t h);
+int mpqr_get_timings(mpqr_handle_t h, mpqr_timings* t);
+/* results: A_out is (m+1) x n in the reference's shifted-reflector layout, Q is m x m */
+int mpqr_get_factor_host(mpqr_handle_t h, float* A_out);
+int mpqr_get_q_host(mpqr_handle_t h, float* Q);
+int mpqr_get_r_host(mpqr_handle_t h, float* R);      /* m x n, strict lower part zero: h_strip_R_from_A qr.cu:85-100 */
+/* three metrics of the reference's testers, computed on the device against the snapshot */
+int mpqr_metrics_device(mpqr_handle_t h, mpqr_metrics* out);
+
+/* ---------------- stage-level entry points (parity tests) ---------------- */
+/* replaces h_householder_qr(float* A,int m,int n,int global_offset,int panel_width)  Cuda/qr.cu:198-293
+ * A: host (m+1) x n, factored in place on the GPU (columns [go, go+pw) only) */
+int mpqr_householder_qr_f32(mpqr_handle_t h, float* A, int m, int n, int global_offset, int panel_width);
+/* replaces h_wy_transform / dev_wy_transform  Cuda/qr.cu:337-426, :535-600.
+ * Compact form: T (pw x pw, row-major, upper) of Q_panel = I - V T V^T built from the reflectors
+ * stored in A.  If Qpanel != NULL also returns the dense (m-go)^2 matrix the reference materialises. */
+int mpqr_wy_transform_f32(mpqr_handle_t h, const float* A, int m, int n, int global_offset, int panel_width,
+                          float* T, float* Qpanel);
+/* replaces h_q_backward_accumulation(float* h_A, float** h_Q, int m, int n)  Cuda/qr.cu:296-335
+ * (Q is caller-allocated, m x m) */
+int mpqr_q_backward_accumulation_f32(mpqr_handle_t h, const float* A, float* Q, int m, int n);
+/* replaces the trailing update  A[l:,tau:] <- Q_panel^T A[l:,tau:]
+ *   shared_mem_mmult_in_place_transpose_a + dev_cpy_strided_array  Cuda/mmult.cu:236-288, qr.cu:1098-1106
+ * with the compact-WY MFMA apply, reflectors of columns [go, go+pw) taken from A itself */
+int mpqr_apply_panel_to_trailing_f32(mpqr_handle_t h, float* A, int m, int n, int global_offset, int panel_width,
+                                     int precision);
+/* replaces h_backward_error / h_q_error / h_lower_trapezoid_error  Cuda/qr.cu:115-196 (host buffers) */
+int mpqr_metrics_f32(mpqr_handle_t h, const float* A, const float* R, const float* Q, int m, int n, mpqr_metrics* out);
+/* pass criterion of the reference's testers: err <= 2^-precision_bits * m  (qr.cu:120,127) */
+int mpqr_error_passes(double err, int m, int precision_bits);
+
+/* ---------------- C++/main.cpp path ---------------- */
+/* replaces void qr_factorization(MatrixXd& A, MatrixXd& Q)  C++/main.cpp:16-43.
+ * column-major doubles (Eigen MatrixXd storage), m x n with m >= n, A -> R in place,
+ * Q (m x m) out.  Runs on the GPU in fp64. */
+int mpqr_qr_factorization_f64(mpqr_handle_t h, double* A, double* Q, int m, int n);
+
+/* ---------------- host-side helpers of the path (no GPU needed) ---------------- */
+/* replaces read_euroc_jacobian(std::string, int*, int*, float**)  Cuda/qr.cu:696-776.
+ * *matrix is malloc'd by the callee (as in the reference); free with mpqr_free_host. */
+int  mpqr_read_euroc_jacobian(const char* path, int* rows, int* cols, float** matrix);
+int  mpqr_write_euroc_jacobian(const char* path, int rows, int cols, const float* matrix);
+void mpqr_free_host(void* p);
+/* replaces h_write_results_to_log  Cuda/qr.cu:58-83: appends "rows,cols,runtime,flops,error" CSV */
+int  mpqr_write_results_to_log(const char* dir, const char* file_name, int height, int width, float time_ms,
+                               float flops_per_second, float backward_error);
+/* replaces h_qr_flops_per_second  Cuda/qr.cu:102-113 (fp32 arithmetic kept on purpose) */
+float  mpqr_qr_flops_per_second(float time_ms, int m, int n);
+/* algorithmic flop counts used for roofline accounting */
+double mpqr_flops_geqrf(int m, int n);                 /* 2 m n^2 - 2/3 n^3                          */
+double mpqr_flops_form_q(int m, int n);                /* 4 (m^2 n - m n^2 + n^3/3)                  */
+double mpqr_flops_trailing(int m, int n, int r);       /* sum_j 4 W r nk + r^2 nk over the block loop */
+double mpqr_flops_panel(int m, int n, int r);          /* sum_j 2 W r^2                               */
+/* host-side U[0,1) generator, bit-identical to mpqr_generate_matrix */
+void   mpqr_generate_matrix_host(float* A, int m, int n, uint64_t seed);
+
+/* ---------------- multi-GPU: 1-D block-cyclic column shards ---------------- */
+/* Column blocks of width `block` are dealt round-robin: block j lives on rank j % world. */
+int  mpqr_part_owner(int col, int block, int world);
+int  mpqr_part_local_cols(int n, int block, int world, int rank);
+int  mpqr_part_local_index(int col, int block, int world);          /* column index inside its owner's shard */
+int  mpqr_part_global_index(int lcol, int block, int world, int rank);
+#ifdef __cplusplus
+}
+#endif
+#endif

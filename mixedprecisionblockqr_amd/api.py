@@ -1,0 +1,239 @@
+"""Host-side mirror of the reference's block-QR interface on top of the C ABI (include/mpqr.h).
+
+Function names, argument meaning and buffer conventions follow the reference's free functions
+(Cuda/qr.cuh:68-137, C++/main.cpp:16) so tests read like the reference's own testers
+(Cuda/qr.cu:1806-1908).  Differences: errors raise MpqrError instead of exit(); buffers are numpy
+arrays.  Everything computes on the GPU through libmpqr.so -- there is no CPU path here.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib as L
+
+
+class MpqrError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"mpqr error {code}: {msg}")
+        self.code = code
+
+
+def _opts(precision=L.PREC_FP16, outer_block=0, form_q=True, lookahead=False):
+    o = L.MpqrOpts()
+    L.lib().mpqr_default_opts(C.byref(o))
+    o.precision, o.outer_block, o.form_q, o.lookahead = int(precision), int(outer_block), int(bool(form_q)), int(bool(lookahead))
+    return o
+
+
+class Handle:
+    """One handle per GPU (owns HIP streams and all device workspace)."""
+
+    def __init__(self, device=0):
+        self._h = C.c_void_p()
+        rc = L.lib().mpqr_create(C.byref(self._h), int(device))
+        if rc != L.OK:
+            raise MpqrError(rc, L.lib().mpqr_last_error(None).decode())
+
+    def close(self):
+        if self._h:
+            L.lib().mpqr_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc):
+        if rc != L.OK:
+            raise MpqrError(rc, L.lib().mpqr_last_error(self._h).decode())
+
+    # ---- device-resident driver
+    def plan(self, m, n, r, **kw):
+        self.m, self.n, self.r = m, n, r
+        o = _opts(**kw)
+        self._chk(L.lib().mpqr_plan(self._h, m, n, r, C.byref(o)))
+
+    def set_matrix(self, A):
+        A = np.ascontiguousarray(A, np.float32)
+        self._chk(L.lib().mpqr_set_matrix_host(self._h, A, A.shape[1]))
+
+    def set_matrix_device(self, ptr, ld):
+        self._chk(L.lib().mpqr_set_matrix_device(self._h, C.c_void_p(ptr), ld))
+
+    def generate(self, seed=1234):
+        self._chk(L.lib().mpqr_generate_matrix(self._h, seed))
+
+    def snapshot(self):
+        self._chk(L.lib().mpqr_snapshot_input(self._h))
+
+    def restore(self):
+        self._chk(L.lib().mpqr_restore_input(self._h))
+
+    def factor(self):
+        self._chk(L.lib().mpqr_factor(self._h))
+
+    def sync(self):
+        self._chk(L.lib().mpqr_sync(self._h))
+
+    def timings(self):
+        t = L.MpqrTimings()
+        self._chk(L.lib().mpqr_get_timings(self._h, C.byref(t)))
+        return {k: getattr(t, k) for k, _ in L.MpqrTimings._fields_ if k != "reserved"}
+
+    def factor_out(self):
+        out = np.empty((self.m + 1, self.n), np.float32)
+        self._chk(L.lib().mpqr_get_factor_host(self._h, out))
+        return out
+
+    def q(self):
+        Q = np.empty((self.m, self.m), np.float32)
+        self._chk(L.lib().mpqr_get_q_host(self._h, Q))
+        return Q
+
+    def r_matrix(self):
+        R = np.empty((self.m, self.n), np.float32)
+        self._chk(L.lib().mpqr_get_r_host(self._h, R))
+        return R
+
+    def metrics(self):
+        mt = L.MpqrMetrics()
+        self._chk(L.lib().mpqr_metrics_device(self._h, C.byref(mt)))
+        return {k: getattr(mt, k) for k, _ in L.MpqrMetrics._fields_}
+
+
+_default = None
+
+
+def default_handle():
+    global _default
+    if _default is None:
+        _default = Handle(0)
+    return _default
+
+
+# ---------------------------------------------------------------- reference-named entry points
+def dev_mixed_precision_block_qr(A, Q, m, n, r, handle=None, **kw):
+    """Cuda/qr.cuh:133.  A: (m+1) x n float32 (in: matrix + zero row; out: R + shifted reflectors),
+    Q: m x m float32 (out).  Both modified in place, like the reference."""
+    return _block_qr(A, Q, m, n, r, L.PREC_FP16, handle, **kw)
+
+
+def dev_block_qr_wy(A, Q, m, n, r, handle=None, **kw):
+    """Cuda/qr.cuh:131 (fp32 twin)."""
+    return _block_qr(A, Q, m, n, r, L.PREC_FP32, handle, **kw)
+
+
+def _block_qr(A, Q, m, n, r, precision, handle, **kw):
+    h = handle or default_handle()
+    assert A.dtype == np.float32 and A.shape == (m + 1, n) and A.flags.c_contiguous
+    o = _opts(precision=precision, **kw)
+    qp = None
+    if o.form_q:
+        assert Q.dtype == np.float32 and Q.shape == (m, m) and Q.flags.c_contiguous
+        qp = Q.ctypes.data_as(C.c_void_p)
+    h._chk(L.lib().mpqr_block_qr_f32(h._h, A, qp, m, n, r, C.byref(o)))
+
+
+def h_householder_qr(A, m, n, global_offset, panel_width, handle=None):
+    """Cuda/qr.cu:198 semantics, executed on the GPU.  A: (m+1) x n, in place."""
+    h = handle or default_handle()
+    h._chk(L.lib().mpqr_householder_qr_f32(h._h, A, m, n, global_offset, panel_width))
+
+
+def wy_transform(A, m, n, global_offset, panel_width, dense=False, handle=None):
+    """Cuda/qr.cu:337/:535.  Returns T (compact WY), and the dense Q_panel if dense=True."""
+    h = handle or default_handle()
+    T = np.empty((panel_width, panel_width), np.float32)
+    Qp = np.empty((m - global_offset, m - global_offset), np.float32) if dense else None
+    h._chk(L.lib().mpqr_wy_transform_f32(h._h, np.ascontiguousarray(A, np.float32), m, n, global_offset, panel_width,
+                                         T.ctypes.data_as(C.c_void_p),
+                                         Qp.ctypes.data_as(C.c_void_p) if dense else None))
+    return (T, Qp) if dense else T
+
+
+def h_q_backward_accumulation(A, m, n, handle=None):
+    """Cuda/qr.cu:296.  Returns Q (m x m) from the reflectors stored in A ((m+1) x n)."""
+    h = handle or default_handle()
+    Q = np.empty((m, m), np.float32)
+    h._chk(L.lib().mpqr_q_backward_accumulation_f32(h._h, np.ascontiguousarray(A, np.float32), Q, m, n))
+    return Q
+
+
+def apply_panel_to_trailing(A, m, n, global_offset, panel_width, precision=L.PREC_FP16, handle=None):
+    """Trailing update A[l:, tau:] <- Q_panel^T A[l:, tau:] (Cuda/qr.cu:1098-1106), in place."""
+    h = handle or default_handle()
+    h._chk(L.lib().mpqr_apply_panel_to_trailing_f32(h._h, A, m, n, global_offset, panel_width, precision))
+
+
+def qr_metrics(A, R, Q, handle=None):
+    """h_backward_error / h_q_error / h_lower_trapezoid_error (Cuda/qr.cu:115-196) on the GPU."""
+    h = handle or default_handle()
+    m, n = A.shape
+    mt = L.MpqrMetrics()
+    f = lambda x: np.ascontiguousarray(x, np.float32)
+    h._chk(L.lib().mpqr_metrics_f32(h._h, f(A), f(R), f(Q), m, n, C.byref(mt)))
+    return {k: getattr(mt, k) for k, _ in L.MpqrMetrics._fields_}
+
+
+def h_strip_R_from_A(A, m, n):
+    """Cuda/qr.cu:85-100 (pure indexing; no arithmetic)."""
+    return np.triu(A[:m, :n]).astype(np.float32)
+
+
+def error_passes(err, m, precision_bits):
+    return bool(L.lib().mpqr_error_passes(float(err), m, precision_bits))
+
+
+def qr_factorization(A, handle=None):
+    """C++/main.cpp:16 on the GPU in fp64.  A: m x n (numpy, row-major view); returns (Q, R)."""
+    h = handle or default_handle()
+    m, n = A.shape
+    Ac = np.ascontiguousarray(A.T.astype(np.float64))       # column-major storage
+    Qc = np.zeros((m, m), np.float64)
+    h._chk(L.lib().mpqr_qr_factorization_f64(h._h, Ac, Qc, m, n))
+    return Qc.T.copy(), Ac.T.copy()
+
+
+def read_euroc_jacobian(path):
+    """Cuda/qr.cu:696.  Returns a dense float32 matrix."""
+    rows, cols = C.c_int(), C.c_int()
+    ptr = C.POINTER(C.c_float)()
+    rc = L.lib().mpqr_read_euroc_jacobian(str(path).encode(), C.byref(rows), C.byref(cols), C.byref(ptr))
+    if rc != L.OK:
+        raise MpqrError(rc, f"cannot read {path}")
+    M = np.ctypeslib.as_array(ptr, shape=(rows.value, cols.value)).copy()
+    L.lib().mpqr_free_host(ptr)
+    return M
+
+
+def write_euroc_jacobian(path, M):
+    M = np.ascontiguousarray(M, np.float32)
+    rc = L.lib().mpqr_write_euroc_jacobian(str(path).encode(), M.shape[0], M.shape[1], M)
+    if rc != L.OK:
+        raise MpqrError(rc, f"cannot write {path}")
+
+
+def h_write_results_to_log(height, width, time_ms, flops_per_second, backward_error, file_name="logFile", log_dir="log"):
+    """Cuda/qr.cu:58-83."""
+    rc = L.lib().mpqr_write_results_to_log(str(log_dir).encode(), file_name.encode(), height, width, time_ms,
+                                           flops_per_second, backward_error)
+    if rc != L.OK:
+        raise MpqrError(rc, "cannot write log")
+
+
+def h_qr_flops_per_second(time_ms, m, n):
+    return float(L.lib().mpqr_qr_flops_per_second(time_ms, m, n))
+
+
+def generate_matrix(m, n, seed=1234):
+    A = np.empty((m, n), np.float32)
+    L.lib().mpqr_generate_matrix_host(A, m, n, seed)
+    return A
+
+
+def flops(m, n, r):
+    l = L.lib()
+    return {"geqrf": l.mpqr_flops_geqrf(m, n), "form_q": l.mpqr_flops_form_q(m, n),
+            "trailing": l.mpqr_flops_trailing(m, n, r), "panel": l.mpqr_flops_panel(m, n, r)}

@@ -1,0 +1,292 @@
+// kernels_gemm.hip -- fp16-operand / fp32-accumulate MFMA GEMM family for gfx950 (CDNA4).
+//
+// These kernels replace the reference's three GEMM-shaped steps
+//   shared_mem_mmult_in_place_transpose_a   Cuda/mmult.cu:236-288  (fp32 trailing update, 32x32 smem tiles)
+//   dev_tensorcore_mmult_tiled<half,half,float>  Cuda/mmult.cuh:252-300 (WMMA Q accumulation)
+//   dev_cpy_and_cast_array / dev_cpy_strided_array  Cuda/mmult.cuh:104-200 (cast + copy-back passes)
+// with one LDS-tiled kernel template built on v_mfma_f32_32x32x16_f16 (wave64).  The casts are
+// fused into the staging pass and the copy-back into the epilogue (true in-place update).
+//
+// All products have the form  C[M x N] = A[M x K] * B[K x N]  with B given as Bt[N][K]
+// (k contiguous), so both LDS images are [row][k] and every MFMA fragment is one ds_read_b128.
+// Tile 128 x 128 x 64, 256 threads = 4 waves as 2 x 2, each wave 64 x 64 = 2 x 2 MFMA tiles.
+#include "mpqr_internal.h"
+
+namespace mpqr {
+
+typedef half_t half8 __attribute__((ext_vector_type(8)));
+typedef half_t half4 __attribute__((ext_vector_type(4)));
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+
+constexpr int BM = 128, BN = 128, BK = 64;
+constexpr int LDSP = BK + 8;   // padded LDS row (halves): 144-B stride is conflict-free for ds_read_b128
+
+struct alignas(16) U4 { uint32_t x, y, z, w; };
+
+__device__ __forceinline__ uint32_t pack2(float a, float b) {
+    typedef half_t half2v __attribute__((ext_vector_type(2)));
+    half2v h = {(half_t)a, (half_t)b};
+    return __builtin_bit_cast(uint32_t, h);
+}
+
+template <int AM, int EM>
+__global__ __launch_bounds__(256) void gemm_f16_kernel(GemmArgs g) {
+    __shared__ __attribute__((aligned(16))) half_t lds[(BM + BN) * LDSP];
+    half_t* As = lds;
+    half_t* Bs = lds + BM * LDSP;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int bm = blockIdx.x * BM, bn = blockIdx.y * BN;
+    const int z = blockIdx.z;
+
+    const int ktiles = g.K / BK;
+    const int per = (ktiles + g.nsplit - 1) / g.nsplit;
+    const int kt0 = z * per;
+    const int kt1 = min(ktiles, kt0 + per);
+
+    // ---- staging registers
+    U4 ra16[4];        // A_H16 / A_F32 (after conversion)
+    float4 raT[8];     // A_F32T
+    U4 rb[4];
+
+    auto load_tile = [&](int kt) {
+        const int k = kt * BK;
+        if (AM == A_H16) {
+            const half_t* A = (const half_t*)g.A;
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                int c = tid + 256 * i, row = c >> 3, kc = (c & 7) * 8;
+                int gm = bm + row;
+                U4 v = {0, 0, 0, 0};
+                if (gm < g.M) v = *(const U4*)(A + (long)gm * g.lda + k + kc);
+                ra16[i] = v;
+            }
+        } else if (AM == A_F32T) {
+            const float* A = (const float*)g.A;
+#pragma unroll
+            for (int i = 0; i < 2; i++) {
+                int id = tid + 256 * i, mg = id & 31, kg = id >> 5;
+                int gm = bm + mg * 4;
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (gm < g.M) v = *(const float4*)(A + (long)(k + kg * 4 + j) * g.lda + gm);
+                    raT[i * 4 + j] = v;
+                }
+            }
+        } else {  // A_F32 with slab sum
+            const float* A = (const float*)g.A;
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                int c = tid + 256 * i, row = c >> 3, kc = (c & 7) * 8;
+                int gm = bm + row;
+                float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0;
+                if (gm < g.M) {
+                    const float* p = A + (long)gm * g.lda + k + kc;
+                    for (int sl = 0; sl < g.nslab_in; sl++) {
+                        float4 a0 = *(const float4*)(p + (long)sl * g.slab_in_stride);
+                        float4 a1 = *(const float4*)(p + (long)sl * g.slab_in_stride + 4);
+                        s0.x += a0.x; s0.y += a0.y; s0.z += a0.z; s0.w += a0.w;
+                        s1.x += a1.x; s1.y += a1.y; s1.z += a1.z; s1.w += a1.w;
+                    }
+                }
+                const float sc = g.in_scale;
+                U4 v;
+                v.x = pack2(s0.x * sc, s0.y * sc); v.y = pack2(s0.z * sc, s0.w * sc);
+                v.z = pack2(s1.x * sc, s1.y * sc); v.w = pack2(s1.z * sc, s1.w * sc);
+                ra16[i] = v;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            int c = tid + 256 * i, row = c >> 3, kc = (c & 7) * 8;
+            int gn = bn + row;
+            U4 v = {0, 0, 0, 0};
+            if (gn < g.N) v = *(const U4*)(g.Bt + (long)gn * g.ldb + k + kc);
+            rb[i] = v;
+        }
+    };
+
+    auto store_tile = [&]() {
+        if (AM == A_F32T) {
+            const float sc = g.in_scale;
+#pragma unroll
+            for (int i = 0; i < 2; i++) {
+                int id = tid + 256 * i, mg = id & 31, kg = id >> 5;
+                const float4 v0 = raT[i * 4 + 0], v1 = raT[i * 4 + 1], v2 = raT[i * 4 + 2], v3 = raT[i * 4 + 3];
+                uint2 w;
+                half_t* base = As + (mg * 4) * LDSP + kg * 4;
+                w.x = pack2(v0.x * sc, v1.x * sc); w.y = pack2(v2.x * sc, v3.x * sc); *(uint2*)(base) = w;
+                w.x = pack2(v0.y * sc, v1.y * sc); w.y = pack2(v2.y * sc, v3.y * sc); *(uint2*)(base + LDSP) = w;
+                w.x = pack2(v0.z * sc, v1.z * sc); w.y = pack2(v2.z * sc, v3.z * sc); *(uint2*)(base + 2 * LDSP) = w;
+                w.x = pack2(v0.w * sc, v1.w * sc); w.y = pack2(v2.w * sc, v3.w * sc); *(uint2*)(base + 3 * LDSP) = w;
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                int c = tid + 256 * i, row = c >> 3, kc = (c & 7) * 8;
+                *(U4*)(As + row * LDSP + kc) = ra16[i];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            int c = tid + 256 * i, row = c >> 3, kc = (c & 7) * 8;
+            *(U4*)(Bs + row * LDSP + kc) = rb[i];
+        }
+    };
+
+    floatx16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++)
+#pragma unroll
+            for (int e = 0; e < 16; e++) acc[i][j][e] = 0.f;
+
+    const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
+
+    if (kt0 < kt1) {
+        load_tile(kt0);
+        store_tile();
+        __syncthreads();
+        for (int kt = kt0; kt < kt1; kt++) {
+            const bool more = (kt + 1 < kt1);
+            if (more) load_tile(kt + 1);
+#pragma unroll
+            for (int ks = 0; ks < BK / 16; ks++) {
+                half8 a[2], b[2];
+#pragma unroll
+                for (int i = 0; i < 2; i++) a[i] = *(const half8*)(As + (wm + i * 32 + r) * LDSP + ks * 16 + h * 8);
+#pragma unroll
+                for (int j = 0; j < 2; j++) b[j] = *(const half8*)(Bs + (wn + j * 32 + r) * LDSP + ks * 16 + h * 8);
+#pragma unroll
+                for (int i = 0; i < 2; i++)
+#pragma unroll
+                    for (int j = 0; j < 2; j++)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i], b[j], acc[i][j], 0, 0, 0);
+            }
+            __syncthreads();
+            if (more) {
+                store_tile();
+                __syncthreads();
+            }
+        }
+    }
+
+    // ---- epilogue.  D layout of 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+    const float alpha = g.alpha;
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+            const int n = bn + wn + j * 32 + r;
+#pragma unroll
+            for (int e = 0; e < 16; e++) {
+                const int m = bm + wm + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+                if (m < g.M && n < g.N) {
+                    const float v = alpha * acc[i][j][e];
+                    if (EM == E_STORE_F32) {
+                        ((float*)g.C)[(long)z * g.slab_out_stride + (long)m * g.ldc + n] = v;
+                    } else if (EM == E_STORE_H16) {
+                        ((half_t*)g.C)[(long)m * g.ldc + n] = (half_t)v;
+                    } else {
+                        if (n >= g.col_lo) {
+                            float* p = (float*)g.C + (long)m * g.ldc + n;
+                            *p = *p - v;
+                        }
+                    }
+                }
+            }
+        }
+}
+
+template <int AM, int EM>
+static void launch_one(const GemmArgs& g, hipStream_t s) {
+    dim3 grid((g.M + BM - 1) / BM, (g.N + BN - 1) / BN, g.nsplit < 1 ? 1 : g.nsplit);
+    GemmArgs a = g;
+    if (a.nsplit < 1) a.nsplit = 1;
+    if (a.nslab_in < 1) a.nslab_in = 1;
+    hipLaunchKernelGGL((gemm_f16_kernel<AM, EM>), grid, dim3(256), 0, s, a);
+}
+
+void launch_gemm_f16(AMode am, EMode em, const GemmArgs& g, hipStream_t s) {
+    if (g.M <= 0 || g.N <= 0 || g.K <= 0) return;
+#define MPQR_CASE(A_, E_) if (am == A_ && em == E_) { launch_one<A_, E_>(g, s); return; }
+    MPQR_CASE(A_F32T, E_STORE_F32)
+    MPQR_CASE(A_F32, E_STORE_H16)
+    MPQR_CASE(A_H16, E_SUB_F32)
+    MPQR_CASE(A_H16, E_STORE_F32)
+#undef MPQR_CASE
+}
+
+// ------------------------------------------------------------------ plain fp32 GEMM (small T merges, metrics)
+// 64 x 64 tile, 256 threads, 4 x 4 outputs per thread, K step 16.  Exact-f32 FMA chain.
+constexpr int SB = 64, SK = 16;
+__global__ __launch_bounds__(256) void sgemm_kernel(SgemmArgs g) {
+    __shared__ float As[SK][SB + 4];
+    __shared__ float Bs[SK][SB + 4];
+    const int tid = threadIdx.x;
+    const int tx = tid & 15, ty = tid >> 4;
+    const int bm = blockIdx.y * SB, bn = blockIdx.x * SB;
+    float acc[4][4] = {};
+    for (int k0 = 0; k0 < g.K; k0 += SK) {
+        // A tile: SB(m) x SK(k); element (m,k) = transA ? A[k][m] : A[m][k]
+        for (int e = tid; e < SB * SK; e += 256) {
+            int mm, kk;
+            if (g.transA) { mm = e % SB; kk = e / SB; } else { kk = e % SK; mm = e / SK; }
+            int gm = bm + mm, gk = k0 + kk;
+            float v = 0.f;
+            if (gm < g.M && gk < g.K) {
+                const float* p = g.transA ? g.A + (long)gk * g.lda + gm : g.A + (long)gm * g.lda + gk;
+                for (int sl = 0; sl < g.nslab_a; sl++) v += p[(long)sl * g.slab_a];
+            }
+            As[kk][mm] = v;
+        }
+        for (int e = tid; e < SB * SK; e += 256) {
+            int nn, kk;
+            if (g.transB) { kk = e % SK; nn = e / SK; } else { nn = e % SB; kk = e / SB; }
+            int gn = bn + nn, gk = k0 + kk;
+            float v = 0.f;
+            if (gn < g.N && gk < g.K) v = g.transB ? g.B[(long)gn * g.ldb + gk] : g.B[(long)gk * g.ldb + gn];
+            Bs[kk][nn] = v;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < SK; kk++) {
+            float a[4], b[4];
+#pragma unroll
+            for (int i = 0; i < 4; i++) a[i] = As[kk][ty * 4 + i];
+#pragma unroll
+            for (int j = 0; j < 4; j++) b[j] = Bs[kk][tx * 4 + j];
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+#pragma unroll
+                for (int j = 0; j < 4; j++) acc[i][j] = fmaf(a[i], b[j], acc[i][j]);
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            int m = bm + ty * 4 + i, n = bn + tx * 4 + j;
+            if (m < g.M && n < g.N) {
+                float* p = g.C + (long)m * g.ldc + n;
+                float v = g.alpha * acc[i][j];
+                if (g.beta != 0.f) v += g.beta * (*p);
+                *p = v;
+            }
+        }
+}
+
+void launch_sgemm(const SgemmArgs& g, hipStream_t s) {
+    if (g.M <= 0 || g.N <= 0) return;
+    SgemmArgs a = g;
+    if (a.nslab_a < 1) a.nslab_a = 1;
+    dim3 grid((g.N + SB - 1) / SB, (g.M + SB - 1) / SB);
+    hipLaunchKernelGGL(sgemm_kernel, grid, dim3(256), 0, s, a);
+}
+
+}  // namespace mpqr

@@ -1,0 +1,241 @@
+// kernels_misc.hip -- data movement, layout conversion, metric reductions, fp64 plumbing path.
+#include "mpqr_internal.h"
+
+namespace mpqr {
+
+// ------------------------------------------------------------------ synthetic input
+// splitmix64(seed) + linear index -> splitmix64 -> top 24 bits -> [0,1).  Identical to
+// mpqr_generate_matrix_host and to the oracle's generator (oracle_qr.c), so CPU and GPU
+// agree bit for bit.  Replaces rand()/RAND_MAX of Cuda/mmult.cuh:38-64.
+__host__ __device__ inline uint64_t splitmix64(uint64_t x) {
+    x += 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+
+// local column lc of rank `rank` maps to global column mpqr_part_global_index(lc); world==1 -> identity
+__global__ void generate_kernel(float* A, long lda, int m, int nloc, int nglob, uint64_t base, int block, int world,
+                                int rank) {
+    const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= (long)m * nloc) return;
+    const int i = (int)(e / nloc), lc = (int)(e % nloc);
+    int gc = lc;
+    if (world > 1) gc = ((lc / block) * world + rank) * block + (lc % block);
+    const uint64_t idx = (uint64_t)i * (uint64_t)nglob + (uint64_t)gc;
+    A[(long)i * lda + lc] = (float)(splitmix64(base + idx) >> 40) * (1.0f / 16777216.0f);
+}
+void launch_generate(float* A, long lda, int m, int n, uint64_t seed, int nglob, int block, int world, int rank,
+                     hipStream_t s) {
+    const long tot = (long)m * n;
+    hipLaunchKernelGGL(generate_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, A, lda, m, n, nglob,
+                       splitmix64(seed), block, world, rank);
+}
+
+__global__ void identity_kernel(float* Q, long ldq, int rows, int cols, int diag_off) {
+    const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= (long)rows * cols) return;
+    const int i = (int)(e / cols), j = (int)(e % cols);
+    Q[(long)i * ldq + j] = (i == j + diag_off) ? 1.f : 0.f;
+}
+void launch_set_identity(float* Q, long ldq, int rows, int cols, hipStream_t s) {
+    const long tot = (long)rows * cols;
+    hipLaunchKernelGGL(identity_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, Q, ldq, rows, cols, 0);
+}
+
+// ------------------------------------------------------------------ boundary layout (Cuda/qr.cu:283-285)
+// internal: R on/above the diagonal, v_k[1:] below it in natural rows, v_k[0] in vdiag[k]
+// boundary: (m+1) x n, reflector k shifted one row down (v_k[j] at row k+1+j)
+__global__ void pack_factor_kernel(const float* A, long lda, const float* vdiag, float* out, int m, int n) {
+    const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= (long)(m + 1) * n) return;
+    const int r = (int)(e / n), c = (int)(e % n);
+    float v;
+    if (r <= c) v = (r < m) ? A[(long)r * lda + c] : 0.f;
+    else if (r - 1 == c) v = vdiag[c];
+    else v = A[(long)(r - 1) * lda + c];
+    out[e] = v;
+}
+void launch_pack_factor(const float* A, long lda, const float* vdiag, float* out, int m, int n, hipStream_t s) {
+    const long tot = (long)(m + 1) * n;
+    hipLaunchKernelGGL(pack_factor_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, A, lda, vdiag, out, m, n);
+}
+
+// boundary -> internal for columns [c0,c1) that already hold reflectors; other columns are copied as plain data
+__global__ void unpack_factor_kernel(const float* in, int m, int n, int c0, int c1, float* A, long lda, float* vdiag,
+                                     half_t* Vh, long ldvh, half_t* Vt, long ldvt) {
+    const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= (long)m * n) return;
+    const int r = (int)(e / n), c = (int)(e % n);
+    if (c >= c0 && c < c1) {
+        if (r <= c) {
+            A[(long)r * lda + c] = in[(long)r * n + c];
+            if (r == c) {
+                const float d = in[(long)(r + 1) * n + c];
+                vdiag[c] = d;
+                Vh[(long)r * ldvh + c] = (half_t)d;
+                Vt[(long)c * ldvt + r] = (half_t)d;
+            }
+        } else {
+            const float v = in[(long)(r + 1) * n + c];
+            A[(long)r * lda + c] = v;
+            Vh[(long)r * ldvh + c] = (half_t)v;
+            Vt[(long)c * ldvt + r] = (half_t)v;
+        }
+    } else {
+        A[(long)r * lda + c] = in[(long)r * n + c];
+    }
+}
+void launch_unpack_factor(const float* in, int m, int n, int c0, int c1, float* A, long lda, float* vdiag, half_t* Vh,
+                          long ldvh, half_t* Vt, long ldvt, hipStream_t s) {
+    const long tot = (long)m * n;
+    hipLaunchKernelGGL(unpack_factor_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, in, m, n, c0, c1, A,
+                       lda, vdiag, Vh, ldvh, Vt, ldvt);
+}
+
+// h_strip_R_from_A, Cuda/qr.cu:85-100
+__global__ void strip_r_kernel(const float* A, long lda, float* R, int m, int n) {
+    const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= (long)m * n) return;
+    const int r = (int)(e / n), c = (int)(e % n);
+    R[e] = (r <= c) ? A[(long)r * lda + c] : 0.f;
+}
+void launch_strip_r(const float* A, long lda, float* R, int m, int n, hipStream_t s) {
+    const long tot = (long)m * n;
+    hipLaunchKernelGGL(strip_r_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, A, lda, R, m, n);
+}
+
+// ------------------------------------------------------------------ reductions
+__device__ __forceinline__ double wave_sum(double v) {
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    return v;
+}
+
+// out[0] = max over columns of sum_i A[i][j]^2 (squared), via atomicMax on the float bits (values >= 0)
+__global__ void colnorm_max_kernel(const float* A, long lda, int m, int n, float* out) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    float s = 0.f;
+    if (j < n)
+        for (int i = 0; i < m; i++) { const float v = A[(long)i * lda + j]; s += v * v; }
+    s = wave_max(s);
+    if ((threadIdx.x & 63) == 0) atomicMax((unsigned int*)out, __float_as_uint(s));
+}
+void launch_colnorm_max(const float* A, long lda, int m, int n, float* out, hipStream_t s) {
+    (void)hipMemsetAsync(out, 0, sizeof(float), s);
+    hipLaunchKernelGGL(colnorm_max_kernel, dim3((n + 255) / 256), dim3(256), 0, s, A, lda, m, n, out);
+}
+
+// out[0] += sum (A-B)^2 ; out[1] += sum A^2   (double accumulation)
+__global__ void diff_norms_kernel(const float* A, long lda, const float* B, long ldb, int m, int n, double* out) {
+    double d2 = 0, a2 = 0;
+    const long tot = (long)m * n;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < tot; e += (long)gridDim.x * blockDim.x) {
+        const int r = (int)(e / n), c = (int)(e % n);
+        const double a = A[(long)r * lda + c], b = B[(long)r * ldb + c];
+        d2 += (a - b) * (a - b); a2 += a * a;
+    }
+    d2 = wave_sum(d2); a2 = wave_sum(a2);
+    if ((threadIdx.x & 63) == 0) { atomicAdd(&out[0], d2); atomicAdd(&out[1], a2); }
+}
+void launch_diff_norms(const float* A, long lda, const float* B, long ldb, int m, int n, double* out, hipStream_t s) {
+    hipLaunchKernelGGL(diff_norms_kernel, dim3(1024), dim3(256), 0, s, A, lda, B, ldb, m, n, out);
+}
+
+// out[0] += sum (G - I)^2 ; low 4 bytes of out[1] = float bits of max SIGNED (G - I)  (h_q_error takes the max of signed values, qr.cu:152)
+__global__ void gram_minus_identity_kernel(const float* G, long ldg, int m, double* out) {
+    double s2 = 0; float mx = 0.f;
+    const long tot = (long)m * m;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < tot; e += (long)gridDim.x * blockDim.x) {
+        const int r = (int)(e / m), c = (int)(e % m);
+        const float d = G[(long)r * ldg + c] - ((r == c) ? 1.f : 0.f);
+        s2 += (double)d * d; mx = fmaxf(mx, d);
+    }
+    s2 = wave_sum(s2); mx = wave_max(mx);
+    if ((threadIdx.x & 63) == 0) {
+        atomicAdd(&out[0], s2);
+        atomicMax((unsigned int*)&out[1], __float_as_uint(mx));   // mx >= 0: bit order == value order
+    }
+}
+void launch_gram_minus_identity(const float* G, long ldg, int m, double* out, hipStream_t s) {
+    hipLaunchKernelGGL(gram_minus_identity_kernel, dim3(1024), dim3(256), 0, s, G, ldg, m, out);
+}
+
+__global__ void lower_norm_kernel(const float* R, long ldr, int m, int n, double* out) {
+    double s2 = 0;
+    const long tot = (long)m * n;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < tot; e += (long)gridDim.x * blockDim.x) {
+        const int r = (int)(e / n), c = (int)(e % n);
+        if (c < r) { const double v = R[(long)r * ldr + c]; s2 += v * v; }
+    }
+    s2 = wave_sum(s2);
+    if ((threadIdx.x & 63) == 0) atomicAdd(&out[0], s2);
+}
+void launch_lower_norm(const float* R, long ldr, int m, int n, double* out, hipStream_t s) {
+    hipLaunchKernelGGL(lower_norm_kernel, dim3(256), dim3(256), 0, s, R, ldr, m, n, out);
+}
+
+// ------------------------------------------------------------------ fp64 plumbing path (C++/main.cpp:5-43)
+// One workgroup, 1024 threads = 16 waves.  Column-major doubles.  For each column i:
+//   sigma = (float)||u||  (truncated to float exactly as main.cpp:6), w = (u - s sigma e1)/||.||,
+//   A <- H A over ALL columns (the reference multiplies the full matrix, so R_ii and the ~1e-7
+//   sub-diagonal residue come out of the same arithmetic), Q <- Q H.
+// Intended for plumbing-sized problems (config 1: 256 x 256); cost O(m n (m + n)) on one CU.
+__device__ __forceinline__ double wave_sum_d(double v) { return wave_sum(v); }
+
+__global__ __launch_bounds__(1024) void qr_f64_kernel(double* A, double* Q, int m, int n, double* w) {
+    __shared__ double red[16];
+    __shared__ double sh_scalar;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int i = 0; i < n; i++) {
+        const int len = m - i;
+        double* col = A + (long)i * m + i;
+        // ||u||^2
+        double s = 0;
+        for (int k = tid; k < len; k += 1024) s += col[k] * col[k];
+        s = wave_sum_d(s);
+        if (lane == 0) red[wave] = s;
+        __syncthreads();
+        if (tid == 0) { double t = 0; for (int q = 0; q < 16; q++) t += red[q]; sh_scalar = t; }
+        __syncthreads();
+        const float sigma = (float)sqrt(sh_scalar);
+        const double sgn = (col[0] >= 0) ? -1.0 : 1.0;
+        __syncthreads();
+        for (int k = tid; k < len; k += 1024) w[k] = col[k] - ((k == 0) ? sgn * (double)sigma : 0.0);
+        __syncthreads();
+        s = 0;
+        for (int k = tid; k < len; k += 1024) s += w[k] * w[k];
+        s = wave_sum_d(s);
+        if (lane == 0) red[wave] = s;
+        __syncthreads();
+        if (tid == 0) { double t = 0; for (int q = 0; q < 16; q++) t += red[q]; sh_scalar = sqrt(t); }
+        __syncthreads();
+        const double nw = sh_scalar;
+        for (int k = tid; k < len; k += 1024) w[k] /= nw;
+        __syncthreads();
+        // A <- H A : wave per column
+        for (int c = wave; c < n; c += 16) {
+            double* x = A + (long)c * m + i;
+            double d = 0;
+            for (int k = lane; k < len; k += 64) d += w[k] * x[k];
+            d = wave_sum_d(d);
+            for (int k = lane; k < len; k += 64) x[k] -= 2.0 * w[k] * d;
+        }
+        // Q <- Q H : wave per row r, elements Q(r, i+k) at (i+k)*m + r
+        for (int r = wave; r < m; r += 16) {
+            double d = 0;
+            for (int k = lane; k < len; k += 64) d += Q[(long)(i + k) * m + r] * w[k];
+            d = wave_sum_d(d);
+            for (int k = lane; k < len; k += 64) Q[(long)(i + k) * m + r] -= 2.0 * d * w[k];
+        }
+        __syncthreads();
+    }
+}
+void launch_qr_f64(double* A, double* Q, int m, int n, double* work, hipStream_t s) {
+    hipLaunchKernelGGL(qr_f64_kernel, dim3(1), dim3(1024), 0, s, A, Q, m, n, work);
+}
+
+}  // namespace mpqr

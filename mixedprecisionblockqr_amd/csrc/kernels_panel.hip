@@ -1,0 +1,244 @@
+// kernels_panel.hip -- fp32 Householder panel ("leaf") factorisation and compact-WY T construction.
+//
+// Replaces the reference's host-side panel  h_householder_qr  (Cuda/qr.cu:198-293, run on the CPU
+// with a whole-matrix H2D/D2H per panel, qr.cu:1080-1082,1215) and its WY builder dev_wy_transform
+// (qr.cu:428-600, dense (m-l)^2 Q_panel) by device kernels working on the resident matrix.
+//
+// Leaf = up to 32 adjacent columns inside one 32-aligned column window, all rows below the
+// diagonal.  One launch per column, many workgroups per launch (256 rows each), no inter-workgroup
+// waiting inside a launch: launch k applies reflector k to the leaf columns AND accumulates the
+// partial dot products  a_{k+1}^T a_j  (j >= k+1) that reflector k+1 needs, so the next launch can
+// derive ||u||, v^T a_j and ||v|| algebraically:
+//     u = A[k:,k], s_j = u^T a_j, alpha = sgn(u_0)||u||, v = (u + alpha e_1)/||u + alpha e_1||,
+//     ||u + alpha e_1||^2 = 2 (s_k + |u_0| ||u||),   v^T a_j = (s_j + alpha a_kj)/||.||
+// (sign rule and zero-column skip exactly as qr.cu:229-244; R_kk = -alpha).
+// Reductions: 8-lane row groups -> DPP/xor shuffles across the wave64 -> LDS across the 4 waves
+// -> per-workgroup partial in HBM, summed by every workgroup of the next launch.
+#include "mpqr_internal.h"
+
+namespace mpqr {
+
+constexpr int RPW = 256;   // rows per workgroup
+
+__device__ __forceinline__ float pick(const float4& v, int c) {
+    return c == 0 ? v.x : (c == 1 ? v.y : (c == 2 ? v.z : v.w));
+}
+
+// partial dots of column kn with leaf columns over rows >= row_lo handled by this workgroup
+// (used to start a leaf: kn = c0, no reflector applied)
+__global__ __launch_bounds__(256) void leaf_init_kernel(LeafArgs a, int kn, float* __restrict__ Pout) {
+    __shared__ float sh_part[4][32];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int cg = tid & 7, rl = tid >> 3;
+    const int row0 = kn + blockIdx.x * RPW;
+    const int kq = kn - a.cb;
+    float pacc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int p = 0; p < RPW / 32; p++) {
+        const int row = row0 + p * 32 + rl;
+        const bool valid = row < a.mrows;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (valid) v = *(const float4*)(a.A + (long)row * a.lda + a.cb + 4 * cg);
+        const float comp = pick(v, kq & 3);
+        const float aikn = __shfl(comp, (lane & ~7) | (kq >> 2));
+        pacc[0] += aikn * v.x; pacc[1] += aikn * v.y; pacc[2] += aikn * v.z; pacc[3] += aikn * v.w;
+    }
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+        float s = pacc[c];
+        s += __shfl_xor(s, 8); s += __shfl_xor(s, 16); s += __shfl_xor(s, 32);
+        pacc[c] = s;
+    }
+    if (lane < 8) {
+#pragma unroll
+        for (int c = 0; c < 4; c++) sh_part[wave][lane * 4 + c] = pacc[c];
+    }
+    __syncthreads();
+    if (tid < 32) Pout[blockIdx.x * 32 + tid] = sh_part[0][tid] + sh_part[1][tid] + sh_part[2][tid] + sh_part[3][tid];
+}
+
+__global__ __launch_bounds__(256) void leaf_step_kernel(LeafArgs a, int k, int nwg_in,
+                                                        const float* __restrict__ Pin, float* __restrict__ Pout) {
+    __shared__ float sh_part[8][32];
+    __shared__ float sh_s[32], sh_rowk[32];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int cg = tid & 7, rl = tid >> 3;
+    const int kq = k - a.cb;
+
+    // ---- phase 0: every workgroup sums the previous launch's partials (tiny, L2-resident)
+    {
+        const int j = tid & 31, gq = tid >> 5;
+        float s = 0.f;
+        for (int w = gq; w < nwg_in; w += 8) s += Pin[w * 32 + j];
+        sh_part[gq][j] = s;
+    }
+    __syncthreads();
+    if (tid < 32) {
+        float s = 0.f;
+#pragma unroll
+        for (int q = 0; q < 8; q++) s += sh_part[q][tid];
+        sh_s[tid] = s;
+        sh_rowk[tid] = a.A[(long)k * a.lda + a.cb + tid];
+    }
+    __syncthreads();
+    const float sk = sh_s[kq], akk = sh_rowk[kq];
+    float alpha = 0.f, inv = 0.f;
+    if (sk != 0.f) {                       // exactly-zero column: skipped (qr.cu:242-244)
+        const float nu = sqrtf(sk);
+        alpha = (akk >= 0.f) ? nu : -nu;
+        inv = 1.0f / sqrtf(2.0f * (sk + fabsf(akk) * nu));
+    }
+    float w[4];
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+        const int j = 4 * cg + c, gj = a.cb + j;
+        w[c] = (gj > k && gj < a.c1) ? 2.0f * (sh_s[j] + alpha * sh_rowk[j]) * inv : 0.f;
+    }
+    __syncthreads();   // sh_part is reused below
+
+    // ---- phase 1: apply reflector k to my rows, emit v, accumulate dots for reflector k+1
+    const int kn = k + 1;
+    const bool have_next = kn < a.c1;
+    const int knq = have_next ? kn - a.cb : kq;
+    const bool own_k = (cg == (kq >> 2));
+    const int row0 = k + blockIdx.x * RPW;
+    float pacc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int p = 0; p < RPW / 32; p++) {
+        const int row = row0 + p * 32 + rl;
+        const bool valid = row < a.mrows;
+        float* ptr = a.A + (long)row * a.lda + a.cb + 4 * cg;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (valid) v = *(const float4*)ptr;
+        const float comp = pick(v, kq & 3);
+        const float aik = __shfl(comp, (lane & ~7) | (kq >> 2));
+        const float vi = (aik + (row == k ? alpha : 0.f)) * inv;
+        v.x -= vi * w[0]; v.y -= vi * w[1]; v.z -= vi * w[2]; v.w -= vi * w[3];
+        if (own_k && sk != 0.f) {
+            const float nv = (row == k) ? -alpha : vi;     // R_kk above, reflector below
+            const int c = kq & 3;
+            if (c == 0) v.x = nv; else if (c == 1) v.y = nv; else if (c == 2) v.z = nv; else v.w = nv;
+        }
+        if (valid) {
+            *(float4*)ptr = v;
+            if (own_k) {
+                a.Vh[(long)row * a.ldvh + k] = (half_t)vi;
+                a.Vt[(long)k * a.ldvt + row] = (half_t)vi;
+                if (row == k) a.vdiag[k] = vi;
+            }
+        }
+        const float comp2 = pick(v, knq & 3);
+        const float aikn = __shfl(comp2, (lane & ~7) | (knq >> 2));
+        if (have_next && valid && row > k) {
+            pacc[0] += aikn * v.x; pacc[1] += aikn * v.y; pacc[2] += aikn * v.z; pacc[3] += aikn * v.w;
+        }
+    }
+    if (!have_next) return;
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+        float s = pacc[c];
+        s += __shfl_xor(s, 8); s += __shfl_xor(s, 16); s += __shfl_xor(s, 32);
+        pacc[c] = s;
+    }
+    if (lane < 8) {
+#pragma unroll
+        for (int c = 0; c < 4; c++) sh_part[wave][lane * 4 + c] = pacc[c];
+    }
+    __syncthreads();
+    if (tid < 32) Pout[blockIdx.x * 32 + tid] = sh_part[0][tid] + sh_part[1][tid] + sh_part[2][tid] + sh_part[3][tid];
+}
+
+void launch_leaf_factor(const LeafArgs& a, hipStream_t s) {
+    if (a.c1 <= a.c0) return;
+    float* P0 = a.P;
+    float* P1 = a.P + (long)a.maxwg * 32;
+    int nwg = (a.mrows - a.c0 + RPW - 1) / RPW;
+    if (nwg < 1) nwg = 1;
+    hipLaunchKernelGGL(leaf_init_kernel, dim3(nwg), dim3(256), 0, s, a, a.c0, P0);
+    int nwg_in = nwg;
+    for (int k = a.c0; k < a.c1; k++) {
+        int grid = (a.mrows - k + RPW - 1) / RPW;
+        if (grid < 1) grid = 1;
+        const bool even = ((k - a.c0) & 1) == 0;
+        hipLaunchKernelGGL(leaf_step_kernel, dim3(grid), dim3(256), 0, s, a, k, nwg_in, even ? P0 : P1, even ? P1 : P0);
+        nwg_in = grid;
+    }
+}
+
+// ------------------------------------------------------------------ T of a leaf
+// T^{-1} = striu(V^T V) + diag(V^T V)/2  (compact WY with H_i = I - (2/v_i^T v_i) v_i v_i^T), so
+// T_ii = 2/S_ii and T[:i,i] = -T_ii T[:i,:i] S[:i,i].  S is the Gram matrix of the fp16-ROUNDED
+// reflectors, which keeps I - V T V^T orthogonal for the V the MFMA GEMMs actually multiply with.
+__global__ __launch_bounds__(64) void t_leaf_kernel(const float* __restrict__ S, int nslab, long slab_stride, int a0,
+                                                    int c0, int c1, float* __restrict__ T, half_t* __restrict__ Th,
+                                                    half_t* __restrict__ Tth, int ldt) {
+    __shared__ float Ss[32][33];
+    __shared__ float Ts[32][33];
+    const int tid = threadIdx.x;
+    const int w = c1 - c0, off = c0 - a0;
+    for (int e = tid; e < 32 * 32; e += 64) {
+        const int i = e >> 5, j = e & 31;
+        float v = 0.f;
+        if (i < w && j < w)
+            for (int sl = 0; sl < nslab; sl++) v += S[(long)sl * slab_stride + (long)(off + i) * 64 + off + j];
+        Ss[i][j] = v;
+        Ts[i][j] = 0.f;
+    }
+    __syncthreads();
+    for (int i = 0; i < w; i++) {
+        const float sii = Ss[i][i];
+        const float tii = sii > 0.f ? 2.0f / sii : 0.f;
+        if (tid < i) {
+            float s = 0.f;
+            for (int b = tid; b < i; b++) s += Ts[tid][b] * Ss[b][i];
+            Ts[tid][i] = -tii * s;
+        } else if (tid == i) {
+            Ts[i][i] = tii;
+        }
+        __syncthreads();
+    }
+    for (int e = tid; e < ldt * ldt; e += 64) {
+        const int i = e / ldt, j = e % ldt;
+        const int li = i - off, lj = j - off;
+        float v = 0.f;
+        if (li >= 0 && li < w && lj >= 0 && lj < w) v = Ts[li][lj];
+        T[(long)i * ldt + j] = v;
+        Th[(long)i * ldt + j] = (half_t)v;
+        Tth[(long)j * ldt + i] = (half_t)v;
+    }
+}
+
+void launch_t_leaf(const float* S, int nslab, long slab_stride, int a0, int c0, int c1, float* T, half_t* Th,
+                   half_t* Tth, int ldt, hipStream_t s) {
+    hipLaunchKernelGGL(t_leaf_kernel, dim3(1), dim3(64), 0, s, S, nslab, slab_stride, a0, c0, c1, T, Th, Tth, ldt);
+}
+
+// parent T = [[T_L, T_LR], [0, T_R]] placed inside the parent's 64-aligned reflector range
+__global__ __launch_bounds__(256) void t_assemble_kernel(float* __restrict__ T, half_t* __restrict__ Th,
+                                                         half_t* __restrict__ Tth, int ldt, int A0,
+                                                         const float* __restrict__ TL, int ldl, int aL0, int c0, int cm,
+                                                         const float* __restrict__ TR, int ldr, int aR0, int c1,
+                                                         const float* __restrict__ TLR, int ldlr) {
+    const long e = (long)blockIdx.x * 256 + threadIdx.x;
+    if (e >= (long)ldt * ldt) return;
+    const int i = (int)(e / ldt), j = (int)(e % ldt);
+    const int gi = A0 + i, gj = A0 + j;
+    float v = 0.f;
+    const bool iL = gi >= c0 && gi < cm, jL = gj >= c0 && gj < cm;
+    const bool iR = gi >= cm && gi < c1, jR = gj >= cm && gj < c1;
+    if (iL && jL) v = TL[(long)(gi - aL0) * ldl + (gj - aL0)];
+    else if (iR && jR) v = TR[(long)(gi - aR0) * ldr + (gj - aR0)];
+    else if (iL && jR) v = TLR[(long)(gi - aL0) * ldlr + (gj - aR0)];
+    T[(long)i * ldt + j] = v;
+    Th[(long)i * ldt + j] = (half_t)v;
+    Tth[(long)j * ldt + i] = (half_t)v;
+}
+
+void launch_t_assemble(float* T, half_t* Th, half_t* Tth, int ldt, int A0, const float* TL, int ldl, int aL0, int c0,
+                       int cm, const float* TR, int ldr, int aR0, int c1, const float* TLR, int ldlr, hipStream_t s) {
+    const long tot = (long)ldt * ldt;
+    hipLaunchKernelGGL(t_assemble_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, T, Th, Tth, ldt, A0,
+                       TL, ldl, aL0, c0, cm, TR, ldr, aR0, c1, TLR, ldlr);
+}
+
+}  // namespace mpqr

@@ -1,0 +1,94 @@
+// mpqr_internal.h -- internal declarations shared by the HIP translation units of libmpqr.so
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include <vector>
+
+#include "../../include/mpqr.h"
+
+namespace mpqr {
+
+typedef _Float16 half_t;
+
+// ------------------------------------------------------------------ GEMM family
+// C[M x N] = A[M x K] * B[K x N], B always supplied as Bt[N][K] (k contiguous, fp16).
+enum AMode {
+    A_H16 = 0,   // fp16 source [M][K], k contiguous
+    A_F32T = 1,  // fp32 source [K][M], m contiguous: converted (x in_scale) and transposed while staged
+    A_F32 = 2    // fp32 source [M][K], k contiguous, summed over nslab slabs while staged
+};
+enum EMode {
+    E_STORE_F32 = 0,  // C(slab z)[m][n] = alpha*acc          (fp32, split-K slabs)
+    E_STORE_H16 = 1,  // C[m][n] = fp16(alpha*acc)
+    E_SUB_F32 = 2     // C[m][n] -= alpha*acc  for n >= col_lo (fp32 read-modify-write)
+};
+
+struct GemmArgs {
+    const void* A;       long lda;
+    const half_t* Bt;    long ldb;
+    void* C;             long ldc;
+    int M, N, K;         // M multiple of 128 not required: rows >= M are zero-filled / not stored. K % 64 == 0.
+    int col_lo;          // E_SUB_F32: columns < col_lo are left untouched
+    float in_scale;      // A_F32T / A_F32 conversion scale
+    float alpha;
+    int nslab_in;        long slab_in_stride;    // A_F32: sum of nslab_in source slabs
+    int nsplit;          long slab_out_stride;   // E_STORE_F32: K split over gridDim.z slabs
+};
+void launch_gemm_f16(AMode am, EMode em, const GemmArgs& g, hipStream_t s);
+
+// ------------------------------------------------------------------ fp32 helper GEMM (T merges, metrics)
+// C[M x N] (ldc) = alpha * opA(A) * opB(B) + beta*C, plain fp32 FMA, any sizes.
+// slabs: A is summed over nslab_a slabs (stride slab_a) while loading.
+struct SgemmArgs {
+    const float* A; long lda; int transA;
+    const float* B; long ldb; int transB;
+    float* C; long ldc;
+    int M, N, K;
+    float alpha, beta;
+    int nslab_a; long slab_a;
+};
+void launch_sgemm(const SgemmArgs& g, hipStream_t s);
+
+// ------------------------------------------------------------------ panel (leaf) kernels
+struct LeafArgs {
+    float* A; long lda;         // internal fp32 matrix (R above, unshifted V below the diagonal)
+    int mrows;                  // rows considered (padded rows are zero)
+    int cb;                     // 32-aligned window start; leaf columns [c0, c1) lie in [cb, cb+32)
+    int c0, c1;
+    half_t* Vh; long ldvh;      // [row][reflector]
+    half_t* Vt; long ldvt;      // [reflector][row]
+    float* vdiag;               // diagonal element of each reflector
+    float* P;                   // partial dot products, 2 x maxwg x 32
+    int maxwg;
+};
+void launch_leaf_factor(const LeafArgs& a, hipStream_t s);   // all columns of the leaf, one launch per column
+
+// T of a leaf from its Gram slabs: S (64 x 64 per slab, aligned range starting at a0)
+void launch_t_leaf(const float* S, int nslab, long slab_stride, int a0, int c0, int c1,
+                   float* T, half_t* Th, half_t* Tth, int ldt, hipStream_t s);
+// assemble a parent T from its children and T_LR
+void launch_t_assemble(float* T, half_t* Th, half_t* Tth, int ldt, int A0,
+                       const float* TL, int ldl, int aL0, int c0, int cm,
+                       const float* TR, int ldr, int aR0, int c1,
+                       const float* TLR, int ldlr, hipStream_t s);
+
+// ------------------------------------------------------------------ misc kernels
+void launch_generate(float* A, long lda, int m, int n, uint64_t seed, int nglob, int block, int world, int rank,
+                     hipStream_t s);
+void launch_set_identity(float* Q, long ldq, int rows, int cols, hipStream_t s);
+void launch_pack_factor(const float* A, long lda, const float* vdiag, float* out, int m, int n, hipStream_t s);
+void launch_unpack_factor(const float* in, int m, int n, int c0, int c1, float* A, long lda, float* vdiag,
+                          half_t* Vh, long ldvh, half_t* Vt, long ldvt, hipStream_t s);
+void launch_strip_r(const float* A, long lda, float* R, int m, int n, hipStream_t s);
+void launch_colnorm_max(const float* A, long lda, int m, int n, float* out /*1*/, hipStream_t s);
+// metrics reductions: out[0] += sum (A - B)^2, out[1] += sum A^2
+void launch_diff_norms(const float* A, long lda, const float* B, long ldb, int m, int n, double* out, hipStream_t s);
+// out[0] += sum (G - I)^2, out[1] = max signed (G - I)
+void launch_gram_minus_identity(const float* G, long ldg, int m, double* out, hipStream_t s);
+void launch_lower_norm(const float* R, long ldr, int m, int n, double* out, hipStream_t s);
+
+// fp64 column-major Householder QR (C++/main.cpp path)
+void launch_qr_f64(double* A, double* Q, int m, int n, double* work, hipStream_t s);
+
+}  // namespace mpqr

@@ -1,0 +1,214 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the CPU oracle on the same inputs.
+
+Tolerances.  MPQR_PREC_FP16 rounds the GEMM operands to fp16 (11 significant bits, u = 2^-11):
+the reference's own criterion for its mixed-precision path is err <= 2^-11 * m (Cuda/qr.cu:1889)
+and the north-star bound is ||A - QR||_F/||A||_F <= 1e-3; element-wise agreement with the exact
+factors is O(u) relative in the Frobenius norm.  fp32 stages (panel, T) must agree to O(2^-23 * m).
+"""
+import numpy as np
+import pytest
+
+from conftest import REF_SWEEP
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def mp():
+    import mixedprecisionblockqr_amd as m
+    return m
+
+
+@pytest.fixture(scope="module")
+def h(mp):
+    hd = mp.Handle(0)
+    yield hd
+    hd.close()
+
+
+def relF(X, Y):
+    return np.linalg.norm(X.astype(np.float64) - Y) / max(np.linalg.norm(Y), 1e-30)
+
+
+def run_gpu(mp, h, A, r):
+    m, n = A.shape
+    Ao = np.zeros((m + 1, n), np.float32); Ao[:m] = A
+    Q = np.zeros((m, m), np.float32)
+    mp.dev_mixed_precision_block_qr(Ao, Q, m, n, r, handle=h)
+    return Ao, Q, mp.h_strip_R_from_A(Ao, m, n)
+
+
+@pytest.mark.parametrize("m,n,r", REF_SWEEP)
+def test_reference_sweep_fp16(mp, h, po, m, n, r):
+    """The 20 shapes of test_qr_by_random_matrix (Cuda/qr.cu:1761-1792), fixed seed."""
+    A = po.generate(m, n, seed=1234)
+    Ao, Q, R = run_gpu(mp, h, A, r)
+    A0, Q0, R0 = po.householder_qr(A)
+    assert np.isfinite(Ao).all() and np.isfinite(Q).all()
+    # reference pass criteria, p = 11 (qr.cu:1889-1892), evaluated by the oracle's metric code
+    mt = po.metrics(A, R, Q)
+    for key in ("backward_error", "q_error_max_signed", "lower_trapezoid"):
+        assert po.lib().orc_error_passes(mt[key], m, 11), (key, mt)
+    assert mt["backward_error_f64"] <= 1e-3, mt
+    assert mt["q_error_fro"] <= 2e-3 * np.sqrt(m) + 1e-4, mt
+    # same factors as the reference path (same signs, same reflectors)
+    assert relF(R, R0) <= 3e-3, relF(R, R0)
+    assert relF(Q, Q0) <= 3e-3, relF(Q, Q0)
+    V = po.extract_V(Ao, m, n, 0, n); V0 = po.extract_V(A0, m, n, 0, n)
+    assert relF(V, V0) <= 3e-3, relF(V, V0)
+    assert np.all(np.sign(np.diag(R)[np.abs(np.diag(R0)) > 1e-3]) == np.sign(np.diag(R0)[np.abs(np.diag(R0)) > 1e-3]))
+
+
+@pytest.mark.parametrize("m,n,go,pw", [(6, 4, 0, 4), (12, 8, 3, 5), (60, 40, 8, 16), (129, 80, 64, 16),
+                                       (300, 200, 0, 64), (600, 400, 128, 128), (97, 90, 80, 16)])
+def test_panel_householder_fp32(mp, h, po, m, n, go, pw):
+    """a-1: h_householder_qr on a panel (Cuda/qr.cu:198-293) -- pure fp32, tight tolerance."""
+    A = po.generate(m, n, seed=7) - 0.25
+    Ag = po.padded(A); Ac = po.padded(A)
+    mp.h_householder_qr(Ag, m, n, go, pw, handle=h)
+    po.lib().orc_householder_qr(Ac, m, n, go, pw)
+    tol = 4e-6 * np.sqrt(m)
+    c1 = min(n, go + pw)
+    np.testing.assert_allclose(Ag[:, go:c1], Ac[:, go:c1], atol=tol * max(1.0, np.abs(Ac).max()))
+    # columns outside the panel are untouched by the reference (qr.cu:264-280)
+    assert np.array_equal(Ag[:, :go], Ac[:, :go]) and np.array_equal(Ag[:, c1:], Ac[:, c1:])
+
+
+@pytest.mark.parametrize("m,n,go,pw", [(12, 8, 0, 8), (60, 40, 8, 16), (129, 80, 16, 48), (300, 200, 64, 128)])
+def test_wy_transform(mp, h, po, m, n, go, pw):
+    """a-2: compact-WY T and the dense Q_panel of h_wy_transform (Cuda/qr.cu:337-426)."""
+    A = po.generate(m, n, seed=9)
+    Ac = po.padded(A)
+    po.lib().orc_householder_qr(Ac, m, n, go, pw)
+    T, Qp = mp.wy_transform(Ac, m, n, go, pw, dense=True, handle=h)
+    T0 = po.compact_T(Ac, m, n, go, pw, round_v_fp16=True)     # the build's "consistent T" (fp16-rounded V)
+    Texact = po.compact_T(Ac, m, n, go, pw)
+    np.testing.assert_allclose(T, T0, atol=2e-5 * pw)
+    np.testing.assert_allclose(T, Texact, atol=3e-3)
+    Qp0 = po.wy_transform(Ac, m, n, go, pw)
+    np.testing.assert_allclose(Qp, Qp0, atol=3e-3)
+    assert np.abs(Qp.T @ Qp - np.eye(m - go)).max() < 3e-3
+
+
+@pytest.mark.parametrize("m,n", [(6, 4), (60, 40), (129, 80), (400, 300)])
+def test_q_backward_accumulation(mp, h, po, m, n):
+    """a-6: h_q_backward_accumulation (Cuda/qr.cu:296-335)."""
+    A = po.generate(m, n, seed=5)
+    A0, Q0, _ = po.householder_qr(A)
+    Q = mp.h_q_backward_accumulation(A0, m, n, handle=h)
+    assert relF(Q, Q0) <= 3e-3
+    assert np.abs(Q.T @ Q - np.eye(m)).max() < 4e-3
+
+
+@pytest.mark.parametrize("m,n,go,pw", [(60, 40, 0, 16), (129, 80, 16, 16), (300, 200, 64, 64), (600, 400, 0, 128)])
+def test_trailing_update(mp, h, po, m, n, go, pw):
+    """a-3: A[l:,tau:] <- Q_panel^T A[l:,tau:] (Cuda/mmult.cu:236-288 + qr.cu:1098-1106)."""
+    A = po.generate(m, n, seed=3)
+    Ac = po.padded(A)
+    po.lib().orc_householder_qr(Ac, m, n, go, pw)
+    Ag = Ac.copy()
+    mp.apply_panel_to_trailing(Ag, m, n, go, pw, handle=h)
+    Qp = po.wy_transform(Ac, m, n, go, pw).astype(np.float64)
+    want = Ac[:m].astype(np.float64).copy()
+    want[go:, go + pw:] = Qp.T @ want[go:, go + pw:]
+    assert relF(Ag[go:m, go + pw:], want[go:, go + pw:]) <= 2e-3
+    assert np.array_equal(Ag[:, :go + pw], Ac[:, :go + pw]) and np.array_equal(Ag[:go], Ac[:go])
+
+
+def test_metrics_match_oracle(mp, h, po):
+    """a-7: the three error metrics (Cuda/qr.cu:115-196) + ||Q^T Q - I||_F."""
+    A = po.generate(200, 120, seed=21)
+    _, Q, R = po.block_qr(A, 16, "compact16")
+    want = po.metrics(A, R, Q)
+    got = mp.qr_metrics(A, R, Q, handle=h)
+    assert abs(got["backward_error"] - want["backward_error_f64"]) <= 2e-2 * want["backward_error_f64"]
+    assert abs(got["q_error_fro"] - want["q_error_fro"]) <= 2e-2 * want["q_error_fro"]
+    assert abs(got["q_error_max_signed"] - want["q_error_max_signed"]) <= 2e-6 + 2e-2 * want["q_error_max_signed"]
+    assert got["lower_trapezoid"] == 0.0
+    assert mp.error_passes(got["backward_error"], 200, 11) and not mp.error_passes(got["backward_error"], 200, 23)
+
+
+def test_degenerate_inputs(mp, h, po, golden):
+    """python/test_data.py:38-57 + exactly-zero columns (Cuda/qr.cu:242-244): stay finite, A = QR."""
+    for name in ("rank1_3x3", "diag_3x3", "zero_rows_3x3", "int3x3_zero_lead", "int6x6", "int5x3"):
+        A = golden[f"{name}__A"].astype(np.float32)
+        Ao, Q, R = run_gpu(mp, h, A, 2)
+        assert np.isfinite(Ao).all() and np.isfinite(Q).all(), name
+        s = max(1.0, np.abs(A).max())
+        assert np.abs(Q @ R - A).max() <= 4e-3 * s, name
+        assert np.abs(Q.T @ Q - np.eye(len(A))).max() <= 4e-3, name
+    Z = np.zeros((40, 24), np.float32)
+    Ao, Q, R = run_gpu(mp, h, Z, 8)
+    assert (Ao == 0).all() and np.array_equal(Q, np.eye(40, dtype=np.float32))
+    Z[:, 5] = 0; Z[:, ::2] = po.generate(40, 12, seed=2)        # every other column exactly zero
+    Ao, Q, R = run_gpu(mp, h, Z, 8)
+    assert np.isfinite(Ao).all() and np.abs(Q @ R - Z).max() <= 4e-3
+
+
+def test_large_values_are_scaled_into_fp16_range(mp, h, po):
+    """Jacobian-like data: entries up to 1e5 would overflow fp16 (65504) without the power-of-two scale."""
+    rng = np.random.default_rng(4)
+    A = (rng.standard_normal((300, 180)) * (rng.random((300, 180)) < 0.05) * 1e5).astype(np.float32)
+    A[np.arange(180), np.arange(180)] += 3e4
+    Ao, Q, R = run_gpu(mp, h, A, 16)
+    assert np.isfinite(Ao).all() and np.isfinite(Q).all()
+    assert po.metrics(A, R, Q)["backward_error_f64"] <= 1e-3
+    A *= 1e-9                                                      # and tiny values must not flush to zero
+    Ao, Q, R = run_gpu(mp, h, A, 16)
+    assert po.metrics(A, R, Q)["backward_error_f64"] <= 1e-3
+
+
+def test_oracle_sized_block_compare_1024(mp, h, po):
+    """1024 x 1024, r = 64: element-level agreement with the oracle's fp16-emulating compact-WY loop."""
+    m = n = 1024; r = 64
+    A = po.generate(m, n, seed=1234)
+    Ao, Q, R = run_gpu(mp, h, A, r)
+    _, Q0, R0 = po.block_qr(A, r, "compact32", omp=True)
+    assert relF(R, R0) <= 2e-3 and relF(Q, Q0) <= 2e-3
+    mt = mp.qr_metrics(A, R, Q, handle=h)
+    assert mt["backward_error"] <= 1e-3 and mt["q_error_fro"] <= 2e-3 * np.sqrt(m)
+
+
+def test_config2_2048_properties(mp, h):
+    """BASELINE config 2 (2048 x 2048, r = 64) through the device-resident API: size-independent
+    properties (A = QR, Q^T Q = I, R upper triangular, repeatability)."""
+    m = n = 2048
+    h.plan(m, n, 64)
+    h.generate(1234); h.snapshot(); h.factor(); h.sync()
+    mt = h.metrics()
+    assert mt["backward_error"] <= 1e-3, mt
+    assert mt["q_error_fro"] <= 2e-3 * np.sqrt(m), mt
+    assert mt["lower_trapezoid"] == 0.0
+    R1 = h.r_matrix()
+    h.restore(); h.factor(); h.sync()
+    assert np.array_equal(R1, h.r_matrix())                        # deterministic (no atomics on the path)
+    t = h.timings()
+    assert t["ms_total"] > 0 and t["n_far_launches"] == 1
+
+
+def test_cpp_main_path_fp64(mp, h, po, golden):
+    """a-10: qr_factorization (C++/main.cpp:16-43) in fp64 on the GPU vs the real reference's outputs."""
+    for name in golden["cppmain_names"]:
+        A = golden[f"{name}__A"]
+        Q, R = mp.qr_factorization(A, handle=h)
+        np.testing.assert_allclose(Q, golden[f"cppmain__{name}__Q"], atol=1e-11, err_msg=name)
+        np.testing.assert_allclose(R, golden[f"cppmain__{name}__R"], atol=1e-9, err_msg=name)
+    A = po.generate(256, 256, seed=1234).astype(np.float64)       # BASELINE config 1
+    Q, R = mp.qr_factorization(A, handle=h)
+    np.testing.assert_allclose(np.diag(R), golden["cppmain__c1_256__diagR"], rtol=1e-9, atol=1e-9)
+    np.testing.assert_allclose(Q[:, 0], golden["cppmain__c1_256__Q_col0"], atol=1e-11)
+    assert np.linalg.norm(A - Q @ R) / np.linalg.norm(A) < 1e-13
+    Qo, Ro = po.qr_factorization_f64(A)
+    np.testing.assert_allclose(Q, Qo, atol=1e-10); np.testing.assert_allclose(R, Ro, atol=1e-9)
+
+
+def test_error_behaviour(mp, h):
+    with pytest.raises(mp.MpqrError):
+        h.plan(4, 8, 2)                                            # n > m
+    with pytest.raises(mp.MpqrError):
+        h.plan(8, 4, 0)                                            # r < 1
+    h2 = mp.Handle(0)
+    with pytest.raises(mp.MpqrError) as e:
+        h2.factor()                                                # factor before plan
+    assert e.value.code == mp._lib.ERR_STATE
+    h2.close()
