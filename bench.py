@@ -1,0 +1,121 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark: GFLOP/s of the mixed-precision block QR (A -> Q, R) on MI355X.
+
+Workload (BASELINE.json configs[3], the configuration the metric's targets are quoted on): 16384 x 16384
+uniform random fp32 matrix, panel width 128, fp32 panel + fp16-operand/fp32-accumulate MFMA trailing update,
+full m x m Q formed (the reference's matrix-in / Q,R-out contract).  One "step" = restore the input from its
+HBM snapshot + factor + form Q.  value = (2 m n^2 - 2/3 n^3) / step time, i.e. GEQRF-equivalent flops only
+(the Q-formation flops are NOT counted, so the figure is conservative); see DESIGN.md "Measurement".
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--config c4|c2|c1]
+For N > 1 the driver launches this file under torch.distributed.run, one rank per GPU.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+CONFIGS = {  # name: (m, n, r)
+    "c1": (256, 256, 32), "c2": (2048, 2048, 64), "c4": (16384, 16384, 128), "c5": (65536, 8192, 256),
+}
+PEAK_FP16_TFLOPS = 2500.0      # MI355X dense fp16 MFMA (MI355X_MICROARCH.md, chip-level parameters)
+
+
+def cpu_baseline(budget_s=20.0):
+    """The CPU oracle's compact-WY block loop (oracle/oracle_qr.c, OpenMP over trailing columns) timed on this
+    box's host cores on a bounded sample of the same workload family: 2048 x 2048, r = 64."""
+    import numpy as np
+    from oracle import pyoracle as po
+    import mixedprecisionblockqr_amd as mp
+    m = n = 2048; r = 64
+    cores = len(os.sched_getaffinity(0))
+    os.environ.setdefault("OMP_NUM_THREADS", str(cores))
+    A = po.generate(m, n, seed=1234)
+    Ao = po.padded(A); Q = np.eye(m, dtype=np.float32)
+    t0 = time.perf_counter()
+    po.lib(omp=True).orc_block_qr_compact(Ao, Q, m, n, r, 0)
+    dt = time.perf_counter() - t0
+    return {"value": mp.flops(m, n, r)["geqrf"] / dt / 1e9, "unit": "GFLOP/s", "cores": cores, "kind": "port",
+            "sample": f"{m}x{n} r={r} fp32 compact-WY block loop incl. Q formation, {dt:.1f} s, GEQRF-equivalent flops"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--config", default="c4", choices=sorted(CONFIGS))
+    ap.add_argument("--outer-block", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import mixedprecisionblockqr_amd as mp
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    m, n, r = CONFIGS[args.config]
+    if world > 1:
+        from mixedprecisionblockqr_amd import dist as mpdist
+        return mpdist.bench_main(args, m, n, r, world, rank, local_rank)
+
+    torch.cuda.set_device(0)
+    h = mp.Handle(0)
+    h.plan(m, n, r, outer_block=args.outer_block)
+    h.generate(1234)
+    h.snapshot()
+    h.sync()
+
+    def step():
+        h.restore()
+        h.factor()
+
+    for _ in range(args.warmup):
+        step()
+    h.sync(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    h.sync(); torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / args.steps
+
+    fl = mp.flops(m, n, r)
+    tm = h.timings()                      # HIP-event timings of the LAST step, on the library's own stream
+    mt = h.metrics()
+    # dominant kernel: the far trailing-update GEMM  A2 -= V Y^T  (fp16 MFMA, K = outer block)
+    nn_t = tm["ms_far_nn"] * 1e-3
+    roof = None
+    if tm["n_far_launches"] > 0 and nn_t > 0:
+        ach = tm["flops_far_nn"] / nn_t / 1e12
+        roof = {"bound": "mfma", "kernel": "gemm_f16_kernel<A_H16,E_SUB_F32> (far A2 -= V*Y^T)",
+                "achieved": ach, "peak": PEAK_FP16_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_FP16_TFLOPS,
+                "traffic": None, "launches": tm["n_far_launches"],
+                "avg_launch_ms": tm["ms_far_nn"] / tm["n_far_launches"],
+                "tn_achieved": (tm["flops_far_tn"] / (tm["ms_far_tn"] * 1e-3) / 1e12) if tm["ms_far_tn"] > 0 else None}
+    out = {
+        "metric": "GFLOP/s block QR (fp16 MFMA trailing)", "value": fl["geqrf"] / dt / 1e9, "unit": "GFLOP/s",
+        "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt * 1e3,
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f16xf16->f32 (fp32 panel)",
+        "data": "synthetic U[0,1) fp32, seed 1234",
+        "config": {"workload": f"{m}x{n} random dense, block={r}, full Q formed", "m": m, "n": n, "block": r,
+                   "outer_block": args.outer_block or 1024, "parallelism": "1 gpu"},
+        "error": {"backward_error": mt["backward_error"], "q_error_fro": mt["q_error_fro"],
+                  "q_error_max_signed": mt["q_error_max_signed"]},
+        "breakdown_ms": {k: tm[k] for k in ("ms_total", "ms_factor", "ms_form_q", "ms_trailing", "ms_panel",
+                                            "ms_far_tn", "ms_far_nn")},
+        "gflops_with_q_flops": (fl["geqrf"] + fl["form_q"]) / dt / 1e9,
+        "gflops_reference_formula": (4.0 * m * m * n - m * n * n + n ** 3 / 3.0) / dt / 1e9,
+        "roofline": roof,
+    }
+    if not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline()
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

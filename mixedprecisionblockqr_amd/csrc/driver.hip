@@ -265,11 +265,13 @@ void factor_node(mpqr_handle_t h, int id, bool do_panel) {
     s1.A = h->S; s1.lda = R.ldt; s1.transA = 0; s1.nslab_a = nslab; s1.slab_a = slab;
     s1.B = h->Tf + R.toff; s1.ldb = R.ldt; s1.transB = 0;
     s1.C = h->tmp1; s1.ldc = R.ldt; s1.M = L.ldt; s1.N = R.ldt; s1.K = R.ldt; s1.alpha = 1.f; s1.beta = 0.f;
+    s1.upperB = 1;
     launch_sgemm(s1, h->s0);
     SgemmArgs s2{};
     s2.A = h->Tf + L.toff; s2.lda = L.ldt; s2.transA = 0; s2.nslab_a = 1;
     s2.B = h->tmp1; s2.ldb = R.ldt; s2.transB = 0;
     s2.C = h->tmp2; s2.ldc = R.ldt; s2.M = L.ldt; s2.N = R.ldt; s2.K = L.ldt; s2.alpha = -1.f; s2.beta = 0.f;
+    s2.upperA = 1;
     launch_sgemm(s2, h->s0);
     launch_t_assemble(h->Tf + nd.toff, h->Th + nd.toff, h->Tth + nd.toff, nd.ldt, nd.a0, h->Tf + L.toff, L.ldt, L.a0,
                       nd.c0, L.c1, h->Tf + R.toff, R.ldt, R.a0, nd.c1, h->tmp2, R.ldt, h->s0);
@@ -282,18 +284,18 @@ int clear_reflectors(mpqr_handle_t h) {
     return MPQR_OK;
 }
 
-// power-of-two scale that brings the largest column norm to ~2^8, so fp16 operands stay in range
+// power-of-two scale so that fp16 operands stay in range (and out of the subnormal range): column norms are
+// bounded by sqrt(m) max|a|, which the scale brings to [2^7, 2^8)
 int compute_scale(mpqr_handle_t h) {
-    launch_colnorm_max(h->dA, h->lda, h->m, h->n, h->dscalar, h->s0);
-    float mx2 = 0.f;
-    HIPCHK(h, hipMemcpyAsync(&mx2, h->dscalar, sizeof(float), hipMemcpyDeviceToHost, h->s0));
+    launch_absmax(h->dA, h->lda, h->m, h->n, h->dscalar, h->s0);
+    float mx = 0.f;
+    HIPCHK(h, hipMemcpyAsync(&mx, h->dscalar, sizeof(float), hipMemcpyDeviceToHost, h->s0));
     HIPCHK(h, hipStreamSynchronize(h->s0));
     float s = 1.f;
-    if (mx2 > 0.f && std::isfinite(mx2)) {
-        const float nrm = sqrtf(mx2);
-        int e; frexpf(nrm, &e);              // nrm = f * 2^e, f in [0.5,1)
-        s = ldexpf(1.f, 8 - e);
-        if (nrm <= 256.f && nrm >= 1.f / 256.f) s = 1.f;   // already comfortable: keep data untouched
+    if (mx > 0.f && std::isfinite(mx)) {
+        const float nrm = mx * sqrtf((float)h->m);
+        int e; frexpf(nrm, &e);                  // nrm = f * 2^e, f in [0.5,1)
+        s = ldexpf(1.f, 8 - e);                  // exact power of two: scaling itself adds no rounding
     }
     h->a_scale = s;
     return MPQR_OK;

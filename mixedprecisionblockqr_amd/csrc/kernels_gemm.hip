@@ -221,62 +221,134 @@ void launch_gemm_f16(AMode am, EMode em, const GemmArgs& g, hipStream_t s) {
 #undef MPQR_CASE
 }
 
-// ------------------------------------------------------------------ plain fp32 GEMM (small T merges, metrics)
-// 64 x 64 tile, 256 threads, 4 x 4 outputs per thread, K step 16.  Exact-f32 FMA chain.
-constexpr int SB = 64, SK = 16;
-__global__ __launch_bounds__(256) void sgemm_kernel(SgemmArgs g) {
-    __shared__ float As[SK][SB + 4];
-    __shared__ float Bs[SK][SB + 4];
-    const int tid = threadIdx.x;
-    const int tx = tid & 15, ty = tid >> 4;
-    const int bm = blockIdx.y * SB, bn = blockIdx.x * SB;
-    float acc[4][4] = {};
-    for (int k0 = 0; k0 < g.K; k0 += SK) {
-        // A tile: SB(m) x SK(k); element (m,k) = transA ? A[k][m] : A[m][k]
-        for (int e = tid; e < SB * SK; e += 256) {
-            int mm, kk;
-            if (g.transA) { mm = e % SB; kk = e / SB; } else { kk = e % SK; mm = e / SK; }
-            int gm = bm + mm, gk = k0 + kk;
-            float v = 0.f;
-            if (gm < g.M && gk < g.K) {
-                const float* p = g.transA ? g.A + (long)gk * g.lda + gm : g.A + (long)gm * g.lda + gk;
-                for (int sl = 0; sl < g.nslab_a; sl++) v += p[(long)sl * g.slab_a];
+// ------------------------------------------------------------------ exact-f32 MFMA GEMM (T merges, metrics, fp32 mode)
+// C[M x N] = alpha * op(A) * op(B) + beta * C on v_mfma_f32_32x32x2_f32: f32 in, f32 accumulate, bit-exact
+// fmaf chain (no reduced-precision step), at the f32 vector peak.  Tile TB x TB x 16, 256 threads = 4 waves
+// (2 x 2), LDS images k-major (As[k][m], Bs[k][n]) so every fragment read is a conflict-free ds_read_b32.
+constexpr int SK = 16;
+
+template <int TB>
+__global__ __launch_bounds__(256) void sgemm_mfma_kernel(SgemmArgs g) {
+    constexpr int LDT = TB + 4;
+    constexpr int NT = TB / 64;                 // 32x32 MFMA tiles per wave per dimension
+    constexpr int NL = TB * SK / 4 / 256;       // float4 loads per thread per operand
+    __shared__ __attribute__((aligned(16))) float As[SK][LDT];
+    __shared__ __attribute__((aligned(16))) float Bs[SK][LDT];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int bm = blockIdx.y * TB, bn = blockIdx.x * TB;
+    const int wm = (wave >> 1) * (TB / 2), wn = (wave & 1) * (TB / 2);
+
+    int k_lo = 0, k_hi = g.K;
+    if (g.upperA) k_lo = (bm / SK) * SK;                  // op(A)[i][k] = 0 for k < i
+    if (g.upperB) k_hi = min(g.K, bn + TB);               // op(B)[k][j] = 0 for k > j
+
+    const bool a_vec = ((g.lda & 3) == 0) && ((((uintptr_t)g.A) & 15) == 0) && ((g.slab_a & 3) == 0);
+    const bool b_vec = ((g.ldb & 3) == 0) && ((((uintptr_t)g.B) & 15) == 0);
+
+    float4 ra[NL], rb[NL];
+    // operand element (row index x in [0,TB), k) ; "kcontig": storage [x][k] (k contiguous) else [k][x]
+    auto load_op = [&](const float* P, long ld, bool kcontig, int x0, int xmax, int k0, bool vec, int nslab, long slab,
+                       float4* reg) {
+#pragma unroll
+        for (int i = 0; i < NL; i++) {
+            const int id = tid + 256 * i;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (kcontig) {
+                const int x = id >> 2, kq = (id & 3) * 4;
+                const int gx = x0 + x, gk = k0 + kq;
+                if (gx < xmax) {
+                    const float* p = P + (long)gx * ld + gk;
+                    for (int sl = 0; sl < nslab; sl++, p += slab) {
+                        if (vec && gk + 3 < g.K) { const float4 t = *(const float4*)p; v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w; }
+                        else {
+                            if (gk + 0 < g.K) v.x += p[0]; if (gk + 1 < g.K) v.y += p[1];
+                            if (gk + 2 < g.K) v.z += p[2]; if (gk + 3 < g.K) v.w += p[3];
+                        }
+                    }
+                }
+            } else {
+                const int kk = id / (TB / 4), xq = (id % (TB / 4)) * 4;
+                const int gk = k0 + kk, gx = x0 + xq;
+                if (gk < g.K) {
+                    const float* p = P + (long)gk * ld + gx;
+                    for (int sl = 0; sl < nslab; sl++, p += slab) {
+                        if (vec && gx + 3 < xmax) { const float4 t = *(const float4*)p; v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w; }
+                        else {
+                            if (gx + 0 < xmax) v.x += p[0]; if (gx + 1 < xmax) v.y += p[1];
+                            if (gx + 2 < xmax) v.z += p[2]; if (gx + 3 < xmax) v.w += p[3];
+                        }
+                    }
+                }
             }
-            As[kk][mm] = v;
+            reg[i] = v;
         }
-        for (int e = tid; e < SB * SK; e += 256) {
-            int nn, kk;
-            if (g.transB) { kk = e % SK; nn = e / SK; } else { nn = e % SB; kk = e / SB; }
-            int gn = bn + nn, gk = k0 + kk;
-            float v = 0.f;
-            if (gn < g.N && gk < g.K) v = g.transB ? g.B[(long)gn * g.ldb + gk] : g.B[(long)gk * g.ldb + gn];
-            Bs[kk][nn] = v;
+    };
+    auto store_op = [&](float (*Ls)[LDT], bool kcontig, const float4* reg) {
+#pragma unroll
+        for (int i = 0; i < NL; i++) {
+            const int id = tid + 256 * i;
+            if (kcontig) {
+                const int x = id >> 2, kq = (id & 3) * 4;
+                Ls[kq + 0][x] = reg[i].x; Ls[kq + 1][x] = reg[i].y; Ls[kq + 2][x] = reg[i].z; Ls[kq + 3][x] = reg[i].w;
+            } else {
+                const int kk = id / (TB / 4), xq = (id % (TB / 4)) * 4;
+                *(float4*)&Ls[kk][xq] = reg[i];
+            }
         }
+    };
+
+    floatx16 acc[NT][NT];
+#pragma unroll
+    for (int i = 0; i < NT; i++)
+#pragma unroll
+        for (int j = 0; j < NT; j++)
+#pragma unroll
+            for (int e = 0; e < 16; e++) acc[i][j][e] = 0.f;
+
+    const bool a_kc = !g.transA, b_kc = g.transB;
+    if (k_lo < k_hi) {
+        load_op(g.A, g.lda, a_kc, bm, g.M, k_lo, a_vec, g.nslab_a, g.slab_a, ra);
+        load_op(g.B, g.ldb, b_kc, bn, g.N, k_lo, b_vec, 1, 0, rb);
+        store_op(As, a_kc, ra); store_op(Bs, b_kc, rb);
         __syncthreads();
+        for (int k0 = k_lo; k0 < k_hi; k0 += SK) {
+            const bool more = k0 + SK < k_hi;
+            if (more) {
+                load_op(g.A, g.lda, a_kc, bm, g.M, k0 + SK, a_vec, g.nslab_a, g.slab_a, ra);
+                load_op(g.B, g.ldb, b_kc, bn, g.N, k0 + SK, b_vec, 1, 0, rb);
+            }
 #pragma unroll
-        for (int kk = 0; kk < SK; kk++) {
-            float a[4], b[4];
+            for (int ks = 0; ks < SK / 2; ks++) {
+                float a[NT], b[NT];
+                const int kr = ks * 2 + (lane >> 5);
 #pragma unroll
-            for (int i = 0; i < 4; i++) a[i] = As[kk][ty * 4 + i];
+                for (int i = 0; i < NT; i++) a[i] = As[kr][wm + i * 32 + (lane & 31)];
 #pragma unroll
-            for (int j = 0; j < 4; j++) b[j] = Bs[kk][tx * 4 + j];
+                for (int j = 0; j < NT; j++) b[j] = Bs[kr][wn + j * 32 + (lane & 31)];
 #pragma unroll
-            for (int i = 0; i < 4; i++)
+                for (int i = 0; i < NT; i++)
 #pragma unroll
-                for (int j = 0; j < 4; j++) acc[i][j] = fmaf(a[i], b[j], acc[i][j]);
+                    for (int j = 0; j < NT; j++)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+            }
+            __syncthreads();
+            if (more) { store_op(As, a_kc, ra); store_op(Bs, b_kc, rb); __syncthreads(); }
         }
-        __syncthreads();
     }
 #pragma unroll
-    for (int i = 0; i < 4; i++)
+    for (int i = 0; i < NT; i++)
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
-            int m = bm + ty * 4 + i, n = bn + tx * 4 + j;
-            if (m < g.M && n < g.N) {
-                float* p = g.C + (long)m * g.ldc + n;
-                float v = g.alpha * acc[i][j];
-                if (g.beta != 0.f) v += g.beta * (*p);
-                *p = v;
+        for (int j = 0; j < NT; j++) {
+            const int n = bn + wn + j * 32 + (lane & 31);
+#pragma unroll
+            for (int e = 0; e < 16; e++) {
+                const int m = bm + wm + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+                if (m < g.M && n < g.N) {
+                    float* p = g.C + (long)m * g.ldc + n;
+                    float v = g.alpha * acc[i][j][e];
+                    if (g.beta != 0.f) v += g.beta * (*p);
+                    *p = v;
+                }
             }
         }
 }
@@ -285,8 +357,14 @@ void launch_sgemm(const SgemmArgs& g, hipStream_t s) {
     if (g.M <= 0 || g.N <= 0) return;
     SgemmArgs a = g;
     if (a.nslab_a < 1) a.nslab_a = 1;
-    dim3 grid((g.N + SB - 1) / SB, (g.M + SB - 1) / SB);
-    hipLaunchKernelGGL(sgemm_kernel, grid, dim3(256), 0, s, a);
+    const long tiles128 = (long)((g.M + 127) / 128) * ((g.N + 127) / 128);
+    if (tiles128 >= 256) {
+        dim3 grid((g.N + 127) / 128, (g.M + 127) / 128);
+        hipLaunchKernelGGL(sgemm_mfma_kernel<128>, grid, dim3(256), 0, s, a);
+    } else {
+        dim3 grid((g.N + 63) / 64, (g.M + 63) / 64);
+        hipLaunchKernelGGL(sgemm_mfma_kernel<64>, grid, dim3(256), 0, s, a);
+    }
 }
 
 }  // namespace mpqr

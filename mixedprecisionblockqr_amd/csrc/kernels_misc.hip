@@ -115,18 +115,20 @@ __device__ __forceinline__ float wave_max(float v) {
     return v;
 }
 
-// out[0] = max over columns of sum_i A[i][j]^2 (squared), via atomicMax on the float bits (values >= 0)
-__global__ void colnorm_max_kernel(const float* A, long lda, int m, int n, float* out) {
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
-    float s = 0.f;
-    if (j < n)
-        for (int i = 0; i < m; i++) { const float v = A[(long)i * lda + j]; s += v * v; }
-    s = wave_max(s);
-    if ((threadIdx.x & 63) == 0) atomicMax((unsigned int*)out, __float_as_uint(s));
+// out[0] = max |A[i][j]| (bit pattern; values >= 0 so uint order == float order)
+__global__ void absmax_kernel(const float* A, long lda, int m, int n, float* out) {
+    float mx = 0.f;
+    const long tot = (long)m * n;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < tot; e += (long)gridDim.x * blockDim.x) {
+        const int r = (int)(e / n), c = (int)(e % n);
+        mx = fmaxf(mx, fabsf(A[(long)r * lda + c]));
+    }
+    mx = wave_max(mx);
+    if ((threadIdx.x & 63) == 0) atomicMax((unsigned int*)out, __float_as_uint(mx));
 }
-void launch_colnorm_max(const float* A, long lda, int m, int n, float* out, hipStream_t s) {
+void launch_absmax(const float* A, long lda, int m, int n, float* out, hipStream_t s) {
     (void)hipMemsetAsync(out, 0, sizeof(float), s);
-    hipLaunchKernelGGL(colnorm_max_kernel, dim3((n + 255) / 256), dim3(256), 0, s, A, lda, m, n, out);
+    hipLaunchKernelGGL(absmax_kernel, dim3(2048), dim3(256), 0, s, A, lda, m, n, out);
 }
 
 // out[0] += sum (A-B)^2 ; out[1] += sum A^2   (double accumulation)

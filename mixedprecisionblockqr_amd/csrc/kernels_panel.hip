@@ -148,8 +148,137 @@ __global__ __launch_bounds__(256) void leaf_step_kernel(LeafArgs a, int k, int n
     if (tid < 32) Pout[blockIdx.x * 32 + tid] = sh_part[0][tid] + sh_part[1][tid] + sh_part[2][tid] + sh_part[3][tid];
 }
 
+// ------------------------------------------------------------------ whole leaf in one workgroup
+// Panels of at most 128*RPT rows: the leaf (rows >= c0, the 32-column window) lives in the registers of
+// one 1024-thread workgroup (128 row lanes x 8 column groups, RPT rows per thread).  Same arithmetic as
+// leaf_step_kernel, but the per-column reduction stays on chip (wave shuffles + one LDS hop), so a leaf
+// costs one launch instead of 33.
+template <int RPT>
+__global__ __launch_bounds__(1024) void leaf_wg_kernel(LeafArgs a) {
+    __shared__ float sh_part[16][32];
+    __shared__ float sh_s[2][32], sh_rowk[2][32], sh_vd[32];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int cg = tid & 7, rl = tid >> 3;
+    const int row0 = a.c0;
+    if (tid < 32) sh_vd[tid] = 0.f;
+    float4 v[RPT];
+#pragma unroll
+    for (int p = 0; p < RPT; p++) {
+        const int row = row0 + p * 128 + rl;
+        v[p] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (row < a.mrows) v[p] = *(const float4*)(a.A + (long)row * a.lda + a.cb + 4 * cg);
+    }
+    float pacc[4] = {0.f, 0.f, 0.f, 0.f};
+    {
+        const int kq = a.c0 - a.cb;
+#pragma unroll
+        for (int p = 0; p < RPT; p++) {
+            const float aik = __shfl(pick(v[p], kq & 3), (lane & ~7) | (kq >> 2));
+            pacc[0] += aik * v[p].x; pacc[1] += aik * v[p].y; pacc[2] += aik * v[p].z; pacc[3] += aik * v[p].w;
+        }
+    }
+    for (int k = a.c0; k < a.c1; k++) {
+        const int kq = k - a.cb, par = k & 1;
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+            float s = pacc[c];
+            s += __shfl_xor(s, 8); s += __shfl_xor(s, 16); s += __shfl_xor(s, 32);
+            pacc[c] = s;
+        }
+        if (lane < 8) {
+#pragma unroll
+            for (int c = 0; c < 4; c++) sh_part[wave][lane * 4 + c] = pacc[c];
+        }
+#pragma unroll
+        for (int p = 0; p < RPT; p++)
+            if (row0 + p * 128 + rl == k) *(float4*)&sh_rowk[par][4 * cg] = v[p];
+        __syncthreads();
+        if (tid < 32) {
+            float s = 0.f;
+#pragma unroll
+            for (int q = 0; q < 16; q++) s += sh_part[q][tid];
+            sh_s[par][tid] = s;
+        }
+        __syncthreads();
+        const float sk = sh_s[par][kq], akk = sh_rowk[par][kq];
+        float alpha = 0.f, inv = 0.f;
+        if (sk != 0.f) {
+            const float nu = sqrtf(sk);
+            alpha = (akk >= 0.f) ? nu : -nu;
+            inv = 1.0f / sqrtf(2.0f * (sk + fabsf(akk) * nu));
+        }
+        float w[4];
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+            const int j = 4 * cg + c, gj = a.cb + j;
+            w[c] = (gj > k && gj < a.c1) ? 2.0f * (sh_s[par][j] + alpha * sh_rowk[par][j]) * inv : 0.f;
+        }
+        const int kn = k + 1;
+        const bool have_next = kn < a.c1;
+        const int knq = have_next ? kn - a.cb : kq;
+        const bool own_k = (cg == (kq >> 2));
+        pacc[0] = pacc[1] = pacc[2] = pacc[3] = 0.f;
+        const int d = k - row0 - rl;                 // slot p holds row k iff p*128 == d
+        const int src_k = (lane & ~7) | (kq >> 2), src_n = (lane & ~7) | (knq >> 2);
+        const int ck = kq & 3, cn = knq & 3;
+#pragma unroll
+        for (int p = 0; p < RPT; p++) {
+            const float aik = __shfl(pick(v[p], ck), src_k);
+            const float vi = (p * 128 >= d) ? (aik + (p * 128 == d ? alpha : 0.f)) * inv : 0.f;
+            v[p].x -= vi * w[0]; v[p].y -= vi * w[1]; v[p].z -= vi * w[2]; v[p].w -= vi * w[3];
+            if (own_k && p * 128 >= d && sk != 0.f) {
+                const float nv = (p * 128 == d) ? -alpha : vi;
+                if (ck == 0) v[p].x = nv; else if (ck == 1) v[p].y = nv; else if (ck == 2) v[p].z = nv; else v[p].w = nv;
+            }
+            if (own_k && p * 128 == d) sh_vd[kq] = vi;
+            const float aikn = __shfl(pick(v[p], cn), src_n);
+            if (have_next && p * 128 > d) {
+                pacc[0] += aikn * v[p].x; pacc[1] += aikn * v[p].y; pacc[2] += aikn * v[p].z; pacc[3] += aikn * v[p].w;
+            }
+            if ((p & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    __syncthreads();
+    if (tid < 32) {
+        const int k = a.cb + tid;
+        if (k >= a.c0 && k < a.c1 && k < a.mrows) {
+            const float vd = sh_vd[tid];
+            a.vdiag[k] = vd;
+            a.Vh[(long)k * a.ldvh + k] = (half_t)vd;
+            a.Vt[(long)k * a.ldvt + k] = (half_t)vd;
+        }
+    }
+    // write back: A (R above the diagonal, reflectors below), fp16 copies of the reflectors
+#pragma unroll
+    for (int p = 0; p < RPT; p++) {
+        const int row = row0 + p * 128 + rl;
+        if (row < a.mrows) {
+            *(float4*)(a.A + (long)row * a.lda + a.cb + 4 * cg) = v[p];
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+                const int gc = a.cb + 4 * cg + c;
+                if (gc >= a.c0 && gc < a.c1 && row > gc) {
+                    const half_t hv = (half_t)pick(v[p], c);
+                    a.Vh[(long)row * a.ldvh + gc] = hv;
+                    a.Vt[(long)gc * a.ldvt + row] = hv;
+                }
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
 void launch_leaf_factor(const LeafArgs& a, hipStream_t s) {
     if (a.c1 <= a.c0) return;
+    const int rows = a.mrows - a.c0;
+    if (rows <= 2048) {
+        if (rows <= 128) hipLaunchKernelGGL(leaf_wg_kernel<1>, dim3(1), dim3(1024), 0, s, a);
+        else if (rows <= 256) hipLaunchKernelGGL(leaf_wg_kernel<2>, dim3(1), dim3(1024), 0, s, a);
+        else if (rows <= 512) hipLaunchKernelGGL(leaf_wg_kernel<4>, dim3(1), dim3(1024), 0, s, a);
+        else if (rows <= 1024) hipLaunchKernelGGL(leaf_wg_kernel<8>, dim3(1), dim3(1024), 0, s, a);
+        else hipLaunchKernelGGL(leaf_wg_kernel<16>, dim3(1), dim3(1024), 0, s, a);
+        return;
+    }
     float* P0 = a.P;
     float* P1 = a.P + (long)a.maxwg * 32;
     int nwg = (a.mrows - a.c0 + RPW - 1) / RPW;
@@ -169,22 +298,23 @@ void launch_leaf_factor(const LeafArgs& a, hipStream_t s) {
 // T^{-1} = striu(V^T V) + diag(V^T V)/2  (compact WY with H_i = I - (2/v_i^T v_i) v_i v_i^T), so
 // T_ii = 2/S_ii and T[:i,i] = -T_ii T[:i,:i] S[:i,i].  S is the Gram matrix of the fp16-ROUNDED
 // reflectors, which keeps I - V T V^T orthogonal for the V the MFMA GEMMs actually multiply with.
-__global__ __launch_bounds__(64) void t_leaf_kernel(const float* __restrict__ S, int nslab, long slab_stride, int a0,
-                                                    int c0, int c1, float* __restrict__ T, half_t* __restrict__ Th,
-                                                    half_t* __restrict__ Tth, int ldt) {
+__global__ __launch_bounds__(1024) void t_leaf_kernel(const float* __restrict__ S, int nslab, long slab_stride, int a0,
+                                                      int c0, int c1, float* __restrict__ T, half_t* __restrict__ Th,
+                                                      half_t* __restrict__ Tth, int ldt) {
     __shared__ float Ss[32][33];
     __shared__ float Ts[32][33];
     const int tid = threadIdx.x;
     const int w = c1 - c0, off = c0 - a0;
-    for (int e = tid; e < 32 * 32; e += 64) {
-        const int i = e >> 5, j = e & 31;
+    {
+        const int i = tid >> 5, j = tid & 31;          // one thread per Gram entry, slabs summed in order
         float v = 0.f;
-        if (i < w && j < w)
+        if (i < w && j < w && j >= i)
             for (int sl = 0; sl < nslab; sl++) v += S[(long)sl * slab_stride + (long)(off + i) * 64 + off + j];
         Ss[i][j] = v;
         Ts[i][j] = 0.f;
     }
     __syncthreads();
+    // column recurrence (rows a < i in parallel), LDS only
     for (int i = 0; i < w; i++) {
         const float sii = Ss[i][i];
         const float tii = sii > 0.f ? 2.0f / sii : 0.f;
@@ -197,7 +327,7 @@ __global__ __launch_bounds__(64) void t_leaf_kernel(const float* __restrict__ S,
         }
         __syncthreads();
     }
-    for (int e = tid; e < ldt * ldt; e += 64) {
+    for (int e = tid; e < ldt * ldt; e += 1024) {
         const int i = e / ldt, j = e % ldt;
         const int li = i - off, lj = j - off;
         float v = 0.f;
@@ -210,7 +340,7 @@ __global__ __launch_bounds__(64) void t_leaf_kernel(const float* __restrict__ S,
 
 void launch_t_leaf(const float* S, int nslab, long slab_stride, int a0, int c0, int c1, float* T, half_t* Th,
                    half_t* Tth, int ldt, hipStream_t s) {
-    hipLaunchKernelGGL(t_leaf_kernel, dim3(1), dim3(64), 0, s, S, nslab, slab_stride, a0, c0, c1, T, Th, Tth, ldt);
+    hipLaunchKernelGGL(t_leaf_kernel, dim3(1), dim3(1024), 0, s, S, nslab, slab_stride, a0, c0, c1, T, Th, Tth, ldt);
 }
 
 // parent T = [[T_L, T_LR], [0, T_R]] placed inside the parent's 64-aligned reflector range

@@ -47,6 +47,7 @@ struct SgemmArgs {
     int M, N, K;
     float alpha, beta;
     int nslab_a; long slab_a;
+    int upperA, upperB;   // operand is upper triangular (op(A)[i][k]=0 for k<i / op(B)[k][j]=0 for k>j): zero K tiles skipped
 };
 void launch_sgemm(const SgemmArgs& g, hipStream_t s);
 
@@ -81,7 +82,7 @@ void launch_pack_factor(const float* A, long lda, const float* vdiag, float* out
 void launch_unpack_factor(const float* in, int m, int n, int c0, int c1, float* A, long lda, float* vdiag,
                           half_t* Vh, long ldvh, half_t* Vt, long ldvt, hipStream_t s);
 void launch_strip_r(const float* A, long lda, float* R, int m, int n, hipStream_t s);
-void launch_colnorm_max(const float* A, long lda, int m, int n, float* out /*1*/, hipStream_t s);
+void launch_absmax(const float* A, long lda, int m, int n, float* out /*1*/, hipStream_t s);
 // metrics reductions: out[0] += sum (A - B)^2, out[1] += sum A^2
 void launch_diff_norms(const float* A, long lda, const float* B, long ldb, int m, int n, double* out, hipStream_t s);
 // out[0] += sum (G - I)^2, out[1] = max signed (G - I)
