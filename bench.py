@@ -3,8 +3,8 @@
 
 Workload (BASELINE.json configs[3], the configuration the metric's targets are quoted on): 16384 x 16384
 uniform random fp32 matrix, panel width 128, fp32 panel + fp16-operand/fp32-accumulate MFMA trailing update,
-full m x m Q formed (the reference's matrix-in / Q,R-out contract).  One "step" = restore the input from its
-HBM snapshot + factor + form Q.  value = (2 m n^2 - 2/3 n^3) / step time, i.e. GEQRF-equivalent flops only
+full m x m Q formed (the reference's matrix-in / Q,R-out contract).  One "step" = copy the HBM-resident input
+into the working matrix + factor + form Q.  value = (2 m n^2 - 2/3 n^3) / step time, i.e. GEQRF-equivalent flops only
 (the Q-formation flops are NOT counted, so the figure is conservative); see DESIGN.md "Measurement".
 
   python bench.py [--gpus N] [--steps K] [--warmup W] [--config c4|c2|c1]
@@ -68,12 +68,10 @@ def main():
     h = mp.Handle(0)
     h.plan(m, n, r, outer_block=args.outer_block)
     h.generate(1234)
-    h.snapshot()
     h.sync()
 
     def step():
-        h.restore()
-        h.factor()
+        h.factor()        # copies the retained input into the working matrix, factors, forms Q
 
     for _ in range(args.warmup):
         step()

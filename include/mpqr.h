@@ -111,10 +111,9 @@ int mpqr_set_matrix_device(mpqr_handle_t h, const float* dA, long ld);
 /* U[0,1) synthetic input generated on the device; bit-identical to the oracle's
  * generator (replaces h_generate_random_matrix<float>, Cuda/mmult.cuh:38-64, with a fixed seed) */
 int mpqr_generate_matrix(mpqr_handle_t h, uint64_t seed);
-/* keep / restore a pristine device copy of the input (benchmark loops factor in place) */
-int mpqr_snapshot_input(mpqr_handle_t h);
-int mpqr_restore_input(mpqr_handle_t h);
-/* A -> R,V in place then (if form_q) Q; asynchronous on the handle's streams */
+/* Factor the loaded input: copy it into the working matrix (the input itself is kept in HBM, so the call
+ * can be repeated and the metrics can be evaluated), A -> R,V, then (if form_q) Q.  The factorisation is
+ * complete when the call returns; Q formation may still be running on the handle's stream. */
 int mpqr_factor(mpqr_handle_t h);
 int mpqr_sync(mpqr_handle_t h);
 int mpqr_get_timings(mpqr_handle_t h, mpqr_timings* t);
@@ -122,7 +121,7 @@ int mpqr_get_timings(mpqr_handle_t h, mpqr_timings* t);
 int mpqr_get_factor_host(mpqr_handle_t h, float* A_out);
 int mpqr_get_q_host(mpqr_handle_t h, float* Q);
 int mpqr_get_r_host(mpqr_handle_t h, float* R);      /* m x n, strict lower part zero: h_strip_R_from_A qr.cu:85-100 */
-/* three metrics of the reference's testers, computed on the device against the snapshot */
+/* three metrics of the reference's testers, computed on the device against the retained input */
 int mpqr_metrics_device(mpqr_handle_t h, mpqr_metrics* out);
 
 /* ---------------- stage-level entry points (parity tests) ---------------- */

@@ -59,8 +59,6 @@ SIGNATURES = {
     "mpqr_set_matrix_host": (_i, [_H, _f32, _l]),
     "mpqr_set_matrix_device": (_i, [_H, _p, _l]),
     "mpqr_generate_matrix": (_i, [_H, C.c_uint64]),
-    "mpqr_snapshot_input": (_i, [_H]),
-    "mpqr_restore_input": (_i, [_H]),
     "mpqr_factor": (_i, [_H]),
     "mpqr_sync": (_i, [_H]),
     "mpqr_get_timings": (_i, [_H, C.POINTER(MpqrTimings)]),

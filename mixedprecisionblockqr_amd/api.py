@@ -65,12 +65,6 @@ class Handle:
     def generate(self, seed=1234):
         self._chk(L.lib().mpqr_generate_matrix(self._h, seed))
 
-    def snapshot(self):
-        self._chk(L.lib().mpqr_snapshot_input(self._h))
-
-    def restore(self):
-        self._chk(L.lib().mpqr_restore_input(self._h))
-
     def factor(self):
         self._chk(L.lib().mpqr_factor(self._h))
 

@@ -54,9 +54,9 @@ struct mpqr_handle_s {
     mpqr_opts opts;
     int Ko = 0;
 
-    float* dA = nullptr;
-    float* dA0 = nullptr;     // snapshot of the input (metrics, benchmark restore)
-    bool have_snapshot = false;
+    float* dA = nullptr;      // working matrix: R above the diagonal, reflectors below
+    float* dA0 = nullptr;     // the input as given (kept: metrics, re-runs, fallback to the robust panel path)
+    bool have_input = false;
     float* dQ = nullptr;
     half_t* Vh = nullptr;
     half_t* Vt = nullptr;
@@ -65,6 +65,9 @@ struct mpqr_handle_s {
     half_t* Yt = nullptr;  size_t yt_elems = 0;
     float* S = nullptr;    size_t s_elems = 0;
     float* P = nullptr;    int maxwg = 0;
+    double* Gp = nullptr;  float* Cv = nullptr; int* dflag = nullptr;   // Gram-Householder leaf workspace
+    bool robust = false;          // true: never use the Gram-Householder leaf (set after a flagged run)
+    int gh_min_rows = 1024;       // leaves with more rows than this use Gram-Householder
     float* tmp1 = nullptr; float* tmp2 = nullptr; size_t tmp_elems = 0;
     float* Tf = nullptr; half_t* Th = nullptr; half_t* Tth = nullptr; size_t t_elems = 0;
     double* dmetric = nullptr;   // 8 doubles
@@ -117,15 +120,16 @@ int dalloc(mpqr_handle_t h, T** p, size_t elems) {
 
 void free_plan(mpqr_handle_t h) {
     void* ptrs[] = {h->dA, h->dA0, h->dQ, h->Vh, h->Vt, h->vdiag, h->Xt, h->Yt, h->S, h->P, h->tmp1, h->tmp2,
-                    h->Tf, h->Th, h->Tth, h->dstage};
+                    h->Tf, h->Th, h->Tth, h->dstage, h->Gp, h->Cv, h->dflag};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     h->dA = h->dA0 = h->dQ = nullptr; h->Vh = h->Vt = nullptr; h->vdiag = nullptr; h->Xt = nullptr; h->Yt = nullptr;
     h->S = nullptr; h->P = nullptr; h->tmp1 = h->tmp2 = nullptr; h->Tf = nullptr; h->Th = h->Tth = nullptr;
     h->dstage = nullptr; h->stage_elems = 0;
+    h->Gp = nullptr; h->Cv = nullptr; h->dflag = nullptr;
     for (hipEvent_t e : h->far_ev) (void)hipEventDestroy(e);
     h->far_ev.clear();
     h->nodes.clear(); h->tops.clear();
-    h->planned = false; h->have_snapshot = false; h->factored = false; h->q_formed = false;
+    h->planned = false; h->have_input = false; h->factored = false; h->q_formed = false;
 }
 
 // ---- column-range tree
@@ -165,8 +169,8 @@ int choose_split(int M, int N, int K, size_t cap_elems, long slab) {
     const int tiles = ((M + 127) / 128) * ((N + 127) / 128);
     const int ktiles = K / 64;
     int ns = 1;
-    if (tiles < 128) ns = std::min(ktiles, std::max(1, 256 / tiles));
-    ns = std::min(ns, 64);
+    if (tiles < 128) ns = std::min(ktiles / 2, std::max(1, 256 / tiles));   // >= 2 k-tiles per slice
+    ns = std::min(ns, 16);   // every consumer re-reads all slabs: keep the fan-in small
     while (ns > 1 && (size_t)ns * (size_t)slab > cap_elems) ns--;
     return std::max(ns, 1);
 }
@@ -246,7 +250,10 @@ void factor_node(mpqr_handle_t h, int id, bool do_panel) {
             a.A = h->dA; a.lda = h->lda; a.mrows = h->m; a.cb = rdown(nd.c0, 32); a.c0 = nd.c0; a.c1 = nd.c1;
             a.Vh = h->Vh; a.ldvh = h->ldvh; a.Vt = h->Vt; a.ldvt = h->ldvt; a.vdiag = h->vdiag;
             a.P = h->P; a.maxwg = h->maxwg;
-            launch_leaf_factor(a, h->s0);
+            if (!h->robust && h->m - nd.c0 > h->gh_min_rows && h->m - nd.c1 >= 1)
+                launch_leaf_gram_householder(a, h->Gp, h->Cv, h->dflag, h->s0);
+            else
+                launch_leaf_factor(a, h->s0);
         }
         int nslab; long slab;
         gram(h, nd, nd, &nslab, &slab);
@@ -286,8 +293,8 @@ int clear_reflectors(mpqr_handle_t h) {
 
 // power-of-two scale so that fp16 operands stay in range (and out of the subnormal range): column norms are
 // bounded by sqrt(m) max|a|, which the scale brings to [2^7, 2^8)
-int compute_scale(mpqr_handle_t h) {
-    launch_absmax(h->dA, h->lda, h->m, h->n, h->dscalar, h->s0);
+int compute_scale(mpqr_handle_t h, const float* src) {
+    launch_absmax(src, h->lda, h->m, h->n, h->dscalar, h->s0);
     float mx = 0.f;
     HIPCHK(h, hipMemcpyAsync(&mx, h->dscalar, sizeof(float), hipMemcpyDeviceToHost, h->s0));
     HIPCHK(h, hipStreamSynchronize(h->s0));
@@ -421,6 +428,12 @@ int mpqr_plan(mpqr_handle_t h, int m, int n, int r, const mpqr_opts* opts) {
     if ((rc = dalloc(h, &h->Yt, h->yt_elems))) return rc;
     if ((rc = dalloc(h, &h->S, h->s_elems))) return rc;
     if ((rc = dalloc(h, &h->P, (size_t)2 * h->maxwg * 32))) return rc;
+    if ((rc = dalloc(h, &h->Gp, (size_t)h->maxwg * 1024))) return rc;
+    if ((rc = dalloc(h, &h->Cv, (size_t)1024))) return rc;
+    if ((rc = dalloc(h, &h->dflag, (size_t)4))) return rc;
+    if ((rc = dalloc(h, &h->dA0, (size_t)h->m_pad * h->lda))) return rc;
+    HIPCHK(h, hipMemsetAsync(h->dA0, 0, (size_t)h->m_pad * h->lda * sizeof(float), h->s0));
+    HIPCHK(h, hipMemsetAsync(h->dflag, 0, 4 * sizeof(int), h->s0));
     if ((rc = dalloc(h, &h->tmp1, h->tmp_elems))) return rc;
     if ((rc = dalloc(h, &h->tmp2, h->tmp_elems))) return rc;
     if ((rc = dalloc(h, &h->Tf, h->t_elems))) return rc;
@@ -445,52 +458,37 @@ static int need_plan(mpqr_handle_t h) {
 int mpqr_set_matrix_host(mpqr_handle_t h, const float* A, long ld) {
     int rc = need_plan(h); if (rc) return rc;
     if (!A || ld < h->n) return fail(h, MPQR_ERR_INVALID, "bad matrix pointer / leading dimension");
-    HIPCHK(h, hipMemcpy2DAsync(h->dA, h->lda * sizeof(float), A, ld * sizeof(float), (size_t)h->n * sizeof(float), h->m,
+    HIPCHK(h, hipMemcpy2DAsync(h->dA0, h->lda * sizeof(float), A, ld * sizeof(float), (size_t)h->n * sizeof(float), h->m,
                                hipMemcpyHostToDevice, h->s0));
     HIPCHK(h, hipStreamSynchronize(h->s0));
-    h->factored = false; h->q_formed = false; h->have_snapshot = false;
+    h->factored = false; h->q_formed = false; h->have_input = true; h->robust = false;
     return MPQR_OK;
 }
 
 int mpqr_set_matrix_device(mpqr_handle_t h, const float* dA, long ld) {
     int rc = need_plan(h); if (rc) return rc;
     if (!dA || ld < h->n) return fail(h, MPQR_ERR_INVALID, "bad matrix pointer / leading dimension");
-    HIPCHK(h, hipMemcpy2DAsync(h->dA, h->lda * sizeof(float), dA, ld * sizeof(float), (size_t)h->n * sizeof(float), h->m,
+    HIPCHK(h, hipMemcpy2DAsync(h->dA0, h->lda * sizeof(float), dA, ld * sizeof(float), (size_t)h->n * sizeof(float), h->m,
                                hipMemcpyDeviceToDevice, h->s0));
-    h->factored = false; h->q_formed = false; h->have_snapshot = false;
+    h->factored = false; h->q_formed = false; h->have_input = true; h->robust = false;
     return MPQR_OK;
 }
 
 int mpqr_generate_matrix(mpqr_handle_t h, uint64_t seed) {
     int rc = need_plan(h); if (rc) return rc;
-    launch_generate(h->dA, h->lda, h->m, h->n, seed, h->n, 1, 1, 0, h->s0);
-    h->factored = false; h->q_formed = false; h->have_snapshot = false;
+    launch_generate(h->dA0, h->lda, h->m, h->n, seed, h->n, 1, 1, 0, h->s0);
+    h->factored = false; h->q_formed = false; h->have_input = true; h->robust = false;
     return MPQR_OK;
 }
 
-int mpqr_snapshot_input(mpqr_handle_t h) {
-    int rc = need_plan(h); if (rc) return rc;
-    if (!h->dA0 && (rc = dalloc(h, &h->dA0, (size_t)h->m_pad * h->lda))) return rc;
-    HIPCHK(h, hipMemcpyAsync(h->dA0, h->dA, (size_t)h->m_pad * h->lda * sizeof(float), hipMemcpyDeviceToDevice, h->s0));
-    h->have_snapshot = true;
-    return MPQR_OK;
-}
-
-int mpqr_restore_input(mpqr_handle_t h) {
-    int rc = need_plan(h); if (rc) return rc;
-    if (!h->have_snapshot) return fail(h, MPQR_ERR_STATE, "no snapshot to restore");
-    HIPCHK(h, hipMemcpyAsync(h->dA, h->dA0, (size_t)h->m_pad * h->lda * sizeof(float), hipMemcpyDeviceToDevice, h->s0));
-    h->factored = false; h->q_formed = false;
-    return MPQR_OK;
-}
-
-int mpqr_factor(mpqr_handle_t h) {
-    int rc = need_plan(h); if (rc) return rc;
-    if (h->opts.precision != MPQR_PREC_FP16) return fail(h, MPQR_ERR_INVALID, "MPQR_PREC_FP32 is not built yet");
+// enqueue copy-in + the whole block loop; returns the leaf flag (1 = a Gram-Householder leaf was too ill-conditioned)
+static int run_block_loop(mpqr_handle_t h, int* flagged) {
+    int rc;
     for (hipEvent_t e : h->far_ev) (void)hipEventDestroy(e);
     h->far_ev.clear(); h->far_flops.clear();
-    if ((rc = compute_scale(h))) return rc;
     HIPCHK(h, hipEventRecord(h->ev[0], h->s0));
+    HIPCHK(h, hipMemcpyAsync(h->dA, h->dA0, (size_t)h->m_pad * h->lda * sizeof(float), hipMemcpyDeviceToDevice, h->s0));
+    HIPCHK(h, hipMemsetAsync(h->dflag, 0, sizeof(int), h->s0));
     if ((rc = clear_reflectors(h))) return rc;
     for (size_t t = 0; t < h->tops.size(); t++) {
         const Node nd = h->nodes[h->tops[t]];
@@ -498,6 +496,25 @@ int mpqr_factor(mpqr_handle_t h) {
         apply_node(h, nd, h->dA, h->lda, nd.c1, h->n, true, h->a_scale, true);
     }
     HIPCHK(h, hipEventRecord(h->ev[1], h->s0));
+    int f = 0;
+    HIPCHK(h, hipMemcpyAsync(&f, h->dflag, sizeof(int), hipMemcpyDeviceToHost, h->s0));
+    HIPCHK(h, hipStreamSynchronize(h->s0));
+    HIPCHK(h, hipGetLastError());
+    *flagged = f;
+    return MPQR_OK;
+}
+
+int mpqr_factor(mpqr_handle_t h) {
+    int rc = need_plan(h); if (rc) return rc;
+    if (!h->have_input) return fail(h, MPQR_ERR_STATE, "no input matrix has been set");
+    if (h->opts.precision != MPQR_PREC_FP16) return fail(h, MPQR_ERR_INVALID, "MPQR_PREC_FP32 is not built yet");
+    if ((rc = compute_scale(h, h->dA0))) return rc;
+    int flagged = 0;
+    if ((rc = run_block_loop(h, &flagged))) return rc;
+    if (flagged && !h->robust) {          // ill-conditioned tall leaf: redo on the column-by-column panel kernels
+        h->robust = true;
+        if ((rc = run_block_loop(h, &flagged))) return rc;
+    }
     h->factored = true;
     if (h->opts.form_q) { if ((rc = form_q(h))) return rc; }
     HIPCHK(h, hipEventRecord(h->ev[2], h->s0));
@@ -624,7 +641,6 @@ int mpqr_metrics_device(mpqr_handle_t h, mpqr_metrics* out) {
     int rc = need_plan(h); if (rc) return rc;
     if (!out) return MPQR_ERR_INVALID;
     if (!h->factored || !h->q_formed) return fail(h, MPQR_ERR_STATE, "factor with form_q=1 first");
-    if (!h->have_snapshot) return fail(h, MPQR_ERR_STATE, "mpqr_snapshot_input must precede mpqr_factor");
     const int m = h->m, n = h->n;
     float* R = nullptr; float* work = nullptr;
     if ((rc = dalloc(h, &R, (size_t)m * n))) return rc;
@@ -703,7 +719,7 @@ static int stage_load(mpqr_handle_t h, const float* A, int m, int n, int r, int 
     HIPCHK(h, hipMemcpyAsync(h->dstage, A, el * sizeof(float), hipMemcpyHostToDevice, h->s0));
     launch_unpack_factor(h->dstage, m, n, c0, c1, h->dA, h->lda, h->vdiag, h->Vh, h->ldvh, h->Vt, h->ldvt, h->s0);
     HIPCHK(h, hipStreamSynchronize(h->s0));
-    h->factored = false; h->q_formed = false; h->have_snapshot = false;
+    h->factored = false; h->q_formed = false; h->have_input = false;
     return MPQR_OK;
 }
 
@@ -743,13 +759,21 @@ int mpqr_householder_qr_f32(mpqr_handle_t h, float* A, int m, int n, int go, int
     int rc = check_shape(h, m, n, 1); if (rc) return rc;
     if (!A || go < 0 || go >= n || pw < 1) return fail(h, MPQR_ERR_INVALID, "bad panel range");
     const int c0 = go, c1 = std::min(n, go + pw);           // qr.cu:210: r = min(go+pw, n)
-    if ((rc = stage_load(h, A, m, n, std::max(1, c1 - c0), 0, 0))) return rc;
-    h->a_scale = 1.f;
-    if ((rc = compute_scale(h))) return rc;
-    StageTree st;
-    if ((rc = stage_tree_begin(h, st, c0, c1, c1 - c0))) { stage_tree_end(h, st); return rc; }
-    factor_node(h, st.root, true);
-    stage_tree_end(h, st);
+    h->robust = false;
+    for (int attempt = 0; attempt < 2; attempt++) {
+        if ((rc = stage_load(h, A, m, n, std::max(1, c1 - c0), 0, 0))) return rc;
+        if ((rc = compute_scale(h, h->dA))) return rc;
+        HIPCHK(h, hipMemsetAsync(h->dflag, 0, sizeof(int), h->s0));
+        StageTree st;
+        if ((rc = stage_tree_begin(h, st, c0, c1, c1 - c0))) { stage_tree_end(h, st); return rc; }
+        factor_node(h, st.root, true);
+        int f = 0;
+        hipError_t fe = hipMemcpyAsync(&f, h->dflag, sizeof(int), hipMemcpyDeviceToHost, h->s0);
+        stage_tree_end(h, st);          // synchronises the stream
+        if (fe != hipSuccess) return fail(h, MPQR_ERR_HIP, "flag readback failed");
+        if (!f || h->robust) break;
+        h->robust = true;               // ill-conditioned tall leaf: redo on the column-by-column kernels
+    }
     // write back only the panel columns, in the reference's shifted layout
     std::vector<float> tmp((size_t)m * n), vd(n);
     HIPCHK(h, hipMemcpy2D(tmp.data(), (size_t)n * 4, h->dA, h->lda * 4, (size_t)n * 4, m, hipMemcpyDeviceToHost));
@@ -813,7 +837,7 @@ int mpqr_apply_panel_to_trailing_f32(mpqr_handle_t h, float* A, int m, int n, in
     if (precision != MPQR_PREC_FP16) return fail(h, MPQR_ERR_INVALID, "MPQR_PREC_FP32 is not built yet");
     const int c0 = go, c1 = go + pw;
     if ((rc = stage_load(h, A, m, n, pw, c0, c1))) return rc;
-    if ((rc = compute_scale(h))) return rc;
+    if ((rc = compute_scale(h, h->dA))) return rc;
     StageTree st;
     if ((rc = stage_tree_begin(h, st, c0, c1, pw))) { stage_tree_end(h, st); return rc; }
     factor_node(h, st.root, false);

@@ -63,7 +63,10 @@ struct LeafArgs {
     float* P;                   // partial dot products, 2 x maxwg x 32
     int maxwg;
 };
-void launch_leaf_factor(const LeafArgs& a, hipStream_t s);   // all columns of the leaf, one launch per column
+void launch_leaf_factor(const LeafArgs& a, hipStream_t s);   // robust path: one workgroup (<=2048 rows) or one launch per column
+// tall leaves (rows below c1 >= 1): Gram-Householder, 3 launches; raises *flag when a leaf is too ill-conditioned
+void launch_leaf_gram_householder(const LeafArgs& a, double* Gp /* nwg x 1024 */, float* Cv /* 1024 */, int* flag,
+                                  hipStream_t s);
 
 // T of a leaf from its Gram slabs: S (64 x 64 per slab, aligned range starting at a0)
 void launch_t_leaf(const float* S, int nslab, long slab_stride, int a0, int c0, int c1,
