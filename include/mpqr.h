@@ -177,6 +177,40 @@ int  mpqr_part_owner(int col, int block, int world);
 int  mpqr_part_local_cols(int n, int block, int world, int rank);
 int  mpqr_part_local_index(int col, int block, int world);          /* column index inside its owner's shard */
 int  mpqr_part_global_index(int lcol, int block, int world, int rank);
+
+/* Distributed driver, one process (and one handle) per GPU.  Column superblocks of `outer_block` columns
+ * (mpqr_dist_block) are dealt round-robin (block s -> rank s % world); every rank holds all m rows of its
+ * columns.  Q is sharded by columns in the same pattern.  The library never communicates: per block the owner
+ * packs one contiguous device buffer, the CALLER broadcasts it (torch.distributed / RCCL over xGMI in bench.py),
+ * and every rank unpacks and updates its own trailing columns:
+ *
+ *     mpqr_dist_plan; mpqr_dist_generate_matrix | mpqr_dist_set_local_matrix_host
+ *     mpqr_dist_local_absmax -> all-reduce(max) -> mpqr_dist_begin(global_absmax)
+ *     for s in 0 .. mpqr_dist_num_blocks-1:
+ *         owner:  mpqr_dist_factor_block(s); mpqr_dist_pack_block(s, buf)
+ *         all:    broadcast(buf, root = mpqr_dist_block_owner(s)); mpqr_dist_unpack_block(s, buf); mpqr_dist_update(s)
+ *     mpqr_dist_form_q                      (no communication)
+ */
+int  mpqr_dist_plan(mpqr_handle_t h, int m, int n, int r, int world, int rank, const mpqr_opts* opts);
+int  mpqr_dist_block(mpqr_handle_t h);              /* columns per distributed block                     */
+int  mpqr_dist_num_blocks(mpqr_handle_t h);
+int  mpqr_dist_block_owner(mpqr_handle_t h, int s);
+int  mpqr_dist_local_cols(mpqr_handle_t h);         /* columns of A held by this rank                    */
+int  mpqr_dist_local_q_cols(mpqr_handle_t h);       /* columns of Q held by this rank                    */
+int  mpqr_dist_set_local_matrix_host(mpqr_handle_t h, const float* A_local, long ld);   /* m x local_cols */
+int  mpqr_dist_generate_matrix(mpqr_handle_t h, uint64_t seed);   /* this rank's columns of the global matrix */
+int  mpqr_dist_local_absmax(mpqr_handle_t h, float* out);
+int  mpqr_dist_begin(mpqr_handle_t h, float global_absmax);
+int  mpqr_dist_factor_block(mpqr_handle_t h, int s);
+long mpqr_dist_block_bytes(mpqr_handle_t h, int s);
+int  mpqr_dist_pack_block(mpqr_handle_t h, int s, void* device_buf);
+int  mpqr_dist_unpack_block(mpqr_handle_t h, int s, const void* device_buf);
+int  mpqr_dist_update(mpqr_handle_t h, int s);
+int  mpqr_dist_form_q(mpqr_handle_t h);
+/* results of this rank: (m+1) x local_cols in the reference's shifted layout; m x local_q_cols; the input */
+int  mpqr_dist_get_local_factor_host(mpqr_handle_t h, float* A_local);
+int  mpqr_dist_get_local_q_host(mpqr_handle_t h, float* Q_local);
+int  mpqr_dist_get_local_input_host(mpqr_handle_t h, float* A_local);
 #ifdef __cplusplus
 }
 #endif

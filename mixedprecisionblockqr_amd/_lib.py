@@ -87,6 +87,25 @@ SIGNATURES = {
     "mpqr_part_local_cols": (_i, [_i, _i, _i, _i]),
     "mpqr_part_local_index": (_i, [_i, _i, _i]),
     "mpqr_part_global_index": (_i, [_i, _i, _i, _i]),
+    "mpqr_dist_plan": (_i, [_H, _i, _i, _i, _i, _i, C.POINTER(MpqrOpts)]),
+    "mpqr_dist_block": (_i, [_H]),
+    "mpqr_dist_num_blocks": (_i, [_H]),
+    "mpqr_dist_block_owner": (_i, [_H, _i]),
+    "mpqr_dist_local_cols": (_i, [_H]),
+    "mpqr_dist_local_q_cols": (_i, [_H]),
+    "mpqr_dist_set_local_matrix_host": (_i, [_H, _p, _l]),
+    "mpqr_dist_generate_matrix": (_i, [_H, C.c_uint64]),
+    "mpqr_dist_local_absmax": (_i, [_H, C.POINTER(_f)]),
+    "mpqr_dist_begin": (_i, [_H, _f]),
+    "mpqr_dist_factor_block": (_i, [_H, _i]),
+    "mpqr_dist_block_bytes": (_l, [_H, _i]),
+    "mpqr_dist_pack_block": (_i, [_H, _i, _p]),
+    "mpqr_dist_unpack_block": (_i, [_H, _i, _p]),
+    "mpqr_dist_update": (_i, [_H, _i]),
+    "mpqr_dist_form_q": (_i, [_H]),
+    "mpqr_dist_get_local_factor_host": (_i, [_H, _p]),
+    "mpqr_dist_get_local_q_host": (_i, [_H, _p]),
+    "mpqr_dist_get_local_input_host": (_i, [_H, _p]),
 }
 
 _lib = None

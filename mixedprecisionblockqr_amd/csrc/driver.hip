@@ -76,6 +76,11 @@ struct mpqr_handle_s {
 
     std::vector<Node> nodes;
     std::vector<int> tops;
+    // 1-D block-cyclic column distribution (world == 1: everything local)
+    int world = 1, rank = 0;
+    int nloc = 0;        // local columns of A
+    int qloc = 0;        // local columns of Q
+    float* Aeff = nullptr;   // dA shifted so that Aeff[row*lda + GLOBAL column] addresses the column being factored
     float a_scale = 1.f;
     bool factored = false, q_formed = false;
 
@@ -247,7 +252,7 @@ void factor_node(mpqr_handle_t h, int id, bool do_panel) {
     if (nd.left < 0) {
         if (do_panel) {
             LeafArgs a{};
-            a.A = h->dA; a.lda = h->lda; a.mrows = h->m; a.cb = rdown(nd.c0, 32); a.c0 = nd.c0; a.c1 = nd.c1;
+            a.A = h->Aeff; a.lda = h->lda; a.mrows = h->m; a.cb = rdown(nd.c0, 32); a.c0 = nd.c0; a.c1 = nd.c1;
             a.Vh = h->Vh; a.ldvh = h->ldvh; a.Vt = h->Vt; a.ldvt = h->ldvt; a.vdiag = h->vdiag;
             a.P = h->P; a.maxwg = h->maxwg;
             if (!h->robust && h->m - nd.c0 > h->gh_min_rows && h->m - nd.c1 >= 1)
@@ -263,7 +268,7 @@ void factor_node(mpqr_handle_t h, int id, bool do_panel) {
     }
     const Node L = h->nodes[nd.left], R = h->nodes[nd.right];
     factor_node(h, nd.left, do_panel);
-    if (do_panel) apply_node(h, L, h->dA, h->lda, R.c0, R.c1, true, h->a_scale, false);
+    if (do_panel) apply_node(h, L, h->Aeff, h->lda, R.c0, R.c1, true, h->a_scale, false);
     factor_node(h, nd.right, do_panel);
     // T_LR = -T_L (V_L^T V_R) T_R
     int nslab; long slab;
@@ -390,33 +395,39 @@ int mpqr_destroy(mpqr_handle_t h) {
 
 const char* mpqr_last_error(mpqr_handle_t h) { return h ? h->err.c_str() : g_create_err.c_str(); }
 
-int mpqr_plan(mpqr_handle_t h, int m, int n, int r, const mpqr_opts* opts) {
+static int plan_common(mpqr_handle_t h, int m, int n, int r, const mpqr_opts* opts, int world, int rank) {
     int rc = check_shape(h, m, n, r);
     if (rc) return rc;
+    if (world < 1 || rank < 0 || rank >= world) return fail(h, MPQR_ERR_INVALID, "bad world/rank");
     HIPCHK(h, hipSetDevice(h->device));
     mpqr_opts o;
     if (opts) o = *opts; else mpqr_default_opts(&o);
     if (o.precision != MPQR_PREC_FP16 && o.precision != MPQR_PREC_FP32)
         return fail(h, MPQR_ERR_INVALID, "unknown precision");
-    if (h->planned && h->m == m && h->n == n && h->r == r && memcmp(&o, &h->opts, sizeof o) == 0) return MPQR_OK;
+    if (h->planned && h->m == m && h->n == n && h->r == r && h->world == world && h->rank == rank &&
+        memcmp(&o, &h->opts, sizeof o) == 0)
+        return MPQR_OK;
     HIPCHK(h, hipStreamSynchronize(h->s0));
     free_plan(h);
-    h->m = m; h->n = n; h->r = r; h->opts = o;
+    h->m = m; h->n = n; h->r = r; h->opts = o; h->world = world; h->rank = rank;
     h->m_pad = rup(m, 256); h->n_pad = rup(n, 256);
-    h->lda = h->n_pad; h->ldq = h->m_pad; h->ldvh = h->n_pad; h->ldvt = h->m_pad;
     int Ko = o.outer_block > 0 ? o.outer_block : 1024;
     Ko = std::max(Ko, 32);
     if (r >= Ko) Ko = r; else Ko = (Ko / r) * r;
     h->Ko = Ko;
-    // tree
+    h->nloc = (world == 1) ? n : mpqr_part_local_cols(n, Ko, world, rank);
+    h->qloc = (world == 1) ? m : mpqr_part_local_cols(m, Ko, world, rank);
+    h->lda = rup(std::max(h->nloc, 1), 256); h->ldq = rup(std::max(h->qloc, 1), 256);
+    h->ldvh = h->n_pad; h->ldvt = h->m_pad;
+    // tree over the GLOBAL columns (every rank builds the same one)
     for (int c = 0; c < n; c += Ko) h->tops.push_back(build_tree(h, c, std::min(n, c + Ko)));
     size_t toff = 0; int max_ldt = 64;
     for (Node& nd : h->nodes) { nd.toff = toff; toff += (size_t)nd.ldt * nd.ldt; max_ldt = std::max(max_ldt, nd.ldt); }
     h->t_elems = toff;
     const size_t maxdim = (size_t)std::max(h->m_pad, h->n_pad);
-    h->xt_elems = std::max(maxdim * (size_t)max_ldt, (size_t)64 * max_ldt * max_ldt);
+    h->xt_elems = std::max(maxdim * (size_t)max_ldt, (size_t)16 * max_ldt * max_ldt);
     h->yt_elems = maxdim * (size_t)max_ldt;
-    h->s_elems = (size_t)64 * max_ldt * max_ldt;
+    h->s_elems = (size_t)16 * max_ldt * max_ldt;
     h->tmp_elems = (size_t)max_ldt * max_ldt;
     h->maxwg = h->m_pad / 256 + 2;
     if ((rc = dalloc(h, &h->dA, (size_t)h->m_pad * h->lda))) return rc;
@@ -432,24 +443,30 @@ int mpqr_plan(mpqr_handle_t h, int m, int n, int r, const mpqr_opts* opts) {
     if ((rc = dalloc(h, &h->Cv, (size_t)1024))) return rc;
     if ((rc = dalloc(h, &h->dflag, (size_t)4))) return rc;
     if ((rc = dalloc(h, &h->dA0, (size_t)h->m_pad * h->lda))) return rc;
-    HIPCHK(h, hipMemsetAsync(h->dA0, 0, (size_t)h->m_pad * h->lda * sizeof(float), h->s0));
-    HIPCHK(h, hipMemsetAsync(h->dflag, 0, 4 * sizeof(int), h->s0));
     if ((rc = dalloc(h, &h->tmp1, h->tmp_elems))) return rc;
     if ((rc = dalloc(h, &h->tmp2, h->tmp_elems))) return rc;
     if ((rc = dalloc(h, &h->Tf, h->t_elems))) return rc;
     if ((rc = dalloc(h, &h->Th, h->t_elems))) return rc;
     if ((rc = dalloc(h, &h->Tth, h->t_elems))) return rc;
+    HIPCHK(h, hipMemsetAsync(h->dA0, 0, (size_t)h->m_pad * h->lda * sizeof(float), h->s0));
+    HIPCHK(h, hipMemsetAsync(h->dflag, 0, 4 * sizeof(int), h->s0));
     HIPCHK(h, hipMemsetAsync(h->dA, 0, (size_t)h->m_pad * h->lda * sizeof(float), h->s0));
     HIPCHK(h, hipMemsetAsync(h->dQ, 0, (size_t)h->m_pad * h->ldq * sizeof(float), h->s0));
     if ((rc = clear_reflectors(h))) return rc;
     HIPCHK(h, hipStreamSynchronize(h->s0));
+    h->Aeff = h->dA;
     h->planned = true;
     return MPQR_OK;
 }
 
-static int need_plan(mpqr_handle_t h) {
+int mpqr_plan(mpqr_handle_t h, int m, int n, int r, const mpqr_opts* opts) {
+    return plan_common(h, m, n, r, opts, 1, 0);
+}
+
+static int need_plan(mpqr_handle_t h, bool dist = false) {
     if (!h) return MPQR_ERR_INVALID;
     if (!h->planned) return fail(h, MPQR_ERR_STATE, "mpqr_plan has not been called");
+    if (!dist && h->world != 1) return fail(h, MPQR_ERR_STATE, "handle holds a distributed plan: use the mpqr_dist_* calls");
     hipError_t e = hipSetDevice(h->device);
     if (e != hipSuccess) return fail(h, MPQR_ERR_HIP, "hipSetDevice failed");
     return MPQR_OK;
@@ -740,7 +757,7 @@ static int stage_tree_begin(mpqr_handle_t h, StageTree& st, int c0, int c1, int 
     h->r = saved_r;
     size_t toff = 0; int max_ldt = 64;
     for (Node& nd : h->nodes) { nd.toff = toff; toff += (size_t)nd.ldt * nd.ldt; max_ldt = std::max(max_ldt, nd.ldt); }
-    if ((size_t)max_ldt * max_ldt > h->tmp_elems || (size_t)64 * max_ldt * max_ldt > h->s_elems ||
+    if ((size_t)max_ldt * max_ldt > h->tmp_elems || (size_t)16 * max_ldt * max_ldt > h->s_elems ||
         (size_t)std::max(h->m_pad, h->n_pad) * max_ldt > h->yt_elems)
         return fail(h, MPQR_ERR_INVALID, "panel too wide for the planned workspace");
     int rc;
@@ -884,6 +901,214 @@ int mpqr_qr_factorization_f64(mpqr_handle_t h, double* A, double* Q, int m, int 
     (void)hipFree(dA); (void)hipFree(dQ); (void)hipFree(dw);
     if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess || e4 != hipSuccess || e5 != hipSuccess)
         return fail(h, MPQR_ERR_HIP, "fp64 path: HIP call failed");
+    return MPQR_OK;
+}
+
+}  // extern "C"
+
+// =====================================================================================
+// Multi-GPU: 1-D block-cyclic columns, one process per GPU.  The reference is single-GPU; this is
+// the sharded form of the same block loop.  Column superblocks (outer_block columns, the unit the far update
+// works with) are dealt round-robin; every rank holds all m rows of its columns and the same column tree.
+//   step s : owner factors superblock s            mpqr_dist_factor_block
+//            owner packs [V^T | T | T^T] (fp16)    mpqr_dist_pack_block     -> caller broadcasts the buffer (RCCL)
+//            everyone unpacks + updates its own trailing columns            mpqr_dist_unpack_block / _update
+//   Q      : columns of Q sharded the same way; each rank applies all (V,T) to its columns, no communication.
+// The broadcast itself stays outside the library (torch.distributed / RCCL in bench.py and dist.py), so the
+// same schedule can be exercised on CPU ranks with a test double.
+extern "C" {
+
+int mpqr_dist_plan(mpqr_handle_t h, int m, int n, int r, int world, int rank, const mpqr_opts* opts) {
+    return plan_common(h, m, n, r, opts, world, rank);
+}
+int mpqr_dist_local_cols(mpqr_handle_t h) { return (h && h->planned) ? h->nloc : -1; }
+int mpqr_dist_local_q_cols(mpqr_handle_t h) { return (h && h->planned) ? h->qloc : -1; }
+int mpqr_dist_block(mpqr_handle_t h) { return (h && h->planned) ? h->Ko : -1; }
+int mpqr_dist_num_blocks(mpqr_handle_t h) { return (h && h->planned) ? (int)h->tops.size() : -1; }
+int mpqr_dist_block_owner(mpqr_handle_t h, int s) {
+    if (!h || !h->planned || s < 0 || s >= (int)h->tops.size()) return -1;
+    return s % h->world;
+}
+
+int mpqr_dist_set_local_matrix_host(mpqr_handle_t h, const float* A_local, long ld) {
+    int rc = need_plan(h, true); if (rc) return rc;
+    if (h->nloc > 0) {
+        if (!A_local || ld < h->nloc) return fail(h, MPQR_ERR_INVALID, "bad local matrix / leading dimension");
+        HIPCHK(h, hipMemcpy2DAsync(h->dA0, h->lda * sizeof(float), A_local, ld * sizeof(float),
+                                   (size_t)h->nloc * sizeof(float), h->m, hipMemcpyHostToDevice, h->s0));
+    }
+    HIPCHK(h, hipStreamSynchronize(h->s0));
+    h->factored = false; h->q_formed = false; h->have_input = true;
+    return MPQR_OK;
+}
+
+int mpqr_dist_generate_matrix(mpqr_handle_t h, uint64_t seed) {
+    int rc = need_plan(h, true); if (rc) return rc;
+    if (h->nloc > 0) launch_generate(h->dA0, h->lda, h->m, h->nloc, seed, h->n, h->Ko, h->world, h->rank, h->s0);
+    h->factored = false; h->q_formed = false; h->have_input = true;
+    return MPQR_OK;
+}
+
+int mpqr_dist_local_absmax(mpqr_handle_t h, float* out) {
+    int rc = need_plan(h, true); if (rc) return rc;
+    if (!out) return MPQR_ERR_INVALID;
+    *out = 0.f;
+    if (h->nloc > 0) {
+        launch_absmax(h->dA0, h->lda, h->m, h->nloc, h->dscalar, h->s0);
+        HIPCHK(h, hipMemcpyAsync(out, h->dscalar, sizeof(float), hipMemcpyDeviceToHost, h->s0));
+    }
+    HIPCHK(h, hipStreamSynchronize(h->s0));
+    return MPQR_OK;
+}
+
+// copy the input into the working matrix and reset the reflector storage; absmax = GLOBAL max |a_ij|
+int mpqr_dist_begin(mpqr_handle_t h, float absmax) {
+    int rc = need_plan(h, true); if (rc) return rc;
+    if (!h->have_input) return fail(h, MPQR_ERR_STATE, "no input matrix has been set");
+    float sc = 1.f;
+    if (absmax > 0.f && std::isfinite(absmax)) { int e; frexpf(absmax * sqrtf((float)h->m), &e); sc = ldexpf(1.f, 8 - e); }
+    h->a_scale = sc;
+    HIPCHK(h, hipEventRecord(h->ev[0], h->s0));
+    HIPCHK(h, hipMemcpyAsync(h->dA, h->dA0, (size_t)h->m_pad * h->lda * sizeof(float), hipMemcpyDeviceToDevice, h->s0));
+    HIPCHK(h, hipMemsetAsync(h->dflag, 0, sizeof(int), h->s0));
+    if ((rc = clear_reflectors(h))) return rc;
+    h->factored = false; h->q_formed = false;
+    return MPQR_OK;
+}
+
+// owner only: factor superblock s of the (already updated) local columns
+int mpqr_dist_factor_block(mpqr_handle_t h, int s) {
+    int rc = need_plan(h, true); if (rc) return rc;
+    if (s < 0 || s >= (int)h->tops.size()) return fail(h, MPQR_ERR_INVALID, "bad block index");
+    if (s % h->world != h->rank) return fail(h, MPQR_ERR_STATE, "this rank does not own that block");
+    const Node nd = h->nodes[h->tops[s]];
+    const int lc0 = mpqr_part_local_index(nd.c0, h->Ko, h->world);
+    // save the block's columns so an ill-conditioned tall leaf can be redone on the robust kernels
+    const size_t wbytes = (size_t)(nd.c1 - nd.c0) * sizeof(float);
+    int rcs = ensure_stage(h, (size_t)h->m_pad * (nd.c1 - nd.c0)); if (rcs) return rcs;
+    HIPCHK(h, hipMemcpy2DAsync(h->dstage, wbytes, h->dA + lc0, h->lda * sizeof(float), wbytes, h->m_pad,
+                               hipMemcpyDeviceToDevice, h->s0));
+    h->Aeff = h->dA + (lc0 - nd.c0);
+    bool saved_robust = h->robust;
+    for (int attempt = 0; attempt < 2; attempt++) {
+        factor_node(h, h->tops[s], true);
+        int f = 0;
+        HIPCHK(h, hipMemcpyAsync(&f, h->dflag, sizeof(int), hipMemcpyDeviceToHost, h->s0));
+        HIPCHK(h, hipStreamSynchronize(h->s0));
+        if (!f || h->robust) break;
+        // restore the block and redo it column by column
+        h->robust = true;
+        HIPCHK(h, hipMemsetAsync(h->dflag, 0, sizeof(int), h->s0));
+        HIPCHK(h, hipMemcpy2DAsync(h->dA + lc0, h->lda * sizeof(float), h->dstage, wbytes, wbytes, h->m_pad,
+                                   hipMemcpyDeviceToDevice, h->s0));
+        HIPCHK(h, hipMemset2DAsync(h->Vh + nd.c0, h->ldvh * sizeof(half_t), 0, (size_t)(nd.c1 - nd.c0) * sizeof(half_t),
+                                   h->m_pad, h->s0));
+        HIPCHK(h, hipMemsetAsync(h->Vt + (size_t)nd.c0 * h->ldvt, 0, (size_t)(nd.c1 - nd.c0) * h->ldvt * sizeof(half_t), h->s0));
+    }
+    h->robust = saved_robust;
+    h->Aeff = h->dA;
+    HIPCHK(h, hipGetLastError());
+    return MPQR_OK;
+}
+
+// bytes of the broadcast buffer of block s: V^T rows (fp16, columns >= the block's first 64-aligned row) | T | T^T
+long mpqr_dist_block_bytes(mpqr_handle_t h, int s) {
+    if (!h || !h->planned || s < 0 || s >= (int)h->tops.size()) return -1;
+    const Node& nd = h->nodes[h->tops[s]];
+    const long Kr = nd.ldt, Wc = h->m_pad - rdown(nd.c0, 64);
+    return (Kr * Wc + 2 * Kr * Kr) * (long)sizeof(half_t);
+}
+
+int mpqr_dist_pack_block(mpqr_handle_t h, int s, void* dbuf) {
+    int rc = need_plan(h, true); if (rc) return rc;
+    if (s < 0 || s >= (int)h->tops.size() || !dbuf) return fail(h, MPQR_ERR_INVALID, "bad arguments");
+    const Node& nd = h->nodes[h->tops[s]];
+    const long Kr = nd.ldt; const int rlo = rdown(nd.c0, 64); const long Wc = h->m_pad - rlo;
+    half_t* out = (half_t*)dbuf;
+    HIPCHK(h, hipMemcpy2DAsync(out, Wc * sizeof(half_t), h->Vt + (size_t)nd.a0 * h->ldvt + rlo, h->ldvt * sizeof(half_t),
+                               Wc * sizeof(half_t), Kr, hipMemcpyDeviceToDevice, h->s0));
+    HIPCHK(h, hipMemcpyAsync(out + Kr * Wc, h->Th + nd.toff, Kr * Kr * sizeof(half_t), hipMemcpyDeviceToDevice, h->s0));
+    HIPCHK(h, hipMemcpyAsync(out + Kr * Wc + Kr * Kr, h->Tth + nd.toff, Kr * Kr * sizeof(half_t), hipMemcpyDeviceToDevice, h->s0));
+    HIPCHK(h, hipStreamSynchronize(h->s0));
+    return MPQR_OK;
+}
+
+int mpqr_dist_unpack_block(mpqr_handle_t h, int s, const void* dbuf) {
+    int rc = need_plan(h, true); if (rc) return rc;
+    if (s < 0 || s >= (int)h->tops.size() || !dbuf) return fail(h, MPQR_ERR_INVALID, "bad arguments");
+    if (s % h->world == h->rank) return MPQR_OK;            // the owner already holds everything
+    const Node& nd = h->nodes[h->tops[s]];
+    const long Kr = nd.ldt; const int rlo = rdown(nd.c0, 64); const long Wc = h->m_pad - rlo;
+    const half_t* in = (const half_t*)dbuf;
+    HIPCHK(h, hipMemcpy2DAsync(h->Vt + (size_t)nd.a0 * h->ldvt + rlo, h->ldvt * sizeof(half_t), in, Wc * sizeof(half_t),
+                               Wc * sizeof(half_t), Kr, hipMemcpyDeviceToDevice, h->s0));
+    HIPCHK(h, hipMemcpyAsync(h->Th + nd.toff, in + Kr * Wc, Kr * Kr * sizeof(half_t), hipMemcpyDeviceToDevice, h->s0));
+    HIPCHK(h, hipMemcpyAsync(h->Tth + nd.toff, in + Kr * Wc + Kr * Kr, Kr * Kr * sizeof(half_t), hipMemcpyDeviceToDevice, h->s0));
+    // Vh[rlo + c][a0 + k] = Vt[a0 + k][rlo + c]
+    launch_transpose_h16(in, Wc, h->Vh + (size_t)rlo * h->ldvh + nd.a0, h->ldvh, (int)Kr, (int)Wc, h->s0);
+    return MPQR_OK;
+}
+
+// apply block s's reflectors to this rank's columns right of it
+int mpqr_dist_update(mpqr_handle_t h, int s) {
+    int rc = need_plan(h, true); if (rc) return rc;
+    if (s < 0 || s >= (int)h->tops.size()) return fail(h, MPQR_ERR_INVALID, "bad block index");
+    const Node nd = h->nodes[h->tops[s]];
+    const int lc_next = mpqr_part_local_cols(std::min(h->n, nd.c1), h->Ko, h->world, h->rank);
+    apply_node(h, nd, h->dA, h->lda, lc_next, h->nloc, true, h->a_scale, false);
+    if (s + 1 == (int)h->tops.size()) { HIPCHK(h, hipEventRecord(h->ev[1], h->s0)); h->factored = true; }
+    HIPCHK(h, hipGetLastError());
+    return MPQR_OK;
+}
+
+int mpqr_dist_form_q(mpqr_handle_t h) {
+    int rc = need_plan(h, true); if (rc) return rc;
+    if (!h->factored) return fail(h, MPQR_ERR_STATE, "factor first");
+    HIPCHK(h, hipMemsetAsync(h->dQ, 0, (size_t)h->m_pad * h->ldq * sizeof(float), h->s0));
+    launch_identity_cyclic(h->dQ, h->ldq, h->m, h->qloc, h->Ko, h->world, h->rank, h->s0);
+    for (int t = (int)h->tops.size() - 1; t >= 0; t--) {
+        const Node& nd = h->nodes[h->tops[t]];
+        const int lq = mpqr_part_local_cols(std::min(h->m, nd.c0), h->Ko, h->world, h->rank);
+        apply_node(h, nd, h->dQ, h->ldq, lq, h->qloc, false, 1.f, false);
+    }
+    h->q_formed = true;
+    HIPCHK(h, hipEventRecord(h->ev[2], h->s0));
+    HIPCHK(h, hipGetLastError());
+    return MPQR_OK;
+}
+
+int mpqr_dist_get_local_factor_host(mpqr_handle_t h, float* A_local) {
+    int rc = need_plan(h, true); if (rc) return rc;
+    if (!h->factored) return fail(h, MPQR_ERR_STATE, "nothing has been factored");
+    if (h->nloc == 0) return MPQR_OK;
+    if (!A_local) return MPQR_ERR_INVALID;
+    const size_t el = (size_t)(h->m + 1) * h->nloc;
+    if ((rc = ensure_stage(h, el))) return rc;
+    launch_pack_factor_cyclic(h->dA, h->lda, h->vdiag, h->dstage, h->m, h->nloc, h->Ko, h->world, h->rank, h->s0);
+    HIPCHK(h, hipMemcpyAsync(A_local, h->dstage, el * sizeof(float), hipMemcpyDeviceToHost, h->s0));
+    HIPCHK(h, hipStreamSynchronize(h->s0));
+    return MPQR_OK;
+}
+
+int mpqr_dist_get_local_q_host(mpqr_handle_t h, float* Q_local) {
+    int rc = need_plan(h, true); if (rc) return rc;
+    if (!h->q_formed) return fail(h, MPQR_ERR_STATE, "Q has not been formed");
+    if (h->qloc == 0) return MPQR_OK;
+    if (!Q_local) return MPQR_ERR_INVALID;
+    HIPCHK(h, hipMemcpy2DAsync(Q_local, (size_t)h->qloc * sizeof(float), h->dQ, h->ldq * sizeof(float),
+                               (size_t)h->qloc * sizeof(float), h->m, hipMemcpyDeviceToHost, h->s0));
+    HIPCHK(h, hipStreamSynchronize(h->s0));
+    return MPQR_OK;
+}
+
+int mpqr_dist_get_local_input_host(mpqr_handle_t h, float* A_local) {
+    int rc = need_plan(h, true); if (rc) return rc;
+    if (!h->have_input) return fail(h, MPQR_ERR_STATE, "no input");
+    if (h->nloc == 0) return MPQR_OK;
+    if (!A_local) return MPQR_ERR_INVALID;
+    HIPCHK(h, hipMemcpy2DAsync(A_local, (size_t)h->nloc * sizeof(float), h->dA0, h->lda * sizeof(float),
+                               (size_t)h->nloc * sizeof(float), h->m, hipMemcpyDeviceToHost, h->s0));
+    HIPCHK(h, hipStreamSynchronize(h->s0));
     return MPQR_OK;
 }
 

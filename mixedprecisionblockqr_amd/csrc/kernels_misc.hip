@@ -93,6 +93,60 @@ void launch_unpack_factor(const float* in, int m, int n, int c0, int c1, float* 
                        lda, vdiag, Vh, ldvh, Vt, ldvt);
 }
 
+// ---- distributed layout helpers (1-D block-cyclic columns: local column lc <-> global column gc)
+__device__ __forceinline__ int cyc_global(int lc, int block, int world, int rank) {
+    return ((lc / block) * world + rank) * block + (lc % block);
+}
+__global__ void identity_cyclic_kernel(float* Q, long ldq, int m, int qloc, int block, int world, int rank) {
+    const int lc = blockIdx.x * blockDim.x + threadIdx.x;
+    if (lc >= qloc) return;
+    const int gc = cyc_global(lc, block, world, rank);
+    if (gc < m) Q[(long)gc * ldq + lc] = 1.f;
+}
+void launch_identity_cyclic(float* Q, long ldq, int m, int qloc, int block, int world, int rank, hipStream_t s) {
+    if (qloc <= 0) return;
+    hipLaunchKernelGGL(identity_cyclic_kernel, dim3((qloc + 255) / 256), dim3(256), 0, s, Q, ldq, m, qloc, block, world, rank);
+}
+// boundary layout ((m+1) x nloc, shifted reflectors) of this rank's columns
+__global__ void pack_factor_cyclic_kernel(const float* A, long lda, const float* vdiag, float* out, int m, int nloc,
+                                          int block, int world, int rank) {
+    const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= (long)(m + 1) * nloc) return;
+    const int r = (int)(e / nloc), lc = (int)(e % nloc);
+    const int gc = cyc_global(lc, block, world, rank);
+    float v;
+    if (r <= gc) v = (r < m) ? A[(long)r * lda + lc] : 0.f;
+    else if (r - 1 == gc) v = vdiag[gc];
+    else v = A[(long)(r - 1) * lda + lc];
+    out[e] = v;
+}
+void launch_pack_factor_cyclic(const float* A, long lda, const float* vdiag, float* out, int m, int nloc, int block,
+                               int world, int rank, hipStream_t s) {
+    const long tot = (long)(m + 1) * nloc;
+    if (tot <= 0) return;
+    hipLaunchKernelGGL(pack_factor_cyclic_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, A, lda, vdiag,
+                       out, m, nloc, block, world, rank);
+}
+// dst[c][r] = src[r][c]  (fp16, 64 x 64 tiles through LDS; rows/cols need not be multiples of 64)
+__global__ __launch_bounds__(256) void transpose_h16_kernel(const half_t* __restrict__ src, long lds_, half_t* __restrict__ dst,
+                                                             long ldd, int rows, int cols) {
+    __shared__ half_t tile[64][66];
+    const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+    for (int e = threadIdx.x; e < 64 * 64; e += 256) {
+        const int r = e >> 6, c = e & 63;
+        tile[r][c] = (r0 + r < rows && c0 + c < cols) ? src[(long)(r0 + r) * lds_ + c0 + c] : (half_t)0.f;
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < 64 * 64; e += 256) {
+        const int c = e >> 6, r = e & 63;
+        if (r0 + r < rows && c0 + c < cols) dst[(long)(c0 + c) * ldd + r0 + r] = tile[r][c];
+    }
+}
+void launch_transpose_h16(const half_t* src, long lds_, half_t* dst, long ldd, int rows, int cols, hipStream_t s) {
+    if (rows <= 0 || cols <= 0) return;
+    hipLaunchKernelGGL(transpose_h16_kernel, dim3((cols + 63) / 64, (rows + 63) / 64), dim3(256), 0, s, src, lds_, dst, ldd, rows, cols);
+}
+
 // h_strip_R_from_A, Cuda/qr.cu:85-100
 __global__ void strip_r_kernel(const float* A, long lda, float* R, int m, int n) {
     const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;

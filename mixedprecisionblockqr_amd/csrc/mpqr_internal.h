@@ -85,6 +85,10 @@ void launch_pack_factor(const float* A, long lda, const float* vdiag, float* out
 void launch_unpack_factor(const float* in, int m, int n, int c0, int c1, float* A, long lda, float* vdiag,
                           half_t* Vh, long ldvh, half_t* Vt, long ldvt, hipStream_t s);
 void launch_strip_r(const float* A, long lda, float* R, int m, int n, hipStream_t s);
+void launch_identity_cyclic(float* Q, long ldq, int m, int qloc, int block, int world, int rank, hipStream_t s);
+void launch_pack_factor_cyclic(const float* A, long lda, const float* vdiag, float* out, int m, int nloc, int block,
+                               int world, int rank, hipStream_t s);
+void launch_transpose_h16(const half_t* src, long lds_, half_t* dst, long ldd, int rows, int cols, hipStream_t s);
 void launch_absmax(const float* A, long lda, int m, int n, float* out /*1*/, hipStream_t s);
 // metrics reductions: out[0] += sum (A - B)^2, out[1] += sum A^2
 void launch_diff_norms(const float* A, long lda, const float* B, long ldb, int m, int n, double* out, hipStream_t s);
