@@ -170,6 +170,19 @@ int build_tree(mpqr_handle_t h, int c0, int c1) {
 }
 
 // ---- GEMM wrappers -------------------------------------------------------------
+// large shapes go to the 256 x 256 tile kernel, everything else to the 128 x 128 one
+void gemm_dispatch(AMode am, EMode em, const GemmArgs& g, hipStream_t s) {
+    static const long min_tiles = []() {            // test hook: MPQR_GEMM2_MIN_TILES=1 forces the large kernel early
+        const char* e = getenv("MPQR_GEMM2_MIN_TILES");
+        return e ? atol(e) : 48L;
+    }();
+    const long tiles = (long)(g.M / 256) * (g.N / 256);
+    if (g.nsplit <= 1 && (g.nslab_in <= 1) && g.M >= 256 && g.N >= 256 && tiles >= min_tiles && (g.K % 64) == 0 &&
+        launch_gemm2_f16(am, em, g, s))
+        return;
+    launch_gemm_f16(am, em, g, s);
+}
+
 int choose_split(int M, int N, int K, size_t cap_elems, long slab) {
     const int tiles = ((M + 127) / 128) * ((N + 127) / 128);
     const int ktiles = K / 64;
@@ -221,7 +234,7 @@ void apply_node(mpqr_handle_t h, const Node& nd, float* C, long ldc, int clo, in
     g1.nsplit = choose_split(M1, Kr, Kw, h->xt_elems, slab);
     g1.slab_out_stride = slab;
     if (record) (void)hipEventRecord(e0, h->s0);
-    launch_gemm_f16(A_F32T, E_STORE_F32, g1, h->s0);
+    gemm_dispatch(A_F32T, E_STORE_F32, g1, h->s0);
     if (record) (void)hipEventRecord(e1, h->s0);
     // op2: Yt[M1 x Kr] = fp16( Xt * T' )
     GemmArgs g2{};
@@ -230,7 +243,7 @@ void apply_node(mpqr_handle_t h, const Node& nd, float* C, long ldc, int clo, in
     g2.C = h->Yt; g2.ldc = Kr;
     g2.M = M1; g2.N = Kr; g2.K = Kr;
     g2.in_scale = 1.f; g2.alpha = 1.f; g2.nsplit = 1;
-    launch_gemm_f16(A_F32, E_STORE_H16, g2, h->s0);
+    gemm_dispatch(A_F32, E_STORE_H16, g2, h->s0);
     // op3: C2 -= (1/in_scale) V Yt^T
     GemmArgs g3{};
     g3.A = h->Vh + (long)rlo * h->ldvh + nd.a0; g3.lda = h->ldvh;
@@ -239,7 +252,7 @@ void apply_node(mpqr_handle_t h, const Node& nd, float* C, long ldc, int clo, in
     g3.M = Kw; g3.N = M1; g3.K = Kr;
     g3.col_lo = clo - clo_al; g3.alpha = 1.0f / in_scale; g3.in_scale = 1.f; g3.nsplit = 1;
     if (record) (void)hipEventRecord(e2, h->s0);
-    launch_gemm_f16(A_H16, E_SUB_F32, g3, h->s0);
+    gemm_dispatch(A_H16, E_SUB_F32, g3, h->s0);
     if (record) {
         (void)hipEventRecord(e3, h->s0);
         h->far_ev.push_back(e0); h->far_ev.push_back(e1); h->far_ev.push_back(e2); h->far_ev.push_back(e3);
@@ -430,24 +443,29 @@ static int plan_common(mpqr_handle_t h, int m, int n, int r, const mpqr_opts* op
     h->s_elems = (size_t)16 * max_ldt * max_ldt;
     h->tmp_elems = (size_t)max_ldt * max_ldt;
     h->maxwg = h->m_pad / 256 + 2;
-    if ((rc = dalloc(h, &h->dA, (size_t)h->m_pad * h->lda))) return rc;
-    if ((rc = dalloc(h, &h->dQ, (size_t)h->m_pad * h->ldq))) return rc;
+    // +1024 floats / +256 rows of slack: the 256-wide GEMM tiles load unmasked (results past M, N are masked at the store)
+    if ((rc = dalloc(h, &h->dA, (size_t)h->m_pad * h->lda + 1024))) return rc;
+    if ((rc = dalloc(h, &h->dQ, (size_t)h->m_pad * h->ldq + 1024))) return rc;
     if ((rc = dalloc(h, &h->Vh, (size_t)(h->m_pad + 256) * h->ldvh))) return rc;
     if ((rc = dalloc(h, &h->Vt, (size_t)(h->n_pad + 256) * h->ldvt))) return rc;
     if ((rc = dalloc(h, &h->vdiag, (size_t)h->n_pad))) return rc;
-    if ((rc = dalloc(h, &h->Xt, h->xt_elems))) return rc;
-    if ((rc = dalloc(h, &h->Yt, h->yt_elems))) return rc;
+    if ((rc = dalloc(h, &h->Xt, h->xt_elems + (size_t)256 * max_ldt))) return rc;
+    if ((rc = dalloc(h, &h->Yt, h->yt_elems + (size_t)256 * max_ldt))) return rc;
+    HIPCHK(h, hipMemsetAsync(h->Xt, 0, (h->xt_elems + (size_t)256 * max_ldt) * sizeof(float), h->s0));
+    HIPCHK(h, hipMemsetAsync(h->Yt, 0, (h->yt_elems + (size_t)256 * max_ldt) * sizeof(half_t), h->s0));
     if ((rc = dalloc(h, &h->S, h->s_elems))) return rc;
     if ((rc = dalloc(h, &h->P, (size_t)2 * h->maxwg * 32))) return rc;
     if ((rc = dalloc(h, &h->Gp, (size_t)h->maxwg * 1024))) return rc;
     if ((rc = dalloc(h, &h->Cv, (size_t)1024))) return rc;
     if ((rc = dalloc(h, &h->dflag, (size_t)4))) return rc;
-    if ((rc = dalloc(h, &h->dA0, (size_t)h->m_pad * h->lda))) return rc;
+    if ((rc = dalloc(h, &h->dA0, (size_t)h->m_pad * h->lda + 1024))) return rc;
     if ((rc = dalloc(h, &h->tmp1, h->tmp_elems))) return rc;
     if ((rc = dalloc(h, &h->tmp2, h->tmp_elems))) return rc;
     if ((rc = dalloc(h, &h->Tf, h->t_elems))) return rc;
-    if ((rc = dalloc(h, &h->Th, h->t_elems))) return rc;
-    if ((rc = dalloc(h, &h->Tth, h->t_elems))) return rc;
+    if ((rc = dalloc(h, &h->Th, h->t_elems + (size_t)256 * max_ldt))) return rc;
+    if ((rc = dalloc(h, &h->Tth, h->t_elems + (size_t)256 * max_ldt))) return rc;
+    HIPCHK(h, hipMemsetAsync(h->Th, 0, (h->t_elems + (size_t)256 * max_ldt) * sizeof(half_t), h->s0));
+    HIPCHK(h, hipMemsetAsync(h->Tth, 0, (h->t_elems + (size_t)256 * max_ldt) * sizeof(half_t), h->s0));
     HIPCHK(h, hipMemsetAsync(h->dA0, 0, (size_t)h->m_pad * h->lda * sizeof(float), h->s0));
     HIPCHK(h, hipMemsetAsync(h->dflag, 0, 4 * sizeof(int), h->s0));
     HIPCHK(h, hipMemsetAsync(h->dA, 0, (size_t)h->m_pad * h->lda * sizeof(float), h->s0));

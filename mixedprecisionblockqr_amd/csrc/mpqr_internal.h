@@ -36,6 +36,8 @@ struct GemmArgs {
     int nsplit;          long slab_out_stride;   // E_STORE_F32: K split over gridDim.z slabs
 };
 void launch_gemm_f16(AMode am, EMode em, const GemmArgs& g, hipStream_t s);
+// 256 x 256 x 64 variant for large shapes (no split-K; operands readable up to the next multiple of 256 rows)
+bool launch_gemm2_f16(AMode am, EMode em, const GemmArgs& g, hipStream_t s);
 
 // ------------------------------------------------------------------ fp32 helper GEMM (T merges, metrics)
 // C[M x N] (ldc) = alpha * opA(A) * opB(B) + beta*C, plain fp32 FMA, any sizes.
