@@ -65,8 +65,9 @@ struct mpqr_handle_s {
     half_t* Yt = nullptr;  size_t yt_elems = 0;
     float* S = nullptr;    size_t s_elems = 0;
     float* P = nullptr;    int maxwg = 0;
-    double* Gp = nullptr;  float* Cv = nullptr; int* dflag = nullptr;   // Gram-Householder leaf workspace
-    bool robust = false;          // true: never use the Gram-Householder leaf (set after a flagged run)
+    double* Gp = nullptr; double* Gs = nullptr; float* Cv = nullptr; int* dflag = nullptr;   // Gram-Householder leaf workspace
+    bool robust = false;          // true: tall leaves are factored column by column instead of by Gram-Householder
+    bool force32 = false;         // tree building: only 32-column leaves (sub-tree of a robustly factored tall leaf)
     int gh_min_rows = 1024;       // leaves with more rows than this use Gram-Householder
     float* tmp1 = nullptr; float* tmp2 = nullptr; size_t tmp_elems = 0;
     float* Tf = nullptr; half_t* Th = nullptr; half_t* Tth = nullptr; size_t t_elems = 0;
@@ -125,12 +126,12 @@ int dalloc(mpqr_handle_t h, T** p, size_t elems) {
 
 void free_plan(mpqr_handle_t h) {
     void* ptrs[] = {h->dA, h->dA0, h->dQ, h->Vh, h->Vt, h->vdiag, h->Xt, h->Yt, h->S, h->P, h->tmp1, h->tmp2,
-                    h->Tf, h->Th, h->Tth, h->dstage, h->Gp, h->Cv, h->dflag};
+                    h->Tf, h->Th, h->Tth, h->dstage, h->Gp, h->Gs, h->Cv, h->dflag};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     h->dA = h->dA0 = h->dQ = nullptr; h->Vh = h->Vt = nullptr; h->vdiag = nullptr; h->Xt = nullptr; h->Yt = nullptr;
     h->S = nullptr; h->P = nullptr; h->tmp1 = h->tmp2 = nullptr; h->Tf = nullptr; h->Th = h->Tth = nullptr;
     h->dstage = nullptr; h->stage_elems = 0;
-    h->Gp = nullptr; h->Cv = nullptr; h->dflag = nullptr;
+    h->Gp = nullptr; h->Gs = nullptr; h->Cv = nullptr; h->dflag = nullptr;
     for (hipEvent_t e : h->far_ev) (void)hipEventDestroy(e);
     h->far_ev.clear();
     h->nodes.clear(); h->tops.clear();
@@ -138,9 +139,15 @@ void free_plan(mpqr_handle_t h) {
 }
 
 // ---- column-range tree
-bool is_leaf(int c0, int c1) { return (c1 - c0) <= 32 && (c0 / 32) == ((c1 - 1) / 32); }
+// A node starting at column c0 is "tall" when more than gh_min_rows rows lie below its diagonal: tall leaves are
+// up to 128 columns wide (Gram-Householder), short ones up to 32 (one workgroup, register resident).
+int leaf_width(mpqr_handle_t h, int c0) { return (!h->force32 && h->m - c0 > h->gh_min_rows) ? 128 : 32; }
+bool is_leaf(mpqr_handle_t h, int c0, int c1) {
+    const int lw = leaf_width(h, c0);
+    return (c1 - c0) <= lw && (c0 / lw) == ((c1 - 1) / lw) && (lw == 32 || h->m - c1 >= 1);
+}
 
-int pick_split(int c0, int c1, int r) {
+int pick_split(mpqr_handle_t h, int c0, int c1, int r) {
     const int mid = (c0 + c1) / 2;
     auto nearest_multiple = [&](int a) -> int {
         int lo = rup(c0 + 1, a), best = -1;
@@ -149,6 +156,7 @@ int pick_split(int c0, int c1, int r) {
         return best;
     };
     int s = nearest_multiple(r);            // keep the caller's r-wide panels intact as long as possible
+    if (s < 0 && leaf_width(h, c0) == 128) s = nearest_multiple(128);
     if (s < 0) s = nearest_multiple(32);
     if (s < 0) s = mid;
     return s;
@@ -160,8 +168,8 @@ int build_tree(mpqr_handle_t h, int c0, int c1) {
     nd.left = nd.right = -1; nd.toff = 0;
     const int id = (int)h->nodes.size();
     h->nodes.push_back(nd);
-    if (!is_leaf(c0, c1)) {
-        const int cm = pick_split(c0, c1, h->r);
+    if (!is_leaf(h, c0, c1)) {
+        const int cm = pick_split(h, c0, c1, h->r);
         const int l = build_tree(h, c0, cm);
         const int rr = build_tree(h, cm, c1);
         h->nodes[id].left = l; h->nodes[id].right = rr;
@@ -260,22 +268,56 @@ void apply_node(mpqr_handle_t h, const Node& nd, float* C, long ldc, int clo, in
     }
 }
 
+void factor_node(mpqr_handle_t h, int id, bool do_panel);
+
+// Robust path for a tall (<=128-column) leaf: factor it through a temporary sub-tree of 32-column leaves
+// (column-by-column kernels + MFMA updates inside the leaf) and keep only the sub-tree's root T.
+void robust_tall_leaf(mpqr_handle_t h, const Node nd, bool do_panel) {
+    std::vector<Node> saved_nodes = h->nodes; std::vector<int> saved_tops = h->tops;
+    float* oTf = h->Tf; half_t* oTh = h->Th; half_t* oTth = h->Tth;
+    h->nodes.clear(); h->tops.clear();
+    h->force32 = true;                                   // stays on while the sub-tree is factored
+    const int root = build_tree(h, nd.c0, nd.c1);
+    size_t toff = 0;
+    for (Node& x : h->nodes) { x.toff = toff; toff += (size_t)x.ldt * x.ldt; }
+    float* Tf = nullptr; half_t* Th = nullptr; half_t* Tth = nullptr;
+    const size_t pad = (size_t)256 * 128;
+    if (hipMalloc((void**)&Tf, (toff + pad) * sizeof(float)) == hipSuccess &&
+        hipMalloc((void**)&Th, (toff + pad) * sizeof(half_t)) == hipSuccess &&
+        hipMalloc((void**)&Tth, (toff + pad) * sizeof(half_t)) == hipSuccess) {
+        (void)hipMemsetAsync(Th, 0, (toff + pad) * sizeof(half_t), h->s0);
+        (void)hipMemsetAsync(Tth, 0, (toff + pad) * sizeof(half_t), h->s0);
+        h->Tf = Tf; h->Th = Th; h->Tth = Tth;
+        factor_node(h, root, do_panel);
+        const Node rt = h->nodes[root];
+        const size_t el = (size_t)rt.ldt * rt.ldt;      // same aligned range as nd
+        (void)hipMemcpyAsync(oTf + nd.toff, Tf + rt.toff, el * sizeof(float), hipMemcpyDeviceToDevice, h->s0);
+        (void)hipMemcpyAsync(oTh + nd.toff, Th + rt.toff, el * sizeof(half_t), hipMemcpyDeviceToDevice, h->s0);
+        (void)hipMemcpyAsync(oTth + nd.toff, Tth + rt.toff, el * sizeof(half_t), hipMemcpyDeviceToDevice, h->s0);
+        (void)hipStreamSynchronize(h->s0);
+    }
+    if (Tf) (void)hipFree(Tf); if (Th) (void)hipFree(Th); if (Tth) (void)hipFree(Tth);
+    h->force32 = false;
+    h->Tf = oTf; h->Th = oTh; h->Tth = oTth;
+    h->nodes = saved_nodes; h->tops = saved_tops;
+}
+
 void factor_node(mpqr_handle_t h, int id, bool do_panel) {
     const Node nd = h->nodes[id];
     if (nd.left < 0) {
+        if (do_panel && h->robust && !h->force32 && leaf_width(h, nd.c0) == 128) { robust_tall_leaf(h, nd, do_panel); return; }
         if (do_panel) {
             LeafArgs a{};
-            a.A = h->Aeff; a.lda = h->lda; a.mrows = h->m; a.cb = rdown(nd.c0, 32); a.c0 = nd.c0; a.c1 = nd.c1;
+            const bool tall = leaf_width(h, nd.c0) == 128;
+            a.A = h->Aeff; a.lda = h->lda; a.mrows = h->m; a.cb = rdown(nd.c0, tall ? 128 : 32); a.c0 = nd.c0; a.c1 = nd.c1;
             a.Vh = h->Vh; a.ldvh = h->ldvh; a.Vt = h->Vt; a.ldvt = h->ldvt; a.vdiag = h->vdiag;
             a.P = h->P; a.maxwg = h->maxwg;
-            if (!h->robust && h->m - nd.c0 > h->gh_min_rows && h->m - nd.c1 >= 1)
-                launch_leaf_gram_householder(a, h->Gp, h->Cv, h->dflag, h->s0);
-            else
-                launch_leaf_factor(a, h->s0);
+            if (tall) launch_leaf_gram_householder(a, h->Gp, h->Gs, h->Cv, h->dflag, h->s0);
+            else launch_leaf_factor(a, h->s0);
         }
         int nslab; long slab;
         gram(h, nd, nd, &nslab, &slab);
-        launch_t_leaf(h->S, nslab, slab, nd.a0, nd.c0, nd.c1, h->Tf + nd.toff, h->Th + nd.toff, h->Tth + nd.toff,
+        launch_t_leaf(h->S, nslab, slab, nd.ldt, nd.a0, nd.c0, nd.c1, h->Tf + nd.toff, h->Th + nd.toff, h->Tth + nd.toff,
                       nd.ldt, h->s0);
         return;
     }
@@ -455,8 +497,9 @@ static int plan_common(mpqr_handle_t h, int m, int n, int r, const mpqr_opts* op
     HIPCHK(h, hipMemsetAsync(h->Yt, 0, (h->yt_elems + (size_t)256 * max_ldt) * sizeof(half_t), h->s0));
     if ((rc = dalloc(h, &h->S, h->s_elems))) return rc;
     if ((rc = dalloc(h, &h->P, (size_t)2 * h->maxwg * 32))) return rc;
-    if ((rc = dalloc(h, &h->Gp, (size_t)h->maxwg * 1024))) return rc;
-    if ((rc = dalloc(h, &h->Cv, (size_t)1024))) return rc;
+    if ((rc = dalloc(h, &h->Gp, (size_t)(h->m_pad / 128 + 2) * 16384))) return rc;
+    if ((rc = dalloc(h, &h->Gs, (size_t)16384))) return rc;
+    if ((rc = dalloc(h, &h->Cv, (size_t)16384))) return rc;
     if ((rc = dalloc(h, &h->dflag, (size_t)4))) return rc;
     if ((rc = dalloc(h, &h->dA0, (size_t)h->m_pad * h->lda + 1024))) return rc;
     if ((rc = dalloc(h, &h->tmp1, h->tmp_elems))) return rc;

@@ -20,6 +20,8 @@ namespace mpqr {
 
 constexpr int RPW = 256;   // rows per workgroup
 
+extern __shared__ __attribute__((aligned(16))) char gh_smem[];   // dynamic LDS of the kernels that need > 64 KiB
+
 __device__ __forceinline__ float pick(const float4& v, int c) {
     return c == 0 ? v.x : (c == 1 ? v.y : (c == 2 ? v.z : v.w));
 }
@@ -269,108 +271,137 @@ __global__ __launch_bounds__(1024) void leaf_wg_kernel(LeafArgs a) {
 }
 
 // ------------------------------------------------------------------ tall leaves: "Gram-Householder"
-// After reflectors c0..k-1 every leaf column is (a combination of the ORIGINAL leaf columns) below row c1
-// plus explicit values in the top w = c1-c0 rows:  B_low = A_low M,  B_top explicit.  All inner products over
-// the tall part therefore follow from G = A_low^T A_low (w x w), so the Householder recursion (same u, alpha,
-// v, w_j as above; same sign rule and zero-column skip) runs on w x w matrices:
-//   launch 1  gh_gram   : per-workgroup partial G over 256 rows, fp32 data, products and sums in fp64
-//   launch 2  gh_solve  : one workgroup, fp64: N = M^T G M kept by rank-2 updates, B_top, M; emits R, V_top,
-//                         C (upper triangular, V_low = A_low C) and rho_k = ||u_k||^2 / ||a_k||^2
-//   launch 3  gh_apply  : V_low = A_low C row-parallel in fp32, written over A_low, plus the fp16 copies
-// No pass over the tall data is sequential in k.  Accuracy: V differs from Householder's by O(2^-24 / sqrt(rho));
-// a leaf with rho < GH_RHO_MIN raises a flag and the driver redoes the factorisation on the column-by-column
-// kernels above (which make no such assumption).
+// Leaf = up to 128 adjacent columns [c0,c1) inside one 128-aligned window [cb, cb+128), w = c1-c0.
+// After reflectors c0..k-1 every leaf column is (a combination of the ORIGINAL leaf columns) below row c1 plus
+// explicit values in the top w rows:  B_low = A_low M,  B_top explicit.  All inner products over the tall part
+// therefore follow from G = A_low^T A_low (w x w), and the Householder recursion (same u, alpha, v, w_j, sign
+// rule and zero-column skip as the kernels above) runs on w x w matrices:
+//   gh_gram    : per-workgroup partial G over 128 rows; fp32 data, products and sums in fp64
+//   gh_reduce  : G = sum of the partials (fixed order: deterministic)
+//   gh_solve   : one workgroup; N = Gram of all not-yet-final rows (fp64), B_top and M (fp32) in registers,
+//                4 x 4 entries per thread; emits R, V_top, C (V_low = A_low C) and rho_k = ||u_k||^2 / ||a_k||^2
+//   gh_apply   : V_low = A_low C on the exact-f32 MFMA, written over A_low, plus fp16 copies V and V^T
+// No pass over the tall data is sequential in k.  V differs from Householder's by O(2^-24 / sqrt(rho)); a leaf
+// with rho < GH_RHO_MIN raises a flag and the driver redoes the work on the column-by-column kernels above.
 constexpr double GH_RHO_MIN = 1e-8;
-constexpr int GH_TS = 36;   // LDS row stride (floats) of the staged 256 x 32 tile
+constexpr int GW = 128;          // window width
+constexpr int GH_TS = 132;       // LDS row stride (floats) of a staged 128-column tile
+constexpr int GH_ROWS = 128;     // rows per workgroup in gh_gram
 
 __global__ __launch_bounds__(256) void gh_gram_kernel(LeafArgs a, double* __restrict__ Gp) {
-    __shared__ __attribute__((aligned(16))) float tile[256 * GH_TS];
+    float* tile = (float*)gh_smem;                       // [GH_ROWS][GH_TS]
     const int tid = threadIdx.x;
-    const int row0 = a.c1 + blockIdx.x * 256;
-    {
-        const int cg = tid & 7, rl = tid >> 3;
+    const int row0 = a.c1 + blockIdx.x * GH_ROWS;
 #pragma unroll
-        for (int p = 0; p < 8; p++) {
-            const int lr = p * 32 + rl, row = row0 + lr;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (row < a.mrows) v = *(const float4*)(a.A + (long)row * a.lda + a.cb + 4 * cg);
-            *(float4*)&tile[lr * GH_TS + 4 * cg] = v;
-        }
+    for (int i = 0; i < 16; i++) {
+        const int id = tid + 256 * i, lr = id >> 5, c4 = id & 31, row = row0 + lr;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (row < a.mrows) v = *(const float4*)(a.A + (long)row * a.lda + a.cb + 4 * c4);
+        *(float4*)&tile[lr * GH_TS + 4 * c4] = v;
     }
     __syncthreads();
-    const int i = tid >> 3, j0 = (tid & 7) * 4;
-    double acc0 = 0, acc1 = 0, acc2 = 0, acc3 = 0;
-#pragma unroll 8
-    for (int r = 0; r < 256; r++) {
-        const double ai = (double)tile[r * GH_TS + i];
-        const float4 bj = *(const float4*)&tile[r * GH_TS + j0];
-        acc0 += ai * (double)bj.x; acc1 += ai * (double)bj.y; acc2 += ai * (double)bj.z; acc3 += ai * (double)bj.w;
+    const int bi = tid >> 4, bj = tid & 15;              // 8 x 8 block (bi, bj) of the 128 x 128 Gram
+    double acc[8][8];
+#pragma unroll
+    for (int x = 0; x < 8; x++)
+#pragma unroll
+        for (int y = 0; y < 8; y++) acc[x][y] = 0.0;
+    for (int r = 0; r < GH_ROWS; r++) {
+        const float4 a0 = *(const float4*)&tile[r * GH_TS + 8 * bi], a1 = *(const float4*)&tile[r * GH_TS + 8 * bi + 4];
+        const float4 b0 = *(const float4*)&tile[r * GH_TS + 8 * bj], b1 = *(const float4*)&tile[r * GH_TS + 8 * bj + 4];
+        const double av[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+        const double bv[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+#pragma unroll
+        for (int x = 0; x < 8; x++)
+#pragma unroll
+            for (int y = 0; y < 8; y++) acc[x][y] += av[x] * bv[y];
     }
-    double* out = Gp + (long)blockIdx.x * 1024 + i * 32 + j0;
-    out[0] = acc0; out[1] = acc1; out[2] = acc2; out[3] = acc3;
+    double* out = Gp + (long)blockIdx.x * (GW * GW);
+#pragma unroll
+    for (int x = 0; x < 8; x++)
+#pragma unroll
+        for (int y = 0; y < 8; y++) out[(8 * bi + x) * GW + 8 * bj + y] = acc[x][y];
 }
 
-// One workgroup, 256 threads as a 16 x 16 grid; thread (ti,tj) keeps the 2 x 2 blocks
-// {2ti,2ti+1} x {2tj,2tj+1} of N, B_top and M in registers (fp64).  Per reflector: the owners of row/column k
-// publish them to LDS, every thread derives alpha, inv, w, v_top, c_k redundantly from those vectors, and
-// updates its own entries -- two barriers per step.  s_j needs the top-row dot products sum_t B[t][k] B[t][j]:
-// they are folded into N up front (N holds the Gram of ALL not-yet-final rows) and row k is removed again
-// once it has become a row of R.
-__global__ __launch_bounds__(256) void gh_solve_kernel(LeafArgs a, const double* __restrict__ Gp, int nwg,
-                                                       float* __restrict__ Cv, int* __restrict__ flag) {
-    __shared__ double rowN[32], rowB[32], colB[32], colM[32], col0[32];
-    __shared__ double stage[32][33];
+__global__ __launch_bounds__(256) void gh_reduce_kernel(const double* __restrict__ Gp, int nwg, double* __restrict__ G) {
+    const int e = blockIdx.x * 256 + threadIdx.x;        // 64 blocks x 256 = 16384 entries
+    double s = 0;
+    for (int q = 0; q < nwg; q++) s += Gp[(long)q * (GW * GW) + e];
+    G[e] = s;
+}
+
+__device__ __forceinline__ double fast_rsqrt(double x) {
+    if (!(x > 1e-30 && x < 1e30)) return 1.0 / sqrt(x);
+    double y = (double)rsqrtf((float)x);
+    y = y * (1.5 - 0.5 * x * y * y); y = y * (1.5 - 0.5 * x * y * y); y = y * (1.5 - 0.5 * x * y * y);
+    return y;
+}
+
+// 1024 threads as a 32 x 32 grid; thread (ti,tj) keeps the 4 x 4 blocks {4ti..4ti+3} x {4tj..4tj+3} of
+// N (fp64), B_top and M (fp32) in registers.  Per reflector: owners of row/column k publish them to LDS, every
+// thread derives alpha, inv, w, v_top redundantly and updates its own entries -- two barriers per step.
+// With u = column k over the remaining rows:  s_j = N[k][j],  w_j = 2 (s_j + alpha B[k][j]) inv,
+// v_top[t] = (B[t][k] + [t==k] alpha) inv,  v_low = A_low (M[:,k] inv).  H is orthogonal, so the Gram matrix of the
+// reflected columns over the same rows is unchanged; only the now-final row k (a row of R) leaves the set:
+// N'_ij = N_ij - R[k][i] R[k][j].
+__global__ __launch_bounds__(1024) void gh_solve_kernel(LeafArgs a, const double* __restrict__ G, float* __restrict__ Cv,
+                                                        int* __restrict__ flag) {
+    float* stage = (float*)gh_smem;                       // [GW][GH_TS] copy of B_top for the fold
+    __shared__ double rowN[GW], col0[GW];
+    __shared__ float rowB[GW], colB[GW], colM[GW];
     const int tid = threadIdx.x;
-    const int ti = tid >> 4, tj = tid & 15;
+    const int ti = tid >> 5, tj = tid & 31;
     const int w = a.c1 - a.c0, off = a.c0 - a.cb;
-    double N[2][2], B[2][2], M[2][2];
-    float C[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
+    for (int e = tid; e < GW * GW; e += 1024) Cv[e] = 0.f;
+    double N[4][4];
+    float B[4][4], M[4][4];
 #pragma unroll
-    for (int x = 0; x < 2; x++)
+    for (int x = 0; x < 4; x++)
 #pragma unroll
-        for (int y = 0; y < 2; y++) {
-            const int i = 2 * ti + x, j = 2 * tj + y;
-            double g = 0, b = 0;
+        for (int y = 0; y < 4; y++) {
+            const int i = 4 * ti + x, j = 4 * tj + y;
+            double g = 0; float b = 0.f;
             if (i < w && j < w) {
-                for (int q = 0; q < nwg; q++) g += Gp[(long)q * 1024 + (off + i) * 32 + off + j];
-                b = (double)a.A[(long)(a.c0 + i) * a.lda + a.c0 + j];
+                g = G[(off + i) * GW + off + j];
+                b = a.A[(long)(a.c0 + i) * a.lda + a.c0 + j];
             }
-            N[x][y] = g; B[x][y] = b; M[x][y] = (i == j) ? 1.0 : 0.0;
-            stage[i][j] = b;
+            N[x][y] = g; B[x][y] = b; M[x][y] = (i == j) ? 1.f : 0.f;
+            stage[i * GH_TS + j] = b;
         }
     __syncthreads();
-    // fold the top rows into N: N_ij += sum_t B[t][i] B[t][j]; col0_j = N_jj = ||a_j||^2 over all leaf rows
+    // fold the top rows into N:  N_ij += sum_t B[t][i] B[t][j];  col0_j = ||a_j||^2 over all leaf rows
+    for (int t = 0; t < w; t++) {
+        const float4 bi = *(const float4*)&stage[t * GH_TS + 4 * ti], bj = *(const float4*)&stage[t * GH_TS + 4 * tj];
+        const double vi[4] = {bi.x, bi.y, bi.z, bi.w}, vj[4] = {bj.x, bj.y, bj.z, bj.w};
 #pragma unroll
-    for (int x = 0; x < 2; x++)
+        for (int x = 0; x < 4; x++)
 #pragma unroll
-        for (int y = 0; y < 2; y++) {
-            const int i = 2 * ti + x, j = 2 * tj + y;
-            double s = 0;
-            for (int t = 0; t < w; t++) s += stage[t][i] * stage[t][j];
-            N[x][y] += s;
-            if (i == j) col0[i] = N[x][y];
-        }
+            for (int y = 0; y < 4; y++) N[x][y] += vi[x] * vj[y];
+    }
+    if (ti == tj) {
+#pragma unroll
+        for (int x = 0; x < 4; x++) col0[4 * ti + x] = N[x][x];
+    }
     __syncthreads();
     for (int kr = 0; kr < w; kr++) {
-        // publish row kr of N and B, column kr of B and M
-        if (ti == (kr >> 1)) {
-            const int x = kr & 1;
-            rowN[2 * tj] = N[x][0]; rowN[2 * tj + 1] = N[x][1];
-            rowB[2 * tj] = B[x][0]; rowB[2 * tj + 1] = B[x][1];
+        if (ti == (kr >> 2)) {
+            const int x = kr & 3;
+#pragma unroll
+            for (int y = 0; y < 4; y++) { rowN[4 * tj + y] = N[x][y]; rowB[4 * tj + y] = B[x][y]; }
         }
-        if (tj == (kr >> 1)) {
-            const int y = kr & 1;
-            colB[2 * ti] = B[0][y]; colB[2 * ti + 1] = B[1][y];
-            colM[2 * ti] = M[0][y]; colM[2 * ti + 1] = M[1][y];
+        if (tj == (kr >> 2)) {
+            const int y = kr & 3;
+#pragma unroll
+            for (int x = 0; x < 4; x++) { colB[4 * ti + x] = B[x][y]; colM[4 * ti + x] = M[x][y]; }
         }
         __syncthreads();
-        const double sk = rowN[kr], u0 = rowB[kr];
+        const double sk = rowN[kr], u0 = (double)rowB[kr];
         double alpha = 0, inv = 0;
         bool skip = true;
         if (sk > 0) {
-            const double nu = sqrt(sk);
+            const double rs = fast_rsqrt(sk), nu = sk * rs;
             alpha = (u0 >= 0) ? nu : -nu;
-            inv = 1.0 / sqrt(2.0 * (sk + fabs(u0) * nu));
+            inv = fast_rsqrt(2.0 * (sk + fabs(u0) * nu));
             skip = false;
         }
         if (tid == 0) {
@@ -383,50 +414,49 @@ __global__ __launch_bounds__(256) void gh_solve_kernel(LeafArgs a, const double*
             a.Vt[(long)k * a.ldvt + k] = (half_t)vd;
         }
         if (!skip) {
-            // With u = column kr over the remaining rows:  s_j = u^T b_j = N[kr][j],
-            //   w_j = 2 v^T b_j = 2 (s_j + alpha B[kr][j]) inv,   v_top[t] = (B[t][kr] + [t==kr] alpha) inv,
-            //   v_low = A_low (M[:,kr] inv).
-            // H is orthogonal, so the Gram matrix of the reflected columns over the same rows is unchanged; the
-            // only change to N is that row kr (now a row of R) leaves the set:  N'_ij = N_ij - R[kr][i] R[kr][j].
+            const double vtk = (u0 + alpha) * inv;            // v_top[kr]
+            double wi[4], wj[4];
 #pragma unroll
-            for (int x = 0; x < 2; x++)
+            for (int x = 0; x < 4; x++) {
+                const int i = 4 * ti + x;
+                wi[x] = (i > kr && i < w) ? 2.0 * (rowN[i] + alpha * (double)rowB[i]) * inv : 0.0;
+            }
 #pragma unroll
-                for (int y = 0; y < 2; y++) {
-                    const int i = 2 * ti + x, j = 2 * tj + y;
-                    if (i < w && j < w) {
-                        const double wi = (i > kr) ? 2.0 * (rowN[i] + alpha * rowB[i]) * inv : 0.0;
-                        const double wj = (j > kr) ? 2.0 * (rowN[j] + alpha * rowB[j]) * inv : 0.0;
-                        const double vti = (i >= kr) ? (colB[i] + (i == kr ? alpha : 0.0)) * inv : 0.0;
-                        if (j > kr) {
-                            // B' = B - v_top w^T on rows >= kr
-                            if (i >= kr) B[x][y] -= vti * wj;
-                            // M' = M - (M[:,kr] inv) w^T
-                            if (i <= kr) M[x][y] -= colM[i] * inv * wj;
-                            // remove the now-final row kr:  R[kr][j] = B[kr][j] - v_top[kr] w_j
-                            if (i > kr) {
-                                const double rki = rowB[i] - ((rowB[kr] + alpha) * inv) * wi;
-                                const double rkj = rowB[j] - ((rowB[kr] + alpha) * inv) * wj;
-                                N[x][y] -= rki * rkj;
-                            }
-                        } else if (j == kr) {
-                            if (i > kr) B[x][y] = vti;            // reflector below the diagonal
-                            else if (i == kr) B[x][y] = -alpha;    // R_kk
-                            if (i <= kr) C[x][y] = (float)(colM[i] * inv);
-                        }
+            for (int y = 0; y < 4; y++) {
+                const int j = 4 * tj + y;
+                wj[y] = (j > kr && j < w) ? 2.0 * (rowN[j] + alpha * (double)rowB[j]) * inv : 0.0;
+            }
+#pragma unroll
+            for (int x = 0; x < 4; x++) {
+                const int i = 4 * ti + x;
+                const float vti = (i >= kr && i < w) ? (float)(((double)colB[i] + (i == kr ? alpha : 0.0)) * inv) : 0.f;
+                const float cvi = (i <= kr) ? (float)((double)colM[i] * inv) : 0.f;
+                const double rki = (double)rowB[i] - vtk * wi[x];          // R[kr][i] for i > kr
+#pragma unroll
+                for (int y = 0; y < 4; y++) {
+                    const int j = 4 * tj + y;
+                    if (j > kr && j < w && i < w) {
+                        const float wjf = (float)wj[y];
+                        if (i >= kr) B[x][y] -= vti * wjf;
+                        if (i <= kr) M[x][y] -= cvi * wjf;
+                        if (i > kr) N[x][y] -= rki * ((double)rowB[j] - vtk * wj[y]);
+                    } else if (j == kr && i < w) {
+                        if (i > kr) B[x][y] = vti;                 // reflector below the diagonal
+                        else if (i == kr) B[x][y] = (float)(-alpha);  // R_kk
+                        if (i <= kr) Cv[i * GW + kr] = cvi;
                     }
                 }
+            }
         }
         __syncthreads();
     }
-    // outputs: top block of A (R on/above the diagonal, reflectors below), fp16 copies, C
 #pragma unroll
-    for (int x = 0; x < 2; x++)
+    for (int x = 0; x < 4; x++)
 #pragma unroll
-        for (int y = 0; y < 2; y++) {
-            const int i = 2 * ti + x, j = 2 * tj + y;
-            Cv[i * 32 + j] = (i < w && j < w) ? C[x][y] : 0.f;
+        for (int y = 0; y < 4; y++) {
+            const int i = 4 * ti + x, j = 4 * tj + y;
             if (i < w && j < w) {
-                const float v = (float)B[x][y];
+                const float v = B[x][y];
                 const int row = a.c0 + i, col = a.c0 + j;
                 a.A[(long)row * a.lda + col] = v;
                 if (i > j) {
@@ -437,66 +467,90 @@ __global__ __launch_bounds__(256) void gh_solve_kernel(LeafArgs a, const double*
         }
 }
 
+// V_low = A_low C for 64 rows per workgroup on v_mfma_f32_32x32x2_f32 (exact f32).  LDS: the 64 x 128 row
+// tile (stride 129: conflict-free fragment reads) and C at window coordinates (zero outside the leaf).
+typedef float floatx16p __attribute__((ext_vector_type(16)));
 __global__ __launch_bounds__(256) void gh_apply_kernel(LeafArgs a, const float* __restrict__ Cv) {
-    __shared__ __attribute__((aligned(16))) float tile[256 * GH_TS];
-    __shared__ __attribute__((aligned(16))) float Cs[32 * GH_TS];
-    const int tid = threadIdx.x;
-    const int cg = tid & 7, rl = tid >> 3;
-    const int row0 = a.c1 + blockIdx.x * 256;
+    float* As = (float*)gh_smem;                         // [64][129] = 8256 floats
+    float* Cs = (float*)gh_smem + 8256;                  // [128][GH_TS], 16-B aligned
+    half_t* Ts = (half_t*)gh_smem;                       // [128][72] halves, reuses the As region after the MFMAs
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int row0 = a.c1 + blockIdx.x * 64;
     const int off = a.c0 - a.cb, w = a.c1 - a.c0;
-    // C placed at window coordinates: Cs[off+i][off+k] = Cv[i][k]
-    for (int e = tid; e < 32 * GH_TS; e += 256) Cs[e] = 0.f;
-    __syncthreads();
-    for (int e = tid; e < 1024; e += 256) {
-        const int i = e >> 5, k = e & 31;
-        if (i < w && k < w) Cs[(off + i) * GH_TS + off + k] = Cv[e];
-    }
+    for (int e = tid; e < GW * GH_TS; e += 256) Cs[e] = 0.f;
 #pragma unroll
-    for (int p = 0; p < 8; p++) {
-        const int lr = p * 32 + rl, row = row0 + lr;
+    for (int i = 0; i < 8; i++) {
+        const int id = tid + 256 * i, lr = id >> 5, c4 = id & 31, row = row0 + lr;
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (row < a.mrows) v = *(const float4*)(a.A + (long)row * a.lda + a.cb + 4 * cg);
-        *(float4*)&tile[lr * GH_TS + 4 * cg] = v;
+        if (row < a.mrows) v = *(const float4*)(a.A + (long)row * a.lda + a.cb + 4 * c4);
+        float* d = &As[lr * 129 + 4 * c4];
+        d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
     }
     __syncthreads();
-    float4 acc[8];
+    for (int e = tid; e < GW * GW; e += 256) {
+        const int i = e >> 7, k = e & 127;
+        if (i < w && k < w && i <= k) Cs[(off + i) * GH_TS + off + k] = Cv[e];
+    }
+    __syncthreads();
+    floatx16p acc0, acc1;
 #pragma unroll
-    for (int p = 0; p < 8; p++) acc[p] = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll 4
-    for (int i = 0; i < 32; i++) {
-        const float4 c = *(const float4*)&Cs[i * GH_TS + 4 * cg];
+    for (int e = 0; e < 16; e++) { acc0[e] = 0.f; acc1[e] = 0.f; }
+    const int n0 = 32 * wave, r = lane & 31, kk = lane >> 5;
+    const int kend = min(GW, n0 + 32);                   // C is upper triangular: C[k][j] = 0 for k > j
+    for (int k0 = 0; k0 < kend; k0 += 2) {
+        const float a0 = As[r * 129 + k0 + kk], a1 = As[(32 + r) * 129 + k0 + kk];
+        const float b = Cs[(k0 + kk) * GH_TS + n0 + r];
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b, acc1, 0, 0, 0);
+    }
+    __syncthreads();                                     // As is dead: reuse as the transpose buffer
+    const int gc = a.cb + n0 + r;
+    const bool in_leaf = gc >= a.c0 && gc < a.c1;
 #pragma unroll
-        for (int p = 0; p < 8; p++) {
-            const float x = tile[(p * 32 + rl) * GH_TS + i];
-            acc[p].x += x * c.x; acc[p].y += x * c.y; acc[p].z += x * c.z; acc[p].w += x * c.w;
+    for (int mt = 0; mt < 2; mt++) {
+#pragma unroll
+        for (int e = 0; e < 16; e++) {
+            const int lm = mt * 32 + (e & 3) + 8 * (e >> 2) + 4 * kk;
+            const float v = mt == 0 ? acc0[e] : acc1[e];
+            const int row = row0 + lm;
+            if (in_leaf && row < a.mrows) {
+                a.A[(long)row * a.lda + gc] = v;
+                a.Vh[(long)row * a.ldvh + gc] = (half_t)v;
+            }
+            Ts[(n0 + r) * 72 + lm] = (half_t)v;
         }
     }
-#pragma unroll
-    for (int p = 0; p < 8; p++) {
-        const int lr = p * 32 + rl, row = row0 + lr;
-        if (row < a.mrows) {
-            float4 o = *(const float4*)&tile[lr * GH_TS + 4 * cg];      // columns outside the leaf keep their data
-            const float vals[4] = {acc[p].x, acc[p].y, acc[p].z, acc[p].w};
-            float ov[4] = {o.x, o.y, o.z, o.w};
-#pragma unroll
-            for (int c = 0; c < 4; c++) {
-                const int gc = a.cb + 4 * cg + c;
-                if (gc >= a.c0 && gc < a.c1) {
-                    ov[c] = vals[c];
-                    a.Vh[(long)row * a.ldvh + gc] = (half_t)vals[c];
-                    a.Vt[(long)gc * a.ldvt + row] = (half_t)vals[c];
-                }
+    __syncthreads();
+    // V^T rows: 128 columns x 64 rows of this workgroup, 16-B chunks along the row index
+    for (int e = tid; e < GW * 8; e += 256) {
+        const int c = e >> 3, ch = e & 7;
+        const int gcol = a.cb + c;
+        if (gcol >= a.c0 && gcol < a.c1) {
+            half_t* dst = a.Vt + (long)gcol * a.ldvt + row0 + 8 * ch;
+            if ((row0 & 7) == 0 && row0 + 8 * ch + 8 <= a.mrows) {
+                *(uint4*)dst = *(const uint4*)&Ts[c * 72 + 8 * ch];
+            } else {
+                for (int q = 0; q < 8; q++)
+                    if (row0 + 8 * ch + q < a.mrows) dst[q] = Ts[c * 72 + 8 * ch + q];
             }
-            *(float4*)(a.A + (long)row * a.lda + a.cb + 4 * cg) = make_float4(ov[0], ov[1], ov[2], ov[3]);
         }
     }
 }
 
-void launch_leaf_gram_householder(const LeafArgs& a, double* Gp, float* Cv, int* flag, hipStream_t s) {
-    const int nwg = (a.mrows - a.c1 + 255) / 256;
-    hipLaunchKernelGGL(gh_gram_kernel, dim3(nwg), dim3(256), 0, s, a, Gp);
-    hipLaunchKernelGGL(gh_solve_kernel, dim3(1), dim3(256), 0, s, a, Gp, nwg, Cv, flag);
-    hipLaunchKernelGGL(gh_apply_kernel, dim3(nwg), dim3(256), 0, s, a, Cv);
+void launch_leaf_gram_householder(const LeafArgs& a, double* Gp, double* G, float* Cv, int* flag, hipStream_t s) {
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute((const void*)gh_gram_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, GH_ROWS * GH_TS * 4);
+        (void)hipFuncSetAttribute((const void*)gh_solve_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, GW * GH_TS * 4);
+        (void)hipFuncSetAttribute((const void*)gh_apply_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (8256 + GW * GH_TS) * 4);
+        attr = true;
+    }
+    const int nwg = (a.mrows - a.c1 + GH_ROWS - 1) / GH_ROWS;
+    hipLaunchKernelGGL(gh_gram_kernel, dim3(nwg), dim3(256), GH_ROWS * GH_TS * 4, s, a, Gp);
+    hipLaunchKernelGGL(gh_reduce_kernel, dim3(64), dim3(256), 0, s, Gp, nwg, G);
+    hipLaunchKernelGGL(gh_solve_kernel, dim3(1), dim3(1024), GW * GH_TS * 4, s, a, G, Cv, flag);
+    const int nwa = (a.mrows - a.c1 + 63) / 64;
+    hipLaunchKernelGGL(gh_apply_kernel, dim3(nwa), dim3(256), (8256 + GW * GH_TS) * 4, s, a, Cv);
 }
 
 void launch_leaf_factor(const LeafArgs& a, hipStream_t s) {
@@ -525,55 +579,101 @@ void launch_leaf_factor(const LeafArgs& a, hipStream_t s) {
     }
 }
 
-// ------------------------------------------------------------------ T of a leaf
-// T^{-1} = striu(V^T V) + diag(V^T V)/2  (compact WY with H_i = I - (2/v_i^T v_i) v_i v_i^T), so
-// T_ii = 2/S_ii and T[:i,i] = -T_ii T[:i,:i] S[:i,i].  S is the Gram matrix of the fp16-ROUNDED
-// reflectors, which keeps I - V T V^T orthogonal for the V the MFMA GEMMs actually multiply with.
-__global__ __launch_bounds__(256) void t_leaf_kernel(const float* __restrict__ S, int nslab, long slab_stride, int a0,
-                                                     int c0, int c1, float* __restrict__ T, half_t* __restrict__ Th,
-                                                     half_t* __restrict__ Tth, int ldt) {
-    __shared__ float Ss[32][33];
-    __shared__ float Ts[32][33];
+// ------------------------------------------------------------------ T of a leaf (up to 128 reflectors)
+// T^{-1} = striu(V^T V) + diag(V^T V)/2  (compact WY with H_i = I - (2/v_i^T v_i) v_i v_i^T).  S is the Gram matrix
+// of the fp16-ROUNDED reflectors, which keeps I - V T V^T orthogonal for the V the MFMA GEMMs actually use.
+// One workgroup, everything in LDS: the four 32 x 32 diagonal blocks by the column recurrence
+// (T_ii = 2/S_ii, T[:i,i] = -T_ii T[:i,:i] S[:i,i]; row a depends on row a only, so lane a runs it in registers),
+// then two levels of  T_LR = -T_L (S_LR T_R).  Indices >= w are padded with S = 2 I (T = I), which decouples.
+// Replaces the reference's dev_wy_transform loop (Cuda/qr.cu:535-600: r rounds of three kernels, dense (m-l)^2).
+constexpr int TP = 128, TPS = 129;
+__global__ __launch_bounds__(1024) void t_panel_kernel(const float* __restrict__ S, int nslab, long slab_stride, int lds_,
+                                                       int a0, int c0, int c1, float* __restrict__ T,
+                                                       half_t* __restrict__ Th, half_t* __restrict__ Tth, int ldt) {
+    float* Ss = (float*)gh_smem;             // [TP][TPS]
+    float* Ts = Ss + TP * TPS;               // [TP][TPS]
     const int tid = threadIdx.x;
     const int w = c1 - c0, off = c0 - a0;
-    for (int e = tid; e < 1024; e += 256) {       // one Gram entry per thread and pass, slabs summed in order
-        const int i = e >> 5, j = e & 31;
-        float v = 0.f;
-        if (i < w && j < w && j >= i)
-            for (int sl = 0; sl < nslab; sl++) v += S[(long)sl * slab_stride + (long)(off + i) * 64 + off + j];
-        Ss[i][j] = v;
-    }
-    __syncthreads();
-    // Row a of T depends on row a only: lane a runs the column recurrence in registers, S read as LDS broadcasts.
-    if (tid < 32) {
-        float tr[32];
-#pragma unroll
-        for (int i = 0; i < 32; i++) {
-            const float sii = Ss[i][i];
-            const float tii = (i < w && sii > 0.f) ? 2.0f / sii : 0.f;
-            float sum = 0.f;
-#pragma unroll
-            for (int b = 0; b < i; b++) sum += tr[b] * Ss[b][i];      // tr[b] == 0 for b < a
-            tr[i] = (tid < i) ? -tii * sum : (tid == i ? tii : 0.f);
+    const int nblk = (w + 31) / 32;          // active 32-blocks
+    for (int e = tid; e < TP * TP; e += 1024) {
+        const int i = e >> 7, j = e & 127;
+        float v = (i == j) ? 2.f : 0.f;
+        if (i < w && j < w) {
+            v = 0.f;
+            if (j >= i) for (int sl = 0; sl < nslab; sl++) v += S[(long)sl * slab_stride + (long)(off + i) * lds_ + off + j];
         }
-#pragma unroll
-        for (int i = 0; i < 32; i++) Ts[tid][i] = tr[i];
+        Ss[i * TPS + j] = v;
+        Ts[i * TPS + j] = 0.f;
     }
     __syncthreads();
-    for (int e = tid; e < ldt * ldt; e += 256) {
+    {   // diagonal blocks: wave b <-> block b, lane a <-> row a of the block
+        const int b = tid >> 6, la = tid & 63;
+        if (b < nblk && la < 32) {
+            const int base = 32 * b;
+            float tr[32];
+#pragma unroll
+            for (int i = 0; i < 32; i++) {
+                const float sii = Ss[(base + i) * TPS + base + i];
+                const float tii = sii > 0.f ? 2.0f / sii : 0.f;
+                float sum = 0.f;
+#pragma unroll
+                for (int q = 0; q < i; q++) sum += tr[q] * Ss[(base + q) * TPS + base + i];
+                tr[i] = (la < i) ? -tii * sum : (la == i ? tii : 0.f);
+            }
+#pragma unroll
+            for (int i = 0; i < 32; i++) Ts[(base + la) * TPS + base + i] = tr[i];
+        }
+    }
+    __syncthreads();
+    // merge levels: half = 32 (pairs of 32-blocks), then 64.  X = S_LR T_R is parked in the (unused) lower-left block.
+    for (int half = 32; half < 32 * nblk; half *= 2) {
+        const int span = 2 * half, npair = TP / span;
+        for (int e = tid; e < npair * half * half; e += 1024) {
+            const int p = e / (half * half), rem = e % (half * half), i = rem / half, j = rem % half;
+            const int L0 = p * span, R0 = L0 + half;
+            if (R0 >= 32 * nblk) continue;
+            float x = 0.f;
+            for (int k = 0; k <= j; k++) x += Ss[(L0 + i) * TPS + R0 + k] * Ts[(R0 + k) * TPS + R0 + j];   // T_R upper
+            Ts[(R0 + i) * TPS + L0 + j] = x;                  // X[i][j] parked at (R0+i, L0+j)
+        }
+        __syncthreads();
+        for (int e = tid; e < npair * half * half; e += 1024) {
+            const int p = e / (half * half), rem = e % (half * half), i = rem / half, j = rem % half;
+            const int L0 = p * span, R0 = L0 + half;
+            if (R0 >= 32 * nblk) continue;
+            float t = 0.f;
+            for (int k = i; k < half; k++) t += Ts[(L0 + i) * TPS + L0 + k] * Ts[(R0 + k) * TPS + L0 + j];  // T_L upper
+            Ss[(L0 + i) * TPS + R0 + j] = -t;                 // T_LR staged in Ss (S_LR is no longer needed)
+        }
+        __syncthreads();
+        for (int e = tid; e < npair * half * half; e += 1024) {
+            const int p = e / (half * half), rem = e % (half * half), i = rem / half, j = rem % half;
+            const int L0 = p * span, R0 = L0 + half;
+            if (R0 >= 32 * nblk) continue;
+            Ts[(L0 + i) * TPS + R0 + j] = Ss[(L0 + i) * TPS + R0 + j];
+        }
+        __syncthreads();
+    }
+    for (int e = tid; e < ldt * ldt; e += 1024) {
         const int i = e / ldt, j = e % ldt;
         const int li = i - off, lj = j - off;
         float v = 0.f;
-        if (li >= 0 && li < w && lj >= 0 && lj < w) v = Ts[li][lj];
+        if (li >= 0 && li < w && lj >= li && lj < w) v = Ts[li * TPS + lj];
         T[(long)i * ldt + j] = v;
         Th[(long)i * ldt + j] = (half_t)v;
         Tth[(long)j * ldt + i] = (half_t)v;
     }
 }
 
-void launch_t_leaf(const float* S, int nslab, long slab_stride, int a0, int c0, int c1, float* T, half_t* Th,
+void launch_t_leaf(const float* S, int nslab, long slab_stride, int lds_, int a0, int c0, int c1, float* T, half_t* Th,
                    half_t* Tth, int ldt, hipStream_t s) {
-    hipLaunchKernelGGL(t_leaf_kernel, dim3(1), dim3(256), 0, s, S, nslab, slab_stride, a0, c0, c1, T, Th, Tth, ldt);
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute((const void*)t_panel_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * TP * TPS * 4);
+        attr = true;
+    }
+    hipLaunchKernelGGL(t_panel_kernel, dim3(1), dim3(1024), 2 * TP * TPS * 4, s, S, nslab, slab_stride, lds_, a0, c0, c1, T, Th,
+                       Tth, ldt);
 }
 
 // parent T = [[T_L, T_LR], [0, T_R]] placed inside the parent's 64-aligned reflector range

@@ -66,12 +66,13 @@ struct LeafArgs {
     int maxwg;
 };
 void launch_leaf_factor(const LeafArgs& a, hipStream_t s);   // robust path: one workgroup (<=2048 rows) or one launch per column
-// tall leaves (rows below c1 >= 1): Gram-Householder, 3 launches; raises *flag when a leaf is too ill-conditioned
-void launch_leaf_gram_householder(const LeafArgs& a, double* Gp /* nwg x 1024 */, float* Cv /* 1024 */, int* flag,
-                                  hipStream_t s);
+// tall leaves (up to 128 columns inside a 128-aligned window, a.cb): Gram-Householder, 4 launches; raises *flag
+// when the leaf is too ill-conditioned for it
+void launch_leaf_gram_householder(const LeafArgs& a, double* Gp /* nwg x 16384 */, double* G /* 16384 */,
+                                  float* Cv /* 16384 */, int* flag, hipStream_t s);
 
-// T of a leaf from its Gram slabs: S (64 x 64 per slab, aligned range starting at a0)
-void launch_t_leaf(const float* S, int nslab, long slab_stride, int a0, int c0, int c1,
+// T of a leaf (<= 128 reflectors) from its Gram slabs S (row stride lds_, aligned range starting at a0)
+void launch_t_leaf(const float* S, int nslab, long slab_stride, int lds_, int a0, int c0, int c1,
                    float* T, half_t* Th, half_t* Tth, int ldt, hipStream_t s);
 // assemble a parent T from its children and T_LR
 void launch_t_assemble(float* T, half_t* Th, half_t* Tth, int ldt, int A0,
