@@ -291,7 +291,8 @@ constexpr int GH_ROWS = 128;     // rows per workgroup in gh_gram
 __global__ __launch_bounds__(256) void gh_gram_kernel(LeafArgs a, double* __restrict__ Gp) {
     float* tile = (float*)gh_smem;                       // [GH_ROWS][GH_TS]
     const int tid = threadIdx.x;
-    const int row0 = a.c1 + blockIdx.x * GH_ROWS;
+    const int row0 = a.c1 + (blockIdx.x >> 1) * GH_ROWS;
+    const int hb = blockIdx.x & 1;                        // which half of G's rows this workgroup produces
 #pragma unroll
     for (int i = 0; i < 16; i++) {
         const int id = tid + 256 * i, lr = id >> 5, c4 = id & 31, row = row0 + lr;
@@ -300,27 +301,30 @@ __global__ __launch_bounds__(256) void gh_gram_kernel(LeafArgs a, double* __rest
         *(float4*)&tile[lr * GH_TS + 4 * c4] = v;
     }
     __syncthreads();
-    const int bi = tid >> 4, bj = tid & 15;              // 8 x 8 block (bi, bj) of the 128 x 128 Gram
-    double acc[8][8];
+    // thread -> 4 x 8 block: rows 64*hb + 4*(tid>>4) .. +3, columns 8*(tid&15) .. +7 of the 128 x 128 Gram
+    const int bi = tid >> 4, bj = tid & 15;
+    const int i0 = 64 * hb + 4 * bi;
+    double acc[4][8];
 #pragma unroll
-    for (int x = 0; x < 8; x++)
+    for (int x = 0; x < 4; x++)
 #pragma unroll
         for (int y = 0; y < 8; y++) acc[x][y] = 0.0;
+#pragma unroll 2
     for (int r = 0; r < GH_ROWS; r++) {
-        const float4 a0 = *(const float4*)&tile[r * GH_TS + 8 * bi], a1 = *(const float4*)&tile[r * GH_TS + 8 * bi + 4];
+        const float4 a0 = *(const float4*)&tile[r * GH_TS + i0];
         const float4 b0 = *(const float4*)&tile[r * GH_TS + 8 * bj], b1 = *(const float4*)&tile[r * GH_TS + 8 * bj + 4];
-        const double av[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+        const double av[4] = {a0.x, a0.y, a0.z, a0.w};
         const double bv[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
 #pragma unroll
-        for (int x = 0; x < 8; x++)
+        for (int x = 0; x < 4; x++)
 #pragma unroll
             for (int y = 0; y < 8; y++) acc[x][y] += av[x] * bv[y];
     }
-    double* out = Gp + (long)blockIdx.x * (GW * GW);
+    double* out = Gp + (long)(blockIdx.x >> 1) * (GW * GW);
 #pragma unroll
-    for (int x = 0; x < 8; x++)
+    for (int x = 0; x < 4; x++)
 #pragma unroll
-        for (int y = 0; y < 8; y++) out[(8 * bi + x) * GW + 8 * bj + y] = acc[x][y];
+        for (int y = 0; y < 8; y++) out[(i0 + x) * GW + 8 * bj + y] = acc[x][y];
 }
 
 __global__ __launch_bounds__(256) void gh_reduce_kernel(const double* __restrict__ Gp, int nwg, double* __restrict__ G) {
@@ -337,29 +341,34 @@ __device__ __forceinline__ double fast_rsqrt(double x) {
     return y;
 }
 
-// 1024 threads as a 32 x 32 grid; thread (ti,tj) keeps the 4 x 4 blocks {4ti..4ti+3} x {4tj..4tj+3} of
+// 512 threads as a 16 x 32 grid; thread (ti,tj) keeps the 8 x 4 blocks {8ti..8ti+7} x {4tj..4tj+3} of
 // N (fp64), B_top and M (fp32) in registers.  Per reflector: owners of row/column k publish them to LDS, every
 // thread derives alpha, inv, w, v_top redundantly and updates its own entries -- two barriers per step.
 // With u = column k over the remaining rows:  s_j = N[k][j],  w_j = 2 (s_j + alpha B[k][j]) inv,
 // v_top[t] = (B[t][k] + [t==k] alpha) inv,  v_low = A_low (M[:,k] inv).  H is orthogonal, so the Gram matrix of the
 // reflected columns over the same rows is unchanged; only the now-final row k (a row of R) leaves the set:
 // N'_ij = N_ij - R[k][i] R[k][j].
-__global__ __launch_bounds__(1024) void gh_solve_kernel(LeafArgs a, const double* __restrict__ G, float* __restrict__ Cv,
-                                                        int* __restrict__ flag) {
+constexpr int SR = 8, SC = 4;
+__global__ __launch_bounds__(512) void gh_solve_kernel(LeafArgs a, const double* __restrict__ G, float* __restrict__ Cv,
+                                                       int* __restrict__ flag) {
     float* stage = (float*)gh_smem;                       // [GW][GH_TS] copy of B_top for the fold
     __shared__ double rowN[GW], col0[GW];
-    __shared__ float rowB[GW], colB[GW], colM[GW];
+    __shared__ float rowB[GW], colB[GW], colM[GW], vdl[GW];
+    __shared__ float vw[GW], vvt[GW], vcv[GW], vcol[GW];
+    __shared__ double vrk[GW];
+    __shared__ int lflag;
     const int tid = threadIdx.x;
     const int ti = tid >> 5, tj = tid & 31;
     const int w = a.c1 - a.c0, off = a.c0 - a.cb;
-    for (int e = tid; e < GW * GW; e += 1024) Cv[e] = 0.f;
-    double N[4][4];
-    float B[4][4], M[4][4];
+    if (tid < GW) vdl[tid] = 0.f;
+    if (tid == 0) lflag = 0;
+    double N[SR][SC];
+    float B[SR][SC], M[SR][SC];
 #pragma unroll
-    for (int x = 0; x < 4; x++)
+    for (int x = 0; x < SR; x++)
 #pragma unroll
-        for (int y = 0; y < 4; y++) {
-            const int i = 4 * ti + x, j = 4 * tj + y;
+        for (int y = 0; y < SC; y++) {
+            const int i = SR * ti + x, j = SC * tj + y;
             double g = 0; float b = 0.f;
             if (i < w && j < w) {
                 g = G[(off + i) * GW + off + j];
@@ -371,90 +380,115 @@ __global__ __launch_bounds__(1024) void gh_solve_kernel(LeafArgs a, const double
     __syncthreads();
     // fold the top rows into N:  N_ij += sum_t B[t][i] B[t][j];  col0_j = ||a_j||^2 over all leaf rows
     for (int t = 0; t < w; t++) {
-        const float4 bi = *(const float4*)&stage[t * GH_TS + 4 * ti], bj = *(const float4*)&stage[t * GH_TS + 4 * tj];
-        const double vi[4] = {bi.x, bi.y, bi.z, bi.w}, vj[4] = {bj.x, bj.y, bj.z, bj.w};
+        const float4 bi0 = *(const float4*)&stage[t * GH_TS + SR * ti], bi1 = *(const float4*)&stage[t * GH_TS + SR * ti + 4];
+        const float4 bj = *(const float4*)&stage[t * GH_TS + SC * tj];
+        const double vi[SR] = {bi0.x, bi0.y, bi0.z, bi0.w, bi1.x, bi1.y, bi1.z, bi1.w}, vj[SC] = {bj.x, bj.y, bj.z, bj.w};
 #pragma unroll
-        for (int x = 0; x < 4; x++)
+        for (int x = 0; x < SR; x++)
 #pragma unroll
-            for (int y = 0; y < 4; y++) N[x][y] += vi[x] * vj[y];
+            for (int y = 0; y < SC; y++) N[x][y] += vi[x] * vj[y];
     }
-    if (ti == tj) {
 #pragma unroll
-        for (int x = 0; x < 4; x++) col0[4 * ti + x] = N[x][x];
-    }
+    for (int x = 0; x < SR; x++)
+#pragma unroll
+        for (int y = 0; y < SC; y++)
+            if (SR * ti + x == SC * tj + y) col0[SR * ti + x] = N[x][y];
+    __syncthreads();
+    // the staged copy of B_top is dead: the same LDS now collects C (no global stores inside the k loop --
+    // a barrier would have to wait for them to drain every step)
+    float* Cs = stage;
+    for (int e = tid; e < GW * GH_TS; e += 512) Cs[e] = 0.f;
     __syncthreads();
     for (int kr = 0; kr < w; kr++) {
-        if (ti == (kr >> 2)) {
-            const int x = kr & 3;
+        // (1) owners publish row kr of N, B and column kr of B, M
+        if (ti == (kr >> 3)) {
 #pragma unroll
-            for (int y = 0; y < 4; y++) { rowN[4 * tj + y] = N[x][y]; rowB[4 * tj + y] = B[x][y]; }
+            for (int x = 0; x < SR; x++)
+                if (x == (kr & 7)) {
+#pragma unroll
+                    for (int y = 0; y < SC; y++) { rowN[SC * tj + y] = N[x][y]; rowB[SC * tj + y] = B[x][y]; }
+                }
         }
         if (tj == (kr >> 2)) {
-            const int y = kr & 3;
 #pragma unroll
-            for (int x = 0; x < 4; x++) { colB[4 * ti + x] = B[x][y]; colM[4 * ti + x] = M[x][y]; }
+            for (int y = 0; y < SC; y++)
+                if (y == (kr & 3)) {
+#pragma unroll
+                    for (int x = 0; x < SR; x++) { colB[SR * ti + x] = B[x][y]; colM[SR * ti + x] = M[x][y]; }
+                }
         }
         __syncthreads();
-        const double sk = rowN[kr], u0 = (double)rowB[kr];
-        double alpha = 0, inv = 0;
-        bool skip = true;
-        if (sk > 0) {
-            const double rs = fast_rsqrt(sk), nu = sk * rs;
-            alpha = (u0 >= 0) ? nu : -nu;
-            inv = fast_rsqrt(2.0 * (sk + fabs(u0) * nu));
-            skip = false;
-        }
-        if (tid == 0) {
-            if (!skip && sk < GH_RHO_MIN * col0[kr]) atomicOr(flag, 1);
-            if (skip && col0[kr] > 0) atomicOr(flag, 1);      // cancelled to <= 0 but not an exactly-zero column
-            const int k = a.c0 + kr;
-            const float vd = skip ? 0.f : (float)((u0 + alpha) * inv);
-            a.vdiag[k] = vd;
-            a.Vh[(long)k * a.ldvh + k] = (half_t)vd;
-            a.Vt[(long)k * a.ldvt + k] = (half_t)vd;
-        }
-        if (!skip) {
-            const double vtk = (u0 + alpha) * inv;            // v_top[kr]
-            double wi[4], wj[4];
-#pragma unroll
-            for (int x = 0; x < 4; x++) {
-                const int i = 4 * ti + x;
-                wi[x] = (i > kr && i < w) ? 2.0 * (rowN[i] + alpha * (double)rowB[i]) * inv : 0.0;
+        // (2) one thread per index derives the step's vectors (zeroed outside their index ranges)
+        if (tid < GW) {
+            const int i = tid;
+            const double sk = rowN[kr], u0 = (double)rowB[kr];
+            double alpha = 0, inv = 0;
+            const bool skip = !(sk > 0);
+            if (!skip) {
+                const double rs = fast_rsqrt(sk), nu = sk * rs;
+                alpha = (u0 >= 0) ? nu : -nu;
+                inv = fast_rsqrt(2.0 * (sk + fabs(u0) * nu));
             }
-#pragma unroll
-            for (int y = 0; y < 4; y++) {
-                const int j = 4 * tj + y;
-                wj[y] = (j > kr && j < w) ? 2.0 * (rowN[j] + alpha * (double)rowB[j]) * inv : 0.0;
+            const double vtk = (u0 + alpha) * inv;                    // v_top[kr]
+            const double wd = (i > kr && i < w) ? 2.0 * (rowN[i] + alpha * (double)rowB[i]) * inv : 0.0;
+            vw[i] = (float)wd;                                         // w_i (0 for i <= kr)
+            vrk[i] = (i > kr) ? (double)rowB[i] - vtk * wd : 0.0;      // R[kr][i] (0 for i <= kr)
+            const float vti = (i >= kr && i < w) ? (float)(((double)colB[i] + (i == kr ? alpha : 0.0)) * inv) : 0.f;
+            vvt[i] = vti;                                              // v_top[i] (0 for i < kr)
+            const float cvi = (i <= kr) ? (float)((double)colM[i] * inv) : 0.f;
+            vcv[i] = cvi;                                              // C[i][kr] (0 for i > kr)
+            vcol[i] = skip ? colB[i] : ((i > kr) ? vti : (i == kr ? (float)(-alpha) : colB[i]));   // new column kr of B
+            Cs[i * GH_TS + kr] = cvi;
+            if (i == 0) {
+                if (!skip && sk < GH_RHO_MIN * col0[kr]) lflag = 1;
+                if (skip && col0[kr] > 0) lflag = 1;                  // cancelled to <= 0 but not an exactly-zero column
+                vdl[kr] = skip ? 0.f : (float)vtk;
             }
+        }
+        __syncthreads();
+        // (3) every thread: three FMAs per entry (a skipped column has all-zero vectors: no-op)
+        {
+            float wj[SC]; double rkj[SC];
 #pragma unroll
-            for (int x = 0; x < 4; x++) {
-                const int i = 4 * ti + x;
-                const float vti = (i >= kr && i < w) ? (float)(((double)colB[i] + (i == kr ? alpha : 0.0)) * inv) : 0.f;
-                const float cvi = (i <= kr) ? (float)((double)colM[i] * inv) : 0.f;
-                const double rki = (double)rowB[i] - vtk * wi[x];          // R[kr][i] for i > kr
+            for (int y = 0; y < SC; y++) { wj[y] = vw[SC * tj + y]; rkj[y] = vrk[SC * tj + y]; }
 #pragma unroll
-                for (int y = 0; y < 4; y++) {
-                    const int j = 4 * tj + y;
-                    if (j > kr && j < w && i < w) {
-                        const float wjf = (float)wj[y];
-                        if (i >= kr) B[x][y] -= vti * wjf;
-                        if (i <= kr) M[x][y] -= cvi * wjf;
-                        if (i > kr) N[x][y] -= rki * ((double)rowB[j] - vtk * wj[y]);
-                    } else if (j == kr && i < w) {
-                        if (i > kr) B[x][y] = vti;                 // reflector below the diagonal
-                        else if (i == kr) B[x][y] = (float)(-alpha);  // R_kk
-                        if (i <= kr) Cv[i * GW + kr] = cvi;
-                    }
+            for (int x = 0; x < SR; x++) {
+                const int i = SR * ti + x;
+                const float nvt = -vvt[i], ncv = -vcv[i];
+                const double nrk = -vrk[i];
+#pragma unroll
+                for (int y = 0; y < SC; y++) {
+                    B[x][y] = fmaf(nvt, wj[y], B[x][y]);
+                    M[x][y] = fmaf(ncv, wj[y], M[x][y]);
+                    N[x][y] = fma(nrk, rkj[y], N[x][y]);
                 }
             }
+            if (tj == (kr >> 2)) {                                     // column kr: reflector below, R_kk on the diagonal
+#pragma unroll
+                for (int y = 0; y < SC; y++)
+                    if (y == (kr & 3)) {
+#pragma unroll
+                        for (int x = 0; x < SR; x++) B[x][y] = vcol[SR * ti + x];
+                    }
+            }
         }
-        __syncthreads();
+        // the next publish overwrites rowN/rowB/colB/colM only, the vectors above are rewritten after its barrier
     }
+    __syncthreads();
+    for (int e = tid; e < GW * GW; e += 512) Cv[e] = Cs[(e >> 7) * GH_TS + (e & 127)];
+    if (tid < w) {
+        const int k = a.c0 + tid;
+        const float vd = vdl[tid];
+        a.vdiag[k] = vd;
+        a.Vh[(long)k * a.ldvh + k] = (half_t)vd;
+        a.Vt[(long)k * a.ldvt + k] = (half_t)vd;
+    }
+    if (tid == 0 && lflag) atomicOr(flag, 1);
 #pragma unroll
-    for (int x = 0; x < 4; x++)
+    for (int x = 0; x < SR; x++)
 #pragma unroll
-        for (int y = 0; y < 4; y++) {
-            const int i = 4 * ti + x, j = 4 * tj + y;
+        for (int y = 0; y < SC; y++) {
+            const int i = SR * ti + x, j = SC * tj + y;
             if (i < w && j < w) {
                 const float v = B[x][y];
                 const int row = a.c0 + i, col = a.c0 + j;
@@ -546,9 +580,9 @@ void launch_leaf_gram_householder(const LeafArgs& a, double* Gp, double* G, floa
         attr = true;
     }
     const int nwg = (a.mrows - a.c1 + GH_ROWS - 1) / GH_ROWS;
-    hipLaunchKernelGGL(gh_gram_kernel, dim3(nwg), dim3(256), GH_ROWS * GH_TS * 4, s, a, Gp);
+    hipLaunchKernelGGL(gh_gram_kernel, dim3(2 * nwg), dim3(256), GH_ROWS * GH_TS * 4, s, a, Gp);
     hipLaunchKernelGGL(gh_reduce_kernel, dim3(64), dim3(256), 0, s, Gp, nwg, G);
-    hipLaunchKernelGGL(gh_solve_kernel, dim3(1), dim3(1024), GW * GH_TS * 4, s, a, G, Cv, flag);
+    hipLaunchKernelGGL(gh_solve_kernel, dim3(1), dim3(512), GW * GH_TS * 4, s, a, G, Cv, flag);
     const int nwa = (a.mrows - a.c1 + 63) / 64;
     hipLaunchKernelGGL(gh_apply_kernel, dim3(nwa), dim3(256), (8256 + GW * GH_TS) * 4, s, a, Cv);
 }
