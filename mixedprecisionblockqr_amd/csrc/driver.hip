@@ -60,6 +60,8 @@ struct mpqr_handle_s {
     float* dQ = nullptr;
     half_t* Vh = nullptr;
     half_t* Vt = nullptr;
+    float* Vf = nullptr;      // MPQR_PREC_FP32 only: fp32 reflectors [row][reflector], zero above the diagonal
+    float* Yf = nullptr;      // MPQR_PREC_FP32 only: fp32 Y = X T'
     float* vdiag = nullptr;
     float* Xt = nullptr;   size_t xt_elems = 0;
     half_t* Yt = nullptr;  size_t yt_elems = 0;
@@ -126,12 +128,12 @@ int dalloc(mpqr_handle_t h, T** p, size_t elems) {
 
 void free_plan(mpqr_handle_t h) {
     void* ptrs[] = {h->dA, h->dA0, h->dQ, h->Vh, h->Vt, h->vdiag, h->Xt, h->Yt, h->S, h->P, h->tmp1, h->tmp2,
-                    h->Tf, h->Th, h->Tth, h->dstage, h->Gp, h->Gs, h->Cv, h->dflag};
+                    h->Tf, h->Th, h->Tth, h->dstage, h->Gp, h->Gs, h->Cv, h->dflag, h->Vf, h->Yf};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     h->dA = h->dA0 = h->dQ = nullptr; h->Vh = h->Vt = nullptr; h->vdiag = nullptr; h->Xt = nullptr; h->Yt = nullptr;
     h->S = nullptr; h->P = nullptr; h->tmp1 = h->tmp2 = nullptr; h->Tf = nullptr; h->Th = h->Tth = nullptr;
     h->dstage = nullptr; h->stage_elems = 0;
-    h->Gp = nullptr; h->Gs = nullptr; h->Cv = nullptr; h->dflag = nullptr;
+    h->Gp = nullptr; h->Gs = nullptr; h->Cv = nullptr; h->dflag = nullptr; h->Vf = nullptr; h->Yf = nullptr;
     for (hipEvent_t e : h->far_ev) (void)hipEventDestroy(e);
     h->far_ev.clear();
     h->nodes.clear(); h->tops.clear();
@@ -204,6 +206,15 @@ int choose_split(int M, int N, int K, size_t cap_elems, long slab) {
 // S (slabs, KrL x KrR, ld = KrR) = V_L^T V_R over rows >= 64-aligned start of R
 int gram(mpqr_handle_t h, const Node& L, const Node& R, int* nslab, long* slab) {
     const int rlo = rdown(R.c0, 64);
+    if (h->opts.precision == MPQR_PREC_FP32) {            // exact-f32 products of the fp32 reflectors
+        SgemmArgs g{};
+        g.A = h->Vf + (long)rlo * h->n_pad + L.a0; g.lda = h->n_pad; g.transA = 1;
+        g.B = h->Vf + (long)rlo * h->n_pad + R.a0; g.ldb = h->n_pad; g.transB = 0;
+        g.C = h->S; g.ldc = R.ldt; g.M = L.ldt; g.N = R.ldt; g.K = h->m_pad - rlo; g.alpha = 1.f; g.beta = 0.f; g.nslab_a = 1;
+        launch_sgemm(g, h->s0);
+        *nslab = 1; *slab = (long)L.ldt * R.ldt;
+        return MPQR_OK;
+    }
     GemmArgs g{};
     g.A = h->Vt + (long)L.a0 * h->ldvt + rlo;  g.lda = h->ldvt;
     g.Bt = h->Vt + (long)R.a0 * h->ldvt + rlo; g.ldb = h->ldvt;
@@ -224,6 +235,27 @@ void apply_node(mpqr_handle_t h, const Node& nd, float* C, long ldc, int clo, in
     if (chi <= clo) return;
     const int rlo = rdown(nd.c0, 64);
     const int Kw = h->m_pad - rlo;
+    if (h->opts.precision == MPQR_PREC_FP32) {            // dev_block_qr_wy twin: every product on the exact-f32 MFMA
+        const int M1 = chi - clo, Kr = nd.ldt;
+        const float* Vn = h->Vf + (long)rlo * h->n_pad + nd.a0;
+        SgemmArgs x{};                                     // X[M1 x Kr] = C2^T V
+        x.A = C + (long)rlo * ldc + clo; x.lda = ldc; x.transA = 1;
+        x.B = Vn; x.ldb = h->n_pad; x.transB = 0;
+        x.C = h->Xt; x.ldc = Kr; x.M = M1; x.N = Kr; x.K = Kw; x.alpha = 1.f; x.beta = 0.f; x.nslab_a = 1;
+        launch_sgemm(x, h->s0);
+        SgemmArgs y{};                                     // Y = X T'   (T' = T for the trailing update, T^T for Q)
+        y.A = h->Xt; y.lda = Kr; y.transA = 0; y.nslab_a = 1;
+        y.B = h->Tf + nd.toff; y.ldb = Kr; y.transB = trans_t ? 0 : 1;
+        y.C = h->Yf; y.ldc = Kr; y.M = M1; y.N = Kr; y.K = Kr; y.alpha = 1.f; y.beta = 0.f;
+        launch_sgemm(y, h->s0);
+        SgemmArgs u{};                                     // C2 -= V Y^T
+        u.A = Vn; u.lda = h->n_pad; u.transA = 0; u.nslab_a = 1;
+        u.B = h->Yf; u.ldb = Kr; u.transB = 1;
+        u.C = C + (long)rlo * ldc + clo; u.ldc = ldc; u.M = Kw; u.N = M1; u.K = Kr; u.alpha = -1.f; u.beta = 1.f;
+        launch_sgemm(u, h->s0);
+        (void)record;
+        return;
+    }
     const int clo_al = rdown(clo, 32);
     const int M1 = chi - clo_al;
     const int Kr = nd.ldt;
@@ -314,6 +346,7 @@ void factor_node(mpqr_handle_t h, int id, bool do_panel) {
             a.P = h->P; a.maxwg = h->maxwg;
             if (tall) launch_leaf_gram_householder(a, h->Gp, h->Gs, h->Cv, h->dflag, h->s0);
             else launch_leaf_factor(a, h->s0);
+            if (h->Vf) launch_extract_vf(h->Aeff, h->lda, h->vdiag, h->Vf, h->n_pad, h->m, nd.c0, nd.c1, h->s0);
         }
         int nslab; long slab;
         gram(h, nd, nd, &nslab, &slab);
@@ -348,6 +381,7 @@ int clear_reflectors(mpqr_handle_t h) {
     HIPCHK(h, hipMemsetAsync(h->Vh, 0, (size_t)(h->m_pad + 256) * h->ldvh * sizeof(half_t), h->s0));
     HIPCHK(h, hipMemsetAsync(h->Vt, 0, (size_t)(h->n_pad + 256) * h->ldvt * sizeof(half_t), h->s0));
     HIPCHK(h, hipMemsetAsync(h->vdiag, 0, (size_t)h->n_pad * sizeof(float), h->s0));
+    if (h->Vf) HIPCHK(h, hipMemsetAsync(h->Vf, 0, (size_t)(h->m_pad + 256) * h->n_pad * sizeof(float), h->s0));
     return MPQR_OK;
 }
 
@@ -491,6 +525,11 @@ static int plan_common(mpqr_handle_t h, int m, int n, int r, const mpqr_opts* op
     if ((rc = dalloc(h, &h->Vh, (size_t)(h->m_pad + 256) * h->ldvh))) return rc;
     if ((rc = dalloc(h, &h->Vt, (size_t)(h->n_pad + 256) * h->ldvt))) return rc;
     if ((rc = dalloc(h, &h->vdiag, (size_t)h->n_pad))) return rc;
+    if (o.precision == MPQR_PREC_FP32) {
+        if (world != 1) return fail(h, MPQR_ERR_INVALID, "MPQR_PREC_FP32 is single-GPU only");
+        if ((rc = dalloc(h, &h->Vf, (size_t)(h->m_pad + 256) * h->n_pad))) return rc;
+        if ((rc = dalloc(h, &h->Yf, maxdim * (size_t)max_ldt + (size_t)256 * max_ldt))) return rc;
+    }
     if ((rc = dalloc(h, &h->Xt, h->xt_elems + (size_t)256 * max_ldt))) return rc;
     if ((rc = dalloc(h, &h->Yt, h->yt_elems + (size_t)256 * max_ldt))) return rc;
     HIPCHK(h, hipMemsetAsync(h->Xt, 0, (h->xt_elems + (size_t)256 * max_ldt) * sizeof(float), h->s0));
@@ -585,7 +624,6 @@ static int run_block_loop(mpqr_handle_t h, int* flagged) {
 int mpqr_factor(mpqr_handle_t h) {
     int rc = need_plan(h); if (rc) return rc;
     if (!h->have_input) return fail(h, MPQR_ERR_STATE, "no input matrix has been set");
-    if (h->opts.precision != MPQR_PREC_FP16) return fail(h, MPQR_ERR_INVALID, "MPQR_PREC_FP32 is not built yet");
     if ((rc = compute_scale(h, h->dA0))) return rc;
     int flagged = 0;
     if ((rc = run_block_loop(h, &flagged))) return rc;
@@ -787,8 +825,8 @@ int mpqr_dev_block_qr_wy(float* A, float* Q, int m, int n, int r) {
 
 // ---------------------------------------------------------------- stage-level entry points
 // load a host (m+1) x n buffer whose columns [c0,c1) hold shifted reflectors (others: plain data)
-static int stage_load(mpqr_handle_t h, const float* A, int m, int n, int r, int c0, int c1) {
-    mpqr_opts o; mpqr_default_opts(&o);
+static int stage_load(mpqr_handle_t h, const float* A, int m, int n, int r, int c0, int c1, int precision = MPQR_PREC_FP16) {
+    mpqr_opts o; mpqr_default_opts(&o); o.precision = precision;
     int rc = mpqr_plan(h, m, n, r, &o); if (rc) return rc;
     const size_t el = (size_t)(m + 1) * n;
     if ((rc = ensure_stage(h, el))) return rc;
@@ -796,7 +834,9 @@ static int stage_load(mpqr_handle_t h, const float* A, int m, int n, int r, int 
     if ((rc = clear_reflectors(h))) return rc;
     HIPCHK(h, hipMemcpyAsync(h->dstage, A, el * sizeof(float), hipMemcpyHostToDevice, h->s0));
     launch_unpack_factor(h->dstage, m, n, c0, c1, h->dA, h->lda, h->vdiag, h->Vh, h->ldvh, h->Vt, h->ldvt, h->s0);
+    if (h->Vf && c1 > c0) launch_extract_vf(h->dA, h->lda, h->vdiag, h->Vf, h->n_pad, h->m, c0, c1, h->s0);
     HIPCHK(h, hipStreamSynchronize(h->s0));
+    h->Aeff = h->dA;
     h->factored = false; h->q_formed = false; h->have_input = false;
     return MPQR_OK;
 }
@@ -912,9 +952,9 @@ int mpqr_wy_transform_f32(mpqr_handle_t h, const float* A, int m, int n, int go,
 int mpqr_apply_panel_to_trailing_f32(mpqr_handle_t h, float* A, int m, int n, int go, int pw, int precision) {
     int rc = check_shape(h, m, n, 1); if (rc) return rc;
     if (!A || go < 0 || pw < 1 || go + pw > n) return fail(h, MPQR_ERR_INVALID, "bad panel range");
-    if (precision != MPQR_PREC_FP16) return fail(h, MPQR_ERR_INVALID, "MPQR_PREC_FP32 is not built yet");
+    if (precision != MPQR_PREC_FP16 && precision != MPQR_PREC_FP32) return fail(h, MPQR_ERR_INVALID, "unknown precision");
     const int c0 = go, c1 = go + pw;
-    if ((rc = stage_load(h, A, m, n, pw, c0, c1))) return rc;
+    if ((rc = stage_load(h, A, m, n, pw, c0, c1, precision))) return rc;
     if ((rc = compute_scale(h, h->dA))) return rc;
     StageTree st;
     if ((rc = stage_tree_begin(h, st, c0, c1, pw))) { stage_tree_end(h, st); return rc; }

@@ -147,6 +147,20 @@ void launch_transpose_h16(const half_t* src, long lds_, half_t* dst, long ldd, i
     hipLaunchKernelGGL(transpose_h16_kernel, dim3((cols + 63) / 64, (rows + 63) / 64), dim3(256), 0, s, src, lds_, dst, ldd, rows, cols);
 }
 
+// fp32 copy of the reflectors of columns [c0,c1) (MPQR_PREC_FP32): zero above the diagonal, v_k[0] from vdiag
+__global__ void extract_vf_kernel(const float* A, long lda, const float* vdiag, float* Vf, long ldvf, int rows, int c0, int c1) {
+    const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int w = c1 - c0;
+    if (e >= (long)rows * w) return;
+    const int r = (int)(e / w), c = c0 + (int)(e % w);
+    Vf[(long)r * ldvf + c] = (r > c) ? A[(long)r * lda + c] : (r == c ? vdiag[c] : 0.f);
+}
+void launch_extract_vf(const float* A, long lda, const float* vdiag, float* Vf, long ldvf, int rows, int c0, int c1, hipStream_t s) {
+    const long tot = (long)rows * (c1 - c0);
+    if (tot <= 0) return;
+    hipLaunchKernelGGL(extract_vf_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, A, lda, vdiag, Vf, ldvf, rows, c0, c1);
+}
+
 // h_strip_R_from_A, Cuda/qr.cu:85-100
 __global__ void strip_r_kernel(const float* A, long lda, float* R, int m, int n) {
     const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;

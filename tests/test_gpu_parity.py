@@ -237,6 +237,40 @@ def test_error_behaviour(mp, h):
     h2.close()
 
 
+@pytest.mark.parametrize("m,n,r", [(6, 4, 2), (12, 8, 5), (60, 40, 16), (97, 90, 16), (129, 80, 16), (600, 400, 16), (1300, 500, 64)])
+def test_fp32_twin_dev_block_qr_wy(mp, h, po, m, n, r):
+    """dev_block_qr_wy (Cuda/qr.cu:958-1047): fp32 everywhere -> the reference's fp32 criterion 2^-23 * m
+    (qr.cu:1836) and element-wise agreement with the oracle's fp32 path."""
+    A = po.generate(m, n, seed=1234)
+    Ao = np.zeros((m + 1, n), np.float32); Ao[:m] = A
+    Q = np.zeros((m, m), np.float32)
+    mp.dev_block_qr_wy(Ao, Q, m, n, r, handle=h)
+    R = mp.h_strip_R_from_A(Ao, m, n)
+    A0, Q0, R0 = po.householder_qr(A)
+    mt = po.metrics(A, R, Q)
+    for key in ("backward_error", "q_error_max_signed", "lower_trapezoid"):
+        assert po.lib().orc_error_passes(mt[key], m, 23), (key, mt)
+    assert mt["backward_error_f64"] <= 3e-6 and mt["q_error_fro"] <= 3e-6 * np.sqrt(m) * 4
+    tol = 3e-5 * np.sqrt(m)
+    np.testing.assert_allclose(R, R0, atol=tol * max(1.0, np.abs(R0).max() / 10))
+    np.testing.assert_allclose(Q, Q0, atol=tol)
+    np.testing.assert_allclose(po.extract_V(Ao, m, n, 0, n), po.extract_V(A0, m, n, 0, n), atol=tol)
+
+
+def test_fp32_trailing_update(mp, h, po):
+    """a-3 in fp32 (the reference's own precision for this step, Cuda/mmult.cu:236-288): tight tolerance."""
+    m, n, go, pw = 300, 200, 64, 64
+    A = po.generate(m, n, seed=3)
+    Ac = po.padded(A)
+    po.lib().orc_householder_qr(Ac, m, n, go, pw)
+    Ag = Ac.copy()
+    mp.apply_panel_to_trailing(Ag, m, n, go, pw, precision=mp.PREC_FP32, handle=h)
+    Qp = po.wy_transform(Ac, m, n, go, pw).astype(np.float64)
+    want = Ac[:m].astype(np.float64).copy()
+    want[go:, go + pw:] = Qp.T @ want[go:, go + pw:]
+    np.testing.assert_allclose(Ag[go:m, go + pw:], want[go:, go + pw:], atol=2e-5)
+
+
 # ---------------------------------------------------------------- distributed path on the one GPU of the box
 def _run_lockstep(mp, engines):
     """Drive `world` GpuEngines (all on cuda:0) through the distributed schedule in lock step: exactly the calls
