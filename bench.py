@@ -32,8 +32,8 @@ def cpu_baseline(budget_s=20.0):
     from oracle import pyoracle as po
     import mixedprecisionblockqr_amd as mp
     m = n = 2048; r = 64
-    cores = len(os.sched_getaffinity(0))
-    os.environ.setdefault("OMP_NUM_THREADS", str(cores))
+    cores = min(len(os.sched_getaffinity(0)), 16)       # the GPU box gives one job a 16-core share
+    os.environ["OMP_NUM_THREADS"] = str(cores)
     A = po.generate(m, n, seed=1234)
     Ao = po.padded(A); Q = np.eye(m, dtype=np.float32)
     t0 = time.perf_counter()
@@ -41,6 +41,21 @@ def cpu_baseline(budget_s=20.0):
     dt = time.perf_counter() - t0
     return {"value": mp.flops(m, n, r)["geqrf"] / dt / 1e9, "unit": "GFLOP/s", "cores": cores, "kind": "port",
             "sample": f"{m}x{n} r={r} fp32 compact-WY block loop incl. Q formation, {dt:.1f} s, GEQRF-equivalent flops"}
+
+
+def _pmc_traffic():
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes of this same command
+    (profiles/, tools/pmc_traffic.py); PMC counters cannot be read from inside the timed run."""
+    best = None
+    pdir = os.path.join(ROOT, "profiles")
+    if os.path.isdir(pdir):
+        for f in sorted(os.listdir(pdir)):
+            if f.endswith("traffic_far_nn.json"):
+                try:
+                    best = json.load(open(os.path.join(pdir, f)))["hbm_bytes_per_launch"]
+                except Exception:
+                    pass
+    return best
 
 
 def main():
@@ -51,6 +66,7 @@ def main():
     ap.add_argument("--config", default="c4", choices=sorted(CONFIGS))
     ap.add_argument("--outer-block", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-lookahead", action="store_true")
     args = ap.parse_args()
 
     import torch
@@ -66,7 +82,7 @@ def main():
 
     torch.cuda.set_device(0)
     h = mp.Handle(0)
-    h.plan(m, n, r, outer_block=args.outer_block)
+    h.plan(m, n, r, outer_block=args.outer_block, lookahead=not args.no_lookahead)
     h.generate(1234)
     h.sync()
 
@@ -92,7 +108,7 @@ def main():
         ach = tm["flops_far_nn"] / nn_t / 1e12
         roof = {"bound": "mfma", "kernel": "gemm_f16_kernel<A_H16,E_SUB_F32> (far A2 -= V*Y^T)",
                 "achieved": ach, "peak": PEAK_FP16_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_FP16_TFLOPS,
-                "traffic": None, "launches": tm["n_far_launches"],
+                "traffic": _pmc_traffic(), "launches": tm["n_far_launches"],
                 "avg_launch_ms": tm["ms_far_nn"] / tm["n_far_launches"],
                 "tn_achieved": (tm["flops_far_tn"] / (tm["ms_far_tn"] * 1e-3) / 1e12) if tm["ms_far_tn"] > 0 else None}
     out = {

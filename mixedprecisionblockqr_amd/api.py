@@ -18,7 +18,7 @@ class MpqrError(RuntimeError):
         self.code = code
 
 
-def _opts(precision=L.PREC_FP16, outer_block=0, form_q=True, lookahead=False):
+def _opts(precision=L.PREC_FP16, outer_block=0, form_q=True, lookahead=True):
     o = L.MpqrOpts()
     L.lib().mpqr_default_opts(C.byref(o))
     o.precision, o.outer_block, o.form_q, o.lookahead = int(precision), int(outer_block), int(bool(form_q)), int(bool(lookahead))

@@ -45,7 +45,8 @@ inline int rup(int x, int a) { return ((x + a - 1) / a) * a; }
 
 struct mpqr_handle_s {
     int device = 0;
-    hipStream_t s0 = nullptr;
+    hipStream_t s0 = nullptr;   // panel chain (high priority)
+    hipStream_t s1 = nullptr;   // far trailing updates / Q formation when opts.lookahead (low priority)
     std::string err;
 
     bool planned = false;
@@ -65,6 +66,8 @@ struct mpqr_handle_s {
     float* vdiag = nullptr;
     float* Xt = nullptr;   size_t xt_elems = 0;
     half_t* Yt = nullptr;  size_t yt_elems = 0;
+    float* Xt1 = nullptr;  half_t* Yt1 = nullptr;      // scratch of the far-update stream (look-ahead)
+    std::vector<hipEvent_t> ev_node, ev_cols;          // per top-level node: reflectors ready / columns up to date
     float* S = nullptr;    size_t s_elems = 0;
     float* P = nullptr;    int maxwg = 0;
     double* Gp = nullptr; double* Gs = nullptr; float* Cv = nullptr; int* dflag = nullptr;   // Gram-Householder leaf workspace
@@ -128,12 +131,16 @@ int dalloc(mpqr_handle_t h, T** p, size_t elems) {
 
 void free_plan(mpqr_handle_t h) {
     void* ptrs[] = {h->dA, h->dA0, h->dQ, h->Vh, h->Vt, h->vdiag, h->Xt, h->Yt, h->S, h->P, h->tmp1, h->tmp2,
-                    h->Tf, h->Th, h->Tth, h->dstage, h->Gp, h->Gs, h->Cv, h->dflag, h->Vf, h->Yf};
+                    h->Tf, h->Th, h->Tth, h->dstage, h->Gp, h->Gs, h->Cv, h->dflag, h->Vf, h->Yf, h->Xt1, h->Yt1};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     h->dA = h->dA0 = h->dQ = nullptr; h->Vh = h->Vt = nullptr; h->vdiag = nullptr; h->Xt = nullptr; h->Yt = nullptr;
     h->S = nullptr; h->P = nullptr; h->tmp1 = h->tmp2 = nullptr; h->Tf = nullptr; h->Th = h->Tth = nullptr;
     h->dstage = nullptr; h->stage_elems = 0;
     h->Gp = nullptr; h->Gs = nullptr; h->Cv = nullptr; h->dflag = nullptr; h->Vf = nullptr; h->Yf = nullptr;
+    h->Xt1 = nullptr; h->Yt1 = nullptr;
+    for (hipEvent_t e : h->ev_node) (void)hipEventDestroy(e);
+    for (hipEvent_t e : h->ev_cols) (void)hipEventDestroy(e);
+    h->ev_node.clear(); h->ev_cols.clear();
     for (hipEvent_t e : h->far_ev) (void)hipEventDestroy(e);
     h->far_ev.clear();
     h->nodes.clear(); h->tops.clear();
@@ -181,6 +188,10 @@ int build_tree(mpqr_handle_t h, int c0, int c1) {
 
 // ---- GEMM wrappers -------------------------------------------------------------
 // large shapes go to the 256 x 256 tile kernel, everything else to the 128 x 128 one
+int gemm2_config() {        // test/tuning hook: MPQR_GEMM2_CONFIG selects the large-kernel tile configuration
+    static const int c = []() { const char* e = getenv("MPQR_GEMM2_CONFIG"); return e ? atoi(e) : 0; }();
+    return c;
+}
 void gemm_dispatch(AMode am, EMode em, const GemmArgs& g, hipStream_t s) {
     static const long min_tiles = []() {            // test hook: MPQR_GEMM2_MIN_TILES=1 forces the large kernel early
         const char* e = getenv("MPQR_GEMM2_MIN_TILES");
@@ -188,7 +199,7 @@ void gemm_dispatch(AMode am, EMode em, const GemmArgs& g, hipStream_t s) {
     }();
     const long tiles = (long)(g.M / 256) * (g.N / 256);
     if (g.nsplit <= 1 && (g.nslab_in <= 1) && g.M >= 256 && g.N >= 256 && tiles >= min_tiles && (g.K % 64) == 0 &&
-        launch_gemm2_f16(am, em, g, s))
+        launch_gemm2_f16(am, em, g, s, gemm2_config()))
         return;
     launch_gemm_f16(am, em, g, s);
 }
@@ -231,8 +242,11 @@ int gram(mpqr_handle_t h, const Node& L, const Node& R, int* nslab, long* slab) 
 
 // C[rows >= rdown(nd.c0,64)][cols clo..chi) <- (I - V T' V^T) C,  T' = T^T (trans_t) or T
 void apply_node(mpqr_handle_t h, const Node& nd, float* C, long ldc, int clo, int chi, bool trans_t, float in_scale,
-                bool record) {
+                bool record, int lane = 0) {
     if (chi <= clo) return;
+    hipStream_t st = lane ? h->s1 : h->s0;                 // lane 1: far-update stream with its own scratch
+    float* const Xt = lane ? h->Xt1 : h->Xt;
+    half_t* const Yt = lane ? h->Yt1 : h->Yt;
     const int rlo = rdown(nd.c0, 64);
     const int Kw = h->m_pad - rlo;
     if (h->opts.precision == MPQR_PREC_FP32) {            // dev_block_qr_wy twin: every product on the exact-f32 MFMA
@@ -267,34 +281,34 @@ void apply_node(mpqr_handle_t h, const Node& nd, float* C, long ldc, int clo, in
     GemmArgs g1{};
     g1.A = C + (long)rlo * ldc + clo_al; g1.lda = ldc;
     g1.Bt = h->Vt + (long)nd.a0 * h->ldvt + rlo; g1.ldb = h->ldvt;
-    g1.C = h->Xt; g1.ldc = Kr;
+    g1.C = Xt; g1.ldc = Kr;
     g1.M = M1; g1.N = Kr; g1.K = Kw;
     g1.in_scale = in_scale; g1.alpha = 1.f;
     const long slab = (long)M1 * Kr;
     g1.nsplit = choose_split(M1, Kr, Kw, h->xt_elems, slab);
     g1.slab_out_stride = slab;
-    if (record) (void)hipEventRecord(e0, h->s0);
-    gemm_dispatch(A_F32T, E_STORE_F32, g1, h->s0);
-    if (record) (void)hipEventRecord(e1, h->s0);
+    if (record) (void)hipEventRecord(e0, st);
+    gemm_dispatch(A_F32T, E_STORE_F32, g1, st);
+    if (record) (void)hipEventRecord(e1, st);
     // op2: Yt[M1 x Kr] = fp16( Xt * T' )
     GemmArgs g2{};
-    g2.A = h->Xt; g2.lda = Kr; g2.nslab_in = g1.nsplit; g2.slab_in_stride = slab;
+    g2.A = Xt; g2.lda = Kr; g2.nslab_in = g1.nsplit; g2.slab_in_stride = slab;
     g2.Bt = (trans_t ? h->Tth : h->Th) + nd.toff; g2.ldb = Kr;
-    g2.C = h->Yt; g2.ldc = Kr;
+    g2.C = Yt; g2.ldc = Kr;
     g2.M = M1; g2.N = Kr; g2.K = Kr;
     g2.in_scale = 1.f; g2.alpha = 1.f; g2.nsplit = 1;
-    gemm_dispatch(A_F32, E_STORE_H16, g2, h->s0);
+    gemm_dispatch(A_F32, E_STORE_H16, g2, st);
     // op3: C2 -= (1/in_scale) V Yt^T
     GemmArgs g3{};
     g3.A = h->Vh + (long)rlo * h->ldvh + nd.a0; g3.lda = h->ldvh;
-    g3.Bt = h->Yt; g3.ldb = Kr;
+    g3.Bt = Yt; g3.ldb = Kr;
     g3.C = C + (long)rlo * ldc + clo_al; g3.ldc = ldc;
     g3.M = Kw; g3.N = M1; g3.K = Kr;
     g3.col_lo = clo - clo_al; g3.alpha = 1.0f / in_scale; g3.in_scale = 1.f; g3.nsplit = 1;
-    if (record) (void)hipEventRecord(e2, h->s0);
-    gemm_dispatch(A_H16, E_SUB_F32, g3, h->s0);
+    if (record) (void)hipEventRecord(e2, st);
+    gemm_dispatch(A_H16, E_SUB_F32, g3, st);
     if (record) {
-        (void)hipEventRecord(e3, h->s0);
+        (void)hipEventRecord(e3, st);
         h->far_ev.push_back(e0); h->far_ev.push_back(e1); h->far_ev.push_back(e2); h->far_ev.push_back(e3);
         h->far_flops.push_back(2.0 * M1 * (double)Kr * Kw);
     }
@@ -413,6 +427,18 @@ int form_q(mpqr_handle_t h) {
     return MPQR_OK;
 }
 
+// The far-update stream may use only 3 of every 4 CUs: its GEMM workgroups hold a CU's LDS for ~100 us each, and
+// the latency-bound panel kernels on s0 would otherwise queue behind them (MPQR_UPDATE_CU_MASK=0 disables this).
+hipError_t create_update_stream(hipStream_t* st, int prio) {
+    const char* e = getenv("MPQR_UPDATE_CU_MASK");
+    if (e && atoi(e) == 0) return hipStreamCreateWithPriority(st, hipStreamNonBlocking, prio);
+    uint32_t mask[8];
+    for (int i = 0; i < 8; i++) mask[i] = 0xEEEEEEEEu;      // CU i enabled unless i % 4 == 0
+    hipError_t rc = hipExtStreamCreateWithCUMask(st, 8, mask);
+    if (rc != hipSuccess) rc = hipStreamCreateWithPriority(st, hipStreamNonBlocking, prio);
+    return rc;
+}
+
 int check_shape(mpqr_handle_t h, int m, int n, int r) {
     if (!h) return MPQR_ERR_INVALID;
     if (m < 1 || n < 1 || r < 1) return fail(h, MPQR_ERR_INVALID, "m, n, r must be >= 1");
@@ -436,7 +462,7 @@ void mpqr_default_opts(mpqr_opts* o) {
     o->precision = MPQR_PREC_FP16;
     o->outer_block = 0;
     o->form_q = 1;
-    o->lookahead = 0;
+    o->lookahead = 1;
 }
 
 int mpqr_create(mpqr_handle_t* out, int device) {
@@ -453,7 +479,11 @@ int mpqr_create(mpqr_handle_t* out, int device) {
     h->device = device;
     mpqr_default_opts(&h->opts);
     memset(&h->last_t, 0, sizeof h->last_t);
-    if (hipSetDevice(device) != hipSuccess || hipStreamCreate(&h->s0) != hipSuccess) {
+    int prio_lo = 0, prio_hi = 0;
+    (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
+    if (hipSetDevice(device) != hipSuccess ||
+        hipStreamCreateWithPriority(&h->s0, hipStreamNonBlocking, prio_hi) != hipSuccess ||
+        create_update_stream(&h->s1, prio_lo) != hipSuccess) {
         g_create_err = "hipSetDevice/hipStreamCreate failed";
         delete h;
         return MPQR_ERR_HIP;
@@ -473,11 +503,13 @@ int mpqr_destroy(mpqr_handle_t h) {
     if (!h) return MPQR_ERR_INVALID;
     (void)hipSetDevice(h->device);
     (void)hipStreamSynchronize(h->s0);
+    if (h->s1) (void)hipStreamSynchronize(h->s1);
     free_plan(h);
     if (h->dmetric) (void)hipFree(h->dmetric);
     if (h->dscalar) (void)hipFree(h->dscalar);
     for (int i = 0; i < 4; i++) if (h->ev[i]) (void)hipEventDestroy(h->ev[i]);
     (void)hipStreamDestroy(h->s0);
+    if (h->s1) (void)hipStreamDestroy(h->s1);
     delete h;
     return MPQR_OK;
 }
@@ -534,6 +566,18 @@ static int plan_common(mpqr_handle_t h, int m, int n, int r, const mpqr_opts* op
     if ((rc = dalloc(h, &h->Yt, h->yt_elems + (size_t)256 * max_ldt))) return rc;
     HIPCHK(h, hipMemsetAsync(h->Xt, 0, (h->xt_elems + (size_t)256 * max_ldt) * sizeof(float), h->s0));
     HIPCHK(h, hipMemsetAsync(h->Yt, 0, (h->yt_elems + (size_t)256 * max_ldt) * sizeof(half_t), h->s0));
+    if (o.lookahead && world == 1 && o.precision == MPQR_PREC_FP16) {
+        if ((rc = dalloc(h, &h->Xt1, h->xt_elems + (size_t)256 * max_ldt))) return rc;
+        if ((rc = dalloc(h, &h->Yt1, h->yt_elems + (size_t)256 * max_ldt))) return rc;
+        HIPCHK(h, hipMemsetAsync(h->Xt1, 0, (h->xt_elems + (size_t)256 * max_ldt) * sizeof(float), h->s0));
+        HIPCHK(h, hipMemsetAsync(h->Yt1, 0, (h->yt_elems + (size_t)256 * max_ldt) * sizeof(half_t), h->s0));
+        for (size_t t = 0; t < h->tops.size(); t++) {
+            hipEvent_t e1, e2;
+            HIPCHK(h, hipEventCreateWithFlags(&e1, hipEventDisableTiming));
+            HIPCHK(h, hipEventCreateWithFlags(&e2, hipEventDisableTiming));
+            h->ev_node.push_back(e1); h->ev_cols.push_back(e2);
+        }
+    }
     if ((rc = dalloc(h, &h->S, h->s_elems))) return rc;
     if ((rc = dalloc(h, &h->P, (size_t)2 * h->maxwg * 32))) return rc;
     if ((rc = dalloc(h, &h->Gp, (size_t)(h->m_pad / 128 + 2) * 16384))) return rc;
@@ -607,10 +651,33 @@ static int run_block_loop(mpqr_handle_t h, int* flagged) {
     HIPCHK(h, hipMemcpyAsync(h->dA, h->dA0, (size_t)h->m_pad * h->lda * sizeof(float), hipMemcpyDeviceToDevice, h->s0));
     HIPCHK(h, hipMemsetAsync(h->dflag, 0, sizeof(int), h->s0));
     if ((rc = clear_reflectors(h))) return rc;
+    const bool la = h->Xt1 != nullptr;                    // look-ahead: far updates on s1, panel chain on s0
+    if (la) {
+        // s1 must see the copy-in / clears issued on s0
+        HIPCHK(h, hipEventRecord(h->ev[3], h->s0));
+        HIPCHK(h, hipStreamWaitEvent(h->s1, h->ev[3], 0));
+    }
     for (size_t t = 0; t < h->tops.size(); t++) {
         const Node nd = h->nodes[h->tops[t]];
+        if (!la) {
+            factor_node(h, h->tops[t], true);
+            apply_node(h, nd, h->dA, h->lda, nd.c1, h->n, true, h->a_scale, true);
+            continue;
+        }
+        if (t > 0) HIPCHK(h, hipStreamWaitEvent(h->s0, h->ev_cols[t], 0));     // my columns carry all earlier updates
         factor_node(h, h->tops[t], true);
-        apply_node(h, nd, h->dA, h->lda, nd.c1, h->n, true, h->a_scale, true);
+        HIPCHK(h, hipEventRecord(h->ev_node[t], h->s0));
+        HIPCHK(h, hipStreamWaitEvent(h->s1, h->ev_node[t], 0));
+        if (t + 1 < h->tops.size()) {
+            const Node nx = h->nodes[h->tops[t + 1]];
+            apply_node(h, nd, h->dA, h->lda, nx.c0, nx.c1, true, h->a_scale, true, 1);    // next block first ...
+            HIPCHK(h, hipEventRecord(h->ev_cols[t + 1], h->s1));
+            apply_node(h, nd, h->dA, h->lda, nx.c1, h->n, true, h->a_scale, true, 1);      // ... the rest overlaps its panels
+        }
+    }
+    if (la) {   // join: everything after this point (Q formation, read-backs) is ordered after both streams
+        HIPCHK(h, hipEventRecord(h->ev[3], h->s1));
+        HIPCHK(h, hipStreamWaitEvent(h->s0, h->ev[3], 0));
     }
     HIPCHK(h, hipEventRecord(h->ev[1], h->s0));
     int f = 0;
@@ -642,6 +709,7 @@ int mpqr_sync(mpqr_handle_t h) {
     if (!h) return MPQR_ERR_INVALID;
     HIPCHK(h, hipSetDevice(h->device));
     HIPCHK(h, hipStreamSynchronize(h->s0));
+    if (h->s1) HIPCHK(h, hipStreamSynchronize(h->s1));
     return MPQR_OK;
 }
 

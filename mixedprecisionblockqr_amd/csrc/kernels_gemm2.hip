@@ -21,10 +21,6 @@ typedef half_t half8 __attribute__((ext_vector_type(8)));
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 
 namespace g2 {
-constexpr int BM = 256, BN = 256, BK = 64;
-constexpr int TILE_BYTES = BM * BK * 2;          // 32 KiB per operand per stage
-constexpr int LDS_BYTES = 4 * TILE_BYTES;        // A0 B0 A1 B1
-
 struct alignas(16) U4 { uint32_t x, y, z, w; };
 
 __device__ __forceinline__ uint32_t pack2(float a, float b) {
@@ -32,20 +28,29 @@ __device__ __forceinline__ uint32_t pack2(float a, float b) {
     half2v h = {(half_t)a, (half_t)b};
     return __builtin_bit_cast(uint32_t, h);
 }
-// byte offset of logical 16-B chunk c (0..7) of row r inside a swizzled [256][64-half] tile
-__device__ __forceinline__ int swz(int r, int c) { return r * 128 + ((c ^ ((r >> 1) & 7)) << 4); }
 }  // namespace g2
 
 extern __shared__ __attribute__((aligned(16))) char g2_smem[];
 
-template <int AM, int EM>
-__global__ __launch_bounds__(512) void gemm2_f16_kernel(GemmArgs g, int tilesM, int tilesN) {
+// WM x WN waves, each wave owns 128 x 64 of the (128 WM) x (64 WN) tile; BK = 32 or 64.
+//   <2,4,64>: 256 x 256 x 64, 512 threads, 128 KiB LDS, one workgroup per CU
+//   <2,2,32>: 256 x 128 x 32, 256 threads,  48 KiB LDS, two workgroups per CU (one's read-modify-write epilogue
+//             overlaps the other's MFMA loop)
+template <int AM, int EM, int WM, int WN, int BK>
+__global__ __launch_bounds__(64 * WM * WN) void gemm2_f16_kernel(GemmArgs g, int tilesM, int tilesN) {
     using namespace g2;
+    constexpr int BM = 128 * WM, BN = 64 * WN, NT = 64 * WM * WN;
+    constexpr int ROWB = BK * 2;                       // bytes per LDS row
+    constexpr int CPR = BK / 8;                        // 16-B chunks per row
+    constexpr int RB = 256 / ROWB;                     // rows per 256-B bank row
+    constexpr int A_BYTES = BM * ROWB, B_BYTES = BN * ROWB, STAGE = A_BYTES + B_BYTES;
+    // byte offset of logical chunk c of row r: XOR swizzle makes 16 consecutive rows hit 16 distinct 16-B bank slots
+    auto swz = [](int r, int c) -> int { return r * ROWB + ((c ^ ((r / RB) & (CPR - 1))) << 4); };
+
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
 
-    // ---- XCD-aware tile order (blocks b and b+8 share an XCD): give each XCD a contiguous run of the
-    // swizzled sequence, then walk 4 x 8 tile groups
+    // ---- XCD-aware tile order (blocks b and b+8 share an XCD): contiguous run of the sequence per XCD, 4 x 8 groups
     const int nwg = gridDim.x, bid = blockIdx.x;
     const int q = nwg / 8, rem = nwg % 8, xcd = bid % 8;
     const int seq = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + bid / 8;
@@ -58,25 +63,27 @@ __global__ __launch_bounds__(512) void gemm2_f16_kernel(GemmArgs g, int tilesM, 
 
     const int ktiles = g.K / BK;
     char* const As0 = g2_smem;
-    char* const Bs0 = g2_smem + TILE_BYTES;
+    char* const Bs0 = g2_smem + A_BYTES;
 
     // ---- A staging through registers
-    U4 ra[4];         // A_H16 / A_F32 (converted): 4 chunks of 16 B per thread
-    float4 raT[8];    // A_F32T: two 4(k) x 4(m) fp32 blocks per thread
+    constexpr int NA = BM * CPR / NT;                  // 16-B chunks per thread (A_H16 / A_F32)
+    constexpr int NBLK = (BK / 4) * (BM / 4) / NT;     // 4 x 4 fp32 blocks per thread (A_F32T)
+    U4 ra[NA];
+    float4 raT[NBLK * 4];
     auto load_A = [&](int kt) {
         const int k = kt * BK;
         if (AM == A_H16) {
             const half_t* A = (const half_t*)g.A;
 #pragma unroll
-            for (int i = 0; i < 4; i++) {
-                const int c = tid + 512 * i, row = c >> 3, kc = c & 7;
+            for (int i = 0; i < NA; i++) {
+                const int c = tid + NT * i, row = c / CPR, kc = c % CPR;
                 ra[i] = *(const U4*)(A + (long)(bm + row) * g.lda + k + kc * 8);
             }
         } else if (AM == A_F32T) {
             const float* A = (const float*)g.A;
 #pragma unroll
-            for (int i = 0; i < 2; i++) {
-                const int id = tid + 512 * i, mg = id & 63, kg = id >> 6;       // 64 m-groups x 16 k-groups
+            for (int i = 0; i < NBLK; i++) {
+                const int id = tid + NT * i, mg = id % (BM / 4), kg = id / (BM / 4);
 #pragma unroll
                 for (int j = 0; j < 4; j++) raT[i * 4 + j] = *(const float4*)(A + (long)(k + kg * 4 + j) * g.lda + bm + mg * 4);
             }
@@ -84,8 +91,8 @@ __global__ __launch_bounds__(512) void gemm2_f16_kernel(GemmArgs g, int tilesM, 
             const float* A = (const float*)g.A;
             const float sc = g.in_scale;
 #pragma unroll
-            for (int i = 0; i < 4; i++) {
-                const int c = tid + 512 * i, row = c >> 3, kc = c & 7;
+            for (int i = 0; i < NA; i++) {
+                const int c = tid + NT * i, row = c / CPR, kc = c % CPR;
                 const float* p = A + (long)(bm + row) * g.lda + k + kc * 8;
                 float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0;
                 for (int sl = 0; sl < g.nslab_in; sl++) {
@@ -102,12 +109,12 @@ __global__ __launch_bounds__(512) void gemm2_f16_kernel(GemmArgs g, int tilesM, 
         }
     };
     auto store_A = [&](int stage) {
-        char* As = As0 + stage * 2 * TILE_BYTES;
+        char* As = As0 + stage * STAGE;
         if (AM == A_F32T) {
             const float sc = g.in_scale;
 #pragma unroll
-            for (int i = 0; i < 2; i++) {
-                const int id = tid + 512 * i, mg = id & 63, kg = id >> 6;
+            for (int i = 0; i < NBLK; i++) {
+                const int id = tid + NT * i, mg = id % (BM / 4), kg = id / (BM / 4);
                 const float4 v0 = raT[i * 4 + 0], v1 = raT[i * 4 + 1], v2 = raT[i * 4 + 2], v3 = raT[i * 4 + 3];
                 const int half_off = (kg & 1) * 8, chunk = kg >> 1;
                 uint2 w;
@@ -118,25 +125,27 @@ __global__ __launch_bounds__(512) void gemm2_f16_kernel(GemmArgs g, int tilesM, 
             }
         } else {
 #pragma unroll
-            for (int i = 0; i < 4; i++) {
-                const int c = tid + 512 * i, row = c >> 3, kc = c & 7;
+            for (int i = 0; i < NA; i++) {
+                const int c = tid + NT * i, row = c / CPR, kc = c % CPR;
                 *(U4*)(As + swz(row, kc)) = ra[i];
             }
         }
     };
-    // ---- B staging: HBM -> LDS directly.  Wave-instruction (i, wave) fills rows 8*(8i+wave) .. +7 (1 KiB, lane-linear);
-    // lane l lands on row rr = base + (l >> 3), physical chunk l & 7, so it must FETCH logical chunk (l&7) ^ ((rr>>1)&7).
+    // ---- B staging: HBM -> LDS directly.  One wave-instruction fills 1 KiB = RPI rows, lane-linear; lane l lands on
+    // row rr = rb + l / CPR, physical chunk l % CPR, so it must FETCH the logical chunk that the swizzle maps there.
+    constexpr int RPI = 1024 / ROWB;                   // rows per wave-instruction
+    constexpr int NB = BN / RPI / (NT / 64);           // wave-instructions per wave
     auto stage_B = [&](int stage, int kt) {
-        char* Bs = Bs0 + stage * 2 * TILE_BYTES;
+        char* Bs = Bs0 + stage * STAGE;
         const int k = kt * BK;
 #pragma unroll
-        for (int i = 0; i < 4; i++) {
-            const int rb = (i * 8 + wave) * 8;
-            const int rr = rb + (lane >> 3);
-            const int c = (lane & 7) ^ ((rr >> 1) & 7);
+        for (int i = 0; i < NB; i++) {
+            const int rb = (i * (NT / 64) + wave) * RPI;
+            const int rr = rb + lane / CPR;
+            const int c = (lane % CPR) ^ ((rr / RB) & (CPR - 1));
             const half_t* src = g.Bt + (long)(bn + rr) * g.ldb + k + c * 8;
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                             (__attribute__((address_space(3))) void*)(Bs + rb * 128), 16, 0, 0);
+                                             (__attribute__((address_space(3))) void*)(Bs + rb * ROWB), 16, 0, 0);
         }
     };
 
@@ -148,7 +157,7 @@ __global__ __launch_bounds__(512) void gemm2_f16_kernel(GemmArgs g, int tilesM, 
 #pragma unroll
             for (int e = 0; e < 16; e++) acc[i][j][e] = 0.f;
 
-    const int wm = (wave >> 2) * 128, wn = (wave & 3) * 64;
+    const int wm = (wave / WN) * 128, wn = (wave % WN) * 64;
 
     stage_B(0, 0);
     load_A(0);
@@ -159,8 +168,8 @@ __global__ __launch_bounds__(512) void gemm2_f16_kernel(GemmArgs g, int tilesM, 
         const int cur = kt & 1;
         const bool more = kt + 1 < ktiles;
         if (more) { stage_B(cur ^ 1, kt + 1); load_A(kt + 1); }
-        const char* As = As0 + cur * 2 * TILE_BYTES;
-        const char* Bs = Bs0 + cur * 2 * TILE_BYTES;
+        const char* As = As0 + cur * STAGE;
+        const char* Bs = Bs0 + cur * STAGE;
 #pragma unroll
         for (int ks = 0; ks < BK / 16; ks++) {
             half8 a[4], b[2];
@@ -205,28 +214,36 @@ __global__ __launch_bounds__(512) void gemm2_f16_kernel(GemmArgs g, int tilesM, 
         }
 }
 
-template <int AM, int EM>
+template <int AM, int EM, int WM, int WN, int BK>
 static void launch2(const GemmArgs& g, hipStream_t s) {
+    constexpr int BM = 128 * WM, BN = 64 * WN, NT = 64 * WM * WN;
+    constexpr int LDS = 2 * (BM + BN) * BK * 2;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)gemm2_f16_kernel<AM, EM>, hipFuncAttributeMaxDynamicSharedMemorySize, g2::LDS_BYTES);
+        (void)hipFuncSetAttribute((const void*)gemm2_f16_kernel<AM, EM, WM, WN, BK>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         attr_set = true;
     }
-    const int tilesM = (g.M + g2::BM - 1) / g2::BM, tilesN = (g.N + g2::BN - 1) / g2::BN;
+    const int tilesM = (g.M + BM - 1) / BM, tilesN = (g.N + BN - 1) / BN;
     const int groups = ((tilesM + 3) / 4) * ((tilesN + 7) / 8);
     GemmArgs a = g;
     if (a.nslab_in < 1) a.nslab_in = 1;
-    hipLaunchKernelGGL((gemm2_f16_kernel<AM, EM>), dim3(groups * 32), dim3(512), g2::LDS_BYTES, s, a, tilesM, tilesN);
+    hipLaunchKernelGGL((gemm2_f16_kernel<AM, EM, WM, WN, BK>), dim3(groups * 32), dim3(NT), LDS, s, a, tilesM, tilesN);
 }
 
 // Large-shape path.  Preconditions (checked by the caller, driver.hip): no split-K, K % 64 == 0, and the
 // operand buffers are readable up to the next multiple of 256 rows (tiles are loaded unmasked; rows past M / N
-// only feed outputs that the epilogue masks).
-bool launch_gemm2_f16(AMode am, EMode em, const GemmArgs& g, hipStream_t s) {
-#define MPQR_CASE2(A_, E_) if (am == A_ && em == E_) { launch2<A_, E_>(g, s); return true; }
+// only feed outputs that the epilogue masks).  config: 0 = 256x256x64 / 512 threads, 1 = 256x128x32 / 256 threads.
+bool launch_gemm2_f16(AMode am, EMode em, const GemmArgs& g, hipStream_t s, int config) {
+#define MPQR_CASE2(A_, E_)                                                  \
+    if (am == A_ && em == E_) {                                             \
+        if (config == 1) launch2<A_, E_, 2, 2, 32>(g, s);                   \
+        else launch2<A_, E_, 2, 4, 64>(g, s);                               \
+        return true;                                                        \
+    }
     MPQR_CASE2(A_F32T, E_STORE_F32)
     MPQR_CASE2(A_F32, E_STORE_H16)
     MPQR_CASE2(A_H16, E_SUB_F32)
+    MPQR_CASE2(A_F32, E_STORE_F32)
 #undef MPQR_CASE2
     return false;
 }

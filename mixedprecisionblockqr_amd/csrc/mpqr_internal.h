@@ -37,7 +37,7 @@ struct GemmArgs {
 };
 void launch_gemm_f16(AMode am, EMode em, const GemmArgs& g, hipStream_t s);
 // 256 x 256 x 64 variant for large shapes (no split-K; operands readable up to the next multiple of 256 rows)
-bool launch_gemm2_f16(AMode am, EMode em, const GemmArgs& g, hipStream_t s);
+bool launch_gemm2_f16(AMode am, EMode em, const GemmArgs& g, hipStream_t s, int config = 0);
 
 // ------------------------------------------------------------------ fp32 helper GEMM (T merges, metrics)
 // C[M x N] (ldc) = alpha * opA(A) * opB(B) + beta*C, plain fp32 FMA, any sizes.

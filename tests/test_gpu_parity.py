@@ -206,7 +206,7 @@ def test_config2_2048_properties(mp, h):
     h.factor(); h.sync()
     assert np.array_equal(R1, h.r_matrix())                        # deterministic (no atomics on the path)
     t = h.timings()
-    assert t["ms_total"] > 0 and t["n_far_launches"] == 1
+    assert t["ms_total"] > 0 and t["n_far_launches"] >= 1
 
 
 def test_cpp_main_path_fp64(mp, h, po, golden):
