@@ -1,0 +1,46 @@
+// gemm_epilogue.h -- shared device epilogue of the MFMA GEMM kernels
+#pragma once
+#include <hip/hip_runtime.h>
+namespace mpqr {
+// Read-modify-write epilogue  C[m][n] -= alpha * acc  for NI x NJ 32x32 MFMA sub-tiles per wave (M % 32 == 0, so a
+// sub-tile is valid or invalid as a whole).  The 16 old values of a sub-tile are loaded back to back (column index
+// clamped instead of branched on: one wait per sub-tile instead of one per element), the loads of the next sub-tile
+// are issued before the current one is stored, and only the stores are predicated (col_lo <= column < N).
+template <int NI, int NJ, typename ACC>
+__device__ __forceinline__ void epilogue_sub_f32(const ACC (&acc)[NI][NJ], float* __restrict__ C, long ldc, int M, int N,
+                                                 int col_lo, float alpha, int row_base, int col_base, int r, int h) {
+    float oldv[2][16];
+    auto tile_ptr = [&](int t) -> float* {
+        const int i = t / NJ, j = t % NJ;
+        const int n = min(col_base + j * 32 + r, N - 1);
+        const int m0 = min(row_base + i * 32, M - 32) + 4 * h;
+        return C + (long)m0 * ldc + n;
+    };
+    auto load_tile = [&](int t, float (&dst)[16]) {
+        const float* p = tile_ptr(t);
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+#pragma unroll
+            for (int e = 0; e < 4; e++) dst[q * 4 + e] = p[(long)e * ldc];
+            p += 8 * ldc;
+        }
+    };
+    load_tile(0, oldv[0]);
+#pragma unroll
+    for (int t = 0; t < NI * NJ; t++) {
+        if (t + 1 < NI * NJ) load_tile(t + 1, oldv[(t + 1) & 1]);
+        const int i = t / NJ, j = t % NJ;
+        const int n = col_base + j * 32 + r;
+        const bool ok = (n < N) && (n >= col_lo) && (row_base + i * 32 < M);
+        float* p = tile_ptr(t);
+        if (ok) {
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+#pragma unroll
+                for (int e = 0; e < 4; e++) p[(long)e * ldc] = oldv[t & 1][q * 4 + e] - alpha * acc[i][j][q * 4 + e];
+                p += 8 * ldc;
+            }
+        }
+    }
+}
+}  // namespace mpqr

@@ -11,6 +11,7 @@
 // (k contiguous), so both LDS images are [row][k] and every MFMA fragment is one ds_read_b128.
 // Tile 128 x 128 x 64, 256 threads = 4 waves as 2 x 2, each wave 64 x 64 = 2 x 2 MFMA tiles.
 #include "mpqr_internal.h"
+#include "gemm_epilogue.h"
 
 namespace mpqr {
 
@@ -177,6 +178,10 @@ __global__ __launch_bounds__(256) void gemm_f16_kernel(GemmArgs g) {
 
     // ---- epilogue.  D layout of 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
     const float alpha = g.alpha;
+    if (EM == E_SUB_F32) {
+        epilogue_sub_f32<2, 2>(acc, (float*)g.C, g.ldc, g.M, g.N, g.col_lo, alpha, bm + wm, bn + wn, r, h);
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < 2; i++)
 #pragma unroll
@@ -187,16 +192,8 @@ __global__ __launch_bounds__(256) void gemm_f16_kernel(GemmArgs g) {
                 const int m = bm + wm + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
                 if (m < g.M && n < g.N) {
                     const float v = alpha * acc[i][j][e];
-                    if (EM == E_STORE_F32) {
-                        ((float*)g.C)[(long)z * g.slab_out_stride + (long)m * g.ldc + n] = v;
-                    } else if (EM == E_STORE_H16) {
-                        ((half_t*)g.C)[(long)m * g.ldc + n] = (half_t)v;
-                    } else {
-                        if (n >= g.col_lo) {
-                            float* p = (float*)g.C + (long)m * g.ldc + n;
-                            *p = *p - v;
-                        }
-                    }
+                    if (EM == E_STORE_F32) ((float*)g.C)[(long)z * g.slab_out_stride + (long)m * g.ldc + n] = v;
+                    else ((half_t*)g.C)[(long)m * g.ldc + n] = (half_t)v;
                 }
             }
         }

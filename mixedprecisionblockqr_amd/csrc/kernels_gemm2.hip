@@ -14,6 +14,7 @@
 //   * blockIdx -> tile map walks 4 x 8 tile groups inside each XCD's share of the grid, so the 32 workgroups
 //     sharing an L2 reuse 4 A panels and 8 B panels instead of streaming them.
 #include "mpqr_internal.h"
+#include "gemm_epilogue.h"
 
 namespace mpqr {
 
@@ -189,6 +190,10 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm2_f16_kernel(GemmArgs g, int
     }
 
     const float alpha = g.alpha;
+    if (EM == E_SUB_F32) {
+        epilogue_sub_f32<4, 2>(acc, (float*)g.C, g.ldc, g.M, g.N, g.col_lo, alpha, bm + wm, bn + wn, r, h);
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < 4; i++)
 #pragma unroll
@@ -199,16 +204,8 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm2_f16_kernel(GemmArgs g, int
                 const int m = bm + wm + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
                 if (m < g.M && n < g.N) {
                     const float v = alpha * acc[i][j][e];
-                    if (EM == E_STORE_F32) {
-                        ((float*)g.C)[(long)m * g.ldc + n] = v;
-                    } else if (EM == E_STORE_H16) {
-                        ((half_t*)g.C)[(long)m * g.ldc + n] = (half_t)v;
-                    } else {
-                        if (n >= g.col_lo) {
-                            float* p = (float*)g.C + (long)m * g.ldc + n;
-                            *p = *p - v;
-                        }
-                    }
+                    if (EM == E_STORE_F32) ((float*)g.C)[(long)m * g.ldc + n] = v;
+                    else ((half_t*)g.C)[(long)m * g.ldc + n] = (half_t)v;
                 }
             }
         }
@@ -230,10 +227,121 @@ static void launch2(const GemmArgs& g, hipStream_t s) {
     hipLaunchKernelGGL((gemm2_f16_kernel<AM, EM, WM, WN, BK>), dim3(groups * 32), dim3(NT), LDS, s, a, tilesM, tilesN);
 }
 
+// ------------------------------------------------------------------ all-DMA 4-stage ring (both operands fp16)
+// C[M x N] (-)= A[M][K] * Bt[N][K]^T with A and Bt both fp16 and k contiguous: the far trailing update
+// A2 -= V Y^T and the Q-formation twin, the dominant kernels of the factorisation.  256 x 256 x 32 tiles,
+// 512 threads = 8 waves (2 x 4), a ring of 4 LDS stages (4 x 32 KiB); A and Bt both go HBM -> LDS with
+// global_load_lds_dwordx4 (4 per wave and K-tile), three K-tiles in flight behind a COUNTED s_waitcnt vmcnt and
+// a raw s_barrier (one per K-tile; __syncthreads() would drain the DMA queue).  Source-side XOR swizzle as above.
+template <int EM>
+__global__ __launch_bounds__(512) void gemm3_f16_kernel(GemmArgs g, int tilesM, int tilesN) {
+    using namespace g2;
+    constexpr int BM = 256, BN = 256, BK = 32, NS = 4;
+    constexpr int ROWB = 64, CPR = 4, RB = 4;
+    constexpr int A_BYTES = BM * ROWB, STAGE = 2 * A_BYTES;
+    auto swz = [](int r, int c) -> int { return r * ROWB + ((c ^ ((r / RB) & (CPR - 1))) << 4); };
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int nwg = gridDim.x, bid = blockIdx.x;
+    const int q = nwg / 8, rem = nwg % 8, xcd = bid % 8;
+    const int seq = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + bid / 8;
+    const int groupsN = (tilesN + 7) / 8;
+    const int grp = seq / 32, within = seq % 32;
+    const int tm = (grp / groupsN) * 4 + within / 8;
+    const int tn = (grp % groupsN) * 8 + within % 8;
+    if (tm >= tilesM || tn >= tilesN) return;
+    const int bm = tm * BM, bn = tn * BN;
+    const int ktiles = g.K / BK;
+    const half_t* const A = (const half_t*)g.A;
+
+    // lane l of wave-instruction (i, wave) lands on row rb + l/4, physical chunk l%4 of a 16-row slab
+    auto issue = [&](int kt) {
+        char* base = g2_smem + (kt & (NS - 1)) * STAGE;
+        const int k = kt * BK;
+#pragma unroll
+        for (int i = 0; i < 2; i++) {
+            const int rb = (i * 8 + wave) * 16;
+            const int rr = rb + (lane >> 2);
+            const int c = (lane & 3) ^ ((rr >> 2) & 3);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(A + (long)(bm + rr) * g.lda + k + c * 8),
+                                             (__attribute__((address_space(3))) void*)(base + rb * ROWB), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g.Bt + (long)(bn + rr) * g.ldb + k + c * 8),
+                                             (__attribute__((address_space(3))) void*)(base + A_BYTES + rb * ROWB), 16, 0, 0);
+        }
+    };
+
+    floatx16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++)
+#pragma unroll
+            for (int e = 0; e < 16; e++) acc[i][j][e] = 0.f;
+    const int wm = (wave >> 2) * 128, wn = (wave & 3) * 64;
+
+    for (int s = 0; s < 3 && s < ktiles; s++) issue(s);
+    for (int kt = 0; kt < ktiles; kt++) {
+        const int ahead = min(2, ktiles - 1 - kt);          // tiles issued after kt that may stay in flight
+        if (ahead == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else if (ahead == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                        // tile kt landed everywhere; stage (kt-1)&3 is free
+        if (kt + 3 < ktiles) issue(kt + 3);
+        const char* As = g2_smem + (kt & (NS - 1)) * STAGE;
+        const char* Bs = As + A_BYTES;
+#pragma unroll
+        for (int ks = 0; ks < 2; ks++) {
+            half8 a[4], b[2];
+#pragma unroll
+            for (int i = 0; i < 4; i++) a[i] = *(const half8*)(As + swz(wm + i * 32 + r, ks * 2 + h));
+#pragma unroll
+            for (int j = 0; j < 2; j++) b[j] = *(const half8*)(Bs + swz(wn + j * 32 + r, ks * 2 + h));
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+#pragma unroll
+                for (int j = 0; j < 2; j++)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+    }
+    const float alpha = g.alpha;
+    if (EM == E_SUB_F32) {
+        epilogue_sub_f32<4, 2>(acc, (float*)g.C, g.ldc, g.M, g.N, g.col_lo, alpha, bm + wm, bn + wn, r, h);
+        return;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+            const int n = bn + wn + j * 32 + r;
+#pragma unroll
+            for (int e = 0; e < 16; e++) {
+                const int m = bm + wm + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+                if (m < g.M && n < g.N) ((float*)g.C)[(long)m * g.ldc + n] = alpha * acc[i][j][e];
+            }
+        }
+}
+
+template <int EM>
+static void launch3(const GemmArgs& g, hipStream_t s) {
+    constexpr int LDS = 4 * 2 * 256 * 64;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)gemm3_f16_kernel<EM>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        attr_set = true;
+    }
+    const int tilesM = (g.M + 255) / 256, tilesN = (g.N + 255) / 256;
+    const int groups = ((tilesM + 3) / 4) * ((tilesN + 7) / 8);
+    hipLaunchKernelGGL((gemm3_f16_kernel<EM>), dim3(groups * 32), dim3(512), LDS, s, g, tilesM, tilesN);
+}
+
 // Large-shape path.  Preconditions (checked by the caller, driver.hip): no split-K, K % 64 == 0, and the
 // operand buffers are readable up to the next multiple of 256 rows (tiles are loaded unmasked; rows past M / N
 // only feed outputs that the epilogue masks).  config: 0 = 256x256x64 / 512 threads, 1 = 256x128x32 / 256 threads.
 bool launch_gemm2_f16(AMode am, EMode em, const GemmArgs& g, hipStream_t s, int config) {
+    if (am == A_H16 && config != 2 && config != 1) {          // config 2 keeps the register-staged kernel (A/B comparison)
+        if (em == E_SUB_F32) { launch3<E_SUB_F32>(g, s); return true; }
+        if (em == E_STORE_F32) { launch3<E_STORE_F32>(g, s); return true; }
+    }
 #define MPQR_CASE2(A_, E_)                                                  \
     if (am == A_ && em == E_) {                                             \
         if (config == 1) launch2<A_, E_, 2, 2, 32>(g, s);                   \
