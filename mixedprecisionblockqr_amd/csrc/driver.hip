@@ -208,8 +208,8 @@ int choose_split(int M, int N, int K, size_t cap_elems, long slab) {
     const int tiles = ((M + 127) / 128) * ((N + 127) / 128);
     const int ktiles = K / 64;
     int ns = 1;
-    if (tiles < 128) ns = std::min(ktiles / 2, std::max(1, 256 / tiles));   // >= 2 k-tiles per slice
-    ns = std::min(ns, 16);   // every consumer re-reads all slabs: keep the fan-in small
+    if (tiles < 128) ns = std::min(ktiles / 2, std::max(1, 512 / tiles));   // >= 2 k-tiles per slice, ~2 workgroups per CU
+    ns = std::min(ns, 64);   // slabs are summed by launch_slab_reduce right after the producer
     while (ns > 1 && (size_t)ns * (size_t)slab > cap_elems) ns--;
     return std::max(ns, 1);
 }
@@ -235,8 +235,9 @@ int gram(mpqr_handle_t h, const Node& L, const Node& R, int* nslab, long* slab) 
     *slab = (long)L.ldt * R.ldt;
     g.nsplit = choose_split(g.M, g.N, g.K, h->s_elems, *slab);
     g.slab_out_stride = *slab;
-    *nslab = g.nsplit;
     launch_gemm_f16(A_H16, E_STORE_F32, g, h->s0);
+    if (g.nsplit > 1) launch_slab_reduce(h->S, g.nsplit, *slab, *slab, h->S, h->s0);
+    *nslab = 1;
     return MPQR_OK;
 }
 
@@ -289,10 +290,11 @@ void apply_node(mpqr_handle_t h, const Node& nd, float* C, long ldc, int clo, in
     g1.slab_out_stride = slab;
     if (record) (void)hipEventRecord(e0, st);
     gemm_dispatch(A_F32T, E_STORE_F32, g1, st);
+    if (g1.nsplit > 1) launch_slab_reduce(Xt, g1.nsplit, slab, slab, Xt, st);
     if (record) (void)hipEventRecord(e1, st);
     // op2: Yt[M1 x Kr] = fp16( Xt * T' )
     GemmArgs g2{};
-    g2.A = Xt; g2.lda = Kr; g2.nslab_in = g1.nsplit; g2.slab_in_stride = slab;
+    g2.A = Xt; g2.lda = Kr; g2.nslab_in = 1; g2.slab_in_stride = slab;
     g2.Bt = (trans_t ? h->Tth : h->Th) + nd.toff; g2.ldb = Kr;
     g2.C = Yt; g2.ldc = Kr;
     g2.M = M1; g2.N = Kr; g2.K = Kr;
@@ -546,9 +548,9 @@ static int plan_common(mpqr_handle_t h, int m, int n, int r, const mpqr_opts* op
     for (Node& nd : h->nodes) { nd.toff = toff; toff += (size_t)nd.ldt * nd.ldt; max_ldt = std::max(max_ldt, nd.ldt); }
     h->t_elems = toff;
     const size_t maxdim = (size_t)std::max(h->m_pad, h->n_pad);
-    h->xt_elems = std::max(maxdim * (size_t)max_ldt, (size_t)16 * max_ldt * max_ldt);
+    h->xt_elems = std::max(maxdim * (size_t)max_ldt, (size_t)64 * max_ldt * max_ldt);
     h->yt_elems = maxdim * (size_t)max_ldt;
-    h->s_elems = (size_t)16 * max_ldt * max_ldt;
+    h->s_elems = (size_t)64 * max_ldt * max_ldt;
     h->tmp_elems = (size_t)max_ldt * max_ldt;
     h->maxwg = h->m_pad / 256 + 2;
     // +1024 floats / +256 rows of slack: the 256-wide GEMM tiles load unmasked (results past M, N are masked at the store)
@@ -926,7 +928,7 @@ static int stage_tree_begin(mpqr_handle_t h, StageTree& st, int c0, int c1, int 
     h->r = saved_r;
     size_t toff = 0; int max_ldt = 64;
     for (Node& nd : h->nodes) { nd.toff = toff; toff += (size_t)nd.ldt * nd.ldt; max_ldt = std::max(max_ldt, nd.ldt); }
-    if ((size_t)max_ldt * max_ldt > h->tmp_elems || (size_t)16 * max_ldt * max_ldt > h->s_elems ||
+    if ((size_t)max_ldt * max_ldt > h->tmp_elems || (size_t)64 * max_ldt * max_ldt > h->s_elems ||
         (size_t)std::max(h->m_pad, h->n_pad) * max_ldt > h->yt_elems)
         return fail(h, MPQR_ERR_INVALID, "panel too wide for the planned workspace");
     int rc;

@@ -161,6 +161,23 @@ void launch_extract_vf(const float* A, long lda, const float* vdiag, float* Vf, 
     hipLaunchKernelGGL(extract_vf_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, A, lda, vdiag, Vf, ldvf, rows, c0, c1);
 }
 
+// dst[e] = sum_q src[q * stride + e] in slab order (deterministic split-K reduction; dst may alias slab 0)
+__global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restrict__ src, int nslab, long stride, long n4, float* dst) {
+    const long e = (long)blockIdx.x * 256 + threadIdx.x;
+    if (e >= n4) return;
+    float4 s = ((const float4*)src)[e];
+    for (int q = 1; q < nslab; q++) {
+        const float4 v = ((const float4*)(src + (long)q * stride))[e];
+        s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+    ((float4*)dst)[e] = s;
+}
+void launch_slab_reduce(const float* src, int nslab, long stride, long n_elems, float* dst, hipStream_t s) {
+    if (nslab <= 1 && src == dst) return;
+    const long n4 = n_elems / 4;                       // callers keep M*N a multiple of 4 (N is a multiple of 64)
+    hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, src, nslab, stride, n4, dst);
+}
+
 // h_strip_R_from_A, Cuda/qr.cu:85-100
 __global__ void strip_r_kernel(const float* A, long lda, float* R, int m, int n) {
     const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;

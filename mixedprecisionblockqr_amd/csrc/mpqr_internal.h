@@ -88,6 +88,7 @@ void launch_pack_factor(const float* A, long lda, const float* vdiag, float* out
 void launch_unpack_factor(const float* in, int m, int n, int c0, int c1, float* A, long lda, float* vdiag,
                           half_t* Vh, long ldvh, half_t* Vt, long ldvt, hipStream_t s);
 void launch_strip_r(const float* A, long lda, float* R, int m, int n, hipStream_t s);
+void launch_slab_reduce(const float* src, int nslab, long stride, long n_elems, float* dst, hipStream_t s);
 void launch_extract_vf(const float* A, long lda, const float* vdiag, float* Vf, long ldvf, int rows, int c0, int c1, hipStream_t s);
 void launch_identity_cyclic(float* Q, long ldq, int m, int qloc, int block, int world, int rank, hipStream_t s);
 void launch_pack_factor_cyclic(const float* A, long lda, const float* vdiag, float* out, int m, int nloc, int block,
