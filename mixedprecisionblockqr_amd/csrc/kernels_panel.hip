@@ -291,7 +291,7 @@ constexpr int GH_ROWS = 128;     // rows per workgroup in gh_gram
 __global__ __launch_bounds__(256) void gh_gram_kernel(LeafArgs a, double* __restrict__ Gp) {
     float* tile = (float*)gh_smem;                       // [GH_ROWS][GH_TS]
     const int tid = threadIdx.x;
-    const int row0 = a.c1 + (blockIdx.x >> 1) * GH_ROWS;
+    const int row0 = a.c0 + (blockIdx.x >> 1) * GH_ROWS;   // ALL leaf rows, top block included: G = Gram of the remaining rows at k = c0
     const int hb = blockIdx.x & 1;                        // which half of G's rows this workgroup produces
 #pragma unroll
     for (int i = 0; i < 16; i++) {
@@ -334,11 +334,16 @@ __global__ __launch_bounds__(256) void gh_reduce_kernel(const double* __restrict
     G[e] = s;
 }
 
+// 1/sqrt(x) in fp64 from an fp32 seed and two Newton steps (2^-23 -> 2^-46 -> 2^-92); x outside the fp32 range
+// takes the library path
+__device__ __forceinline__ double refine_rsqrt(double x, double y) {
+    y = y * fma(-0.5 * x, y * y, 1.5);
+    y = y * fma(-0.5 * x, y * y, 1.5);
+    return y;
+}
 __device__ __forceinline__ double fast_rsqrt(double x) {
     if (!(x > 1e-30 && x < 1e30)) return 1.0 / sqrt(x);
-    double y = (double)rsqrtf((float)x);
-    y = y * (1.5 - 0.5 * x * y * y); y = y * (1.5 - 0.5 * x * y * y); y = y * (1.5 - 0.5 * x * y * y);
-    return y;
+    return refine_rsqrt(x, (double)rsqrtf((float)x));
 }
 
 // 512 threads as a 16 x 32 grid; thread (ti,tj) keeps the 8 x 4 blocks {8ti..8ti+7} x {4tj..4tj+3} of
@@ -350,8 +355,8 @@ __device__ __forceinline__ double fast_rsqrt(double x) {
 // N'_ij = N_ij - R[k][i] R[k][j].
 constexpr int SR = 8, SC = 4;
 __global__ __launch_bounds__(512) void gh_solve_kernel(LeafArgs a, const double* __restrict__ G, float* __restrict__ Cv,
-                                                       int* __restrict__ flag) {
-    float* stage = (float*)gh_smem;                       // [GW][GH_TS] copy of B_top for the fold
+                                                       int* __restrict__ flag, int dbg) {
+    float* stage = (float*)gh_smem;                       // [GW][GH_TS]: collects C during the k loop
     __shared__ double rowN[GW], col0[GW];
     __shared__ float rowB[GW], colB[GW], colM[GW], vdl[GW];
     __shared__ float vw[GW], vvt[GW], vcv[GW], vcol[GW];
@@ -375,33 +380,15 @@ __global__ __launch_bounds__(512) void gh_solve_kernel(LeafArgs a, const double*
                 b = a.A[(long)(a.c0 + i) * a.lda + a.c0 + j];
             }
             N[x][y] = g; B[x][y] = b; M[x][y] = (i == j) ? 1.f : 0.f;
-            stage[i * GH_TS + j] = b;
+            if (i == j) col0[i] = g;                       // ||a_j||^2 over all leaf rows
         }
-    __syncthreads();
-    // fold the top rows into N:  N_ij += sum_t B[t][i] B[t][j];  col0_j = ||a_j||^2 over all leaf rows
-    for (int t = 0; t < w; t++) {
-        const float4 bi0 = *(const float4*)&stage[t * GH_TS + SR * ti], bi1 = *(const float4*)&stage[t * GH_TS + SR * ti + 4];
-        const float4 bj = *(const float4*)&stage[t * GH_TS + SC * tj];
-        const double vi[SR] = {bi0.x, bi0.y, bi0.z, bi0.w, bi1.x, bi1.y, bi1.z, bi1.w}, vj[SC] = {bj.x, bj.y, bj.z, bj.w};
-#pragma unroll
-        for (int x = 0; x < SR; x++)
-#pragma unroll
-            for (int y = 0; y < SC; y++) N[x][y] += vi[x] * vj[y];
-    }
-#pragma unroll
-    for (int x = 0; x < SR; x++)
-#pragma unroll
-        for (int y = 0; y < SC; y++)
-            if (SR * ti + x == SC * tj + y) col0[SR * ti + x] = N[x][y];
-    __syncthreads();
-    // the staged copy of B_top is dead: the same LDS now collects C (no global stores inside the k loop --
-    // a barrier would have to wait for them to drain every step)
+    // C is collected in LDS (no global stores inside the k loop -- a barrier would have to wait for them to drain)
     float* Cs = stage;
     for (int e = tid; e < GW * GH_TS; e += 512) Cs[e] = 0.f;
     __syncthreads();
     for (int kr = 0; kr < w; kr++) {
         // (1) owners publish row kr of N, B and column kr of B, M
-        if (ti == (kr >> 3)) {
+        if (ti == (kr >> 3) && dbg != 3) {
 #pragma unroll
             for (int x = 0; x < SR; x++)
                 if (x == (kr & 7)) {
@@ -419,15 +406,24 @@ __global__ __launch_bounds__(512) void gh_solve_kernel(LeafArgs a, const double*
         }
         __syncthreads();
         // (2) one thread per index derives the step's vectors (zeroed outside their index ranges)
-        if (tid < GW) {
+        if (tid < GW && dbg != 2) {
             const int i = tid;
             const double sk = rowN[kr], u0 = (double)rowB[kr];
             double alpha = 0, inv = 0;
             const bool skip = !(sk > 0);
             if (!skip) {
-                const double rs = fast_rsqrt(sk), nu = sk * rs;
-                alpha = (u0 >= 0) ? nu : -nu;
-                inv = fast_rsqrt(2.0 * (sk + fabs(u0) * nu));
+                if (sk > 1e-30 && sk < 1e30) {
+                    // both fp32 seeds first (short fp32 chain), then the two fp64 refinements
+                    const float skf = (float)sk, s1 = rsqrtf(skf), nuf = skf * s1;
+                    const float s2 = rsqrtf(2.0f * (skf + fabsf((float)u0) * nuf));
+                    const double nu = sk * refine_rsqrt(sk, (double)s1);
+                    alpha = (u0 >= 0) ? nu : -nu;
+                    inv = refine_rsqrt(2.0 * (sk + fabs(u0) * nu), (double)s2);
+                } else {
+                    const double nu = sqrt(sk);
+                    alpha = (u0 >= 0) ? nu : -nu;
+                    inv = 1.0 / sqrt(2.0 * (sk + fabs(u0) * nu));
+                }
             }
             const double vtk = (u0 + alpha) * inv;                    // v_top[kr]
             const double wd = (i > kr && i < w) ? 2.0 * (rowN[i] + alpha * (double)rowB[i]) * inv : 0.0;
@@ -447,7 +443,7 @@ __global__ __launch_bounds__(512) void gh_solve_kernel(LeafArgs a, const double*
         }
         __syncthreads();
         // (3) every thread: three FMAs per entry (a skipped column has all-zero vectors: no-op)
-        {
+        if (dbg != 1) {
             float wj[SC]; double rkj[SC];
 #pragma unroll
             for (int y = 0; y < SC; y++) { wj[y] = vw[SC * tj + y]; rkj[y] = vrk[SC * tj + y]; }
@@ -579,10 +575,11 @@ void launch_leaf_gram_householder(const LeafArgs& a, double* Gp, double* G, floa
         (void)hipFuncSetAttribute((const void*)gh_apply_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (8256 + GW * GH_TS) * 4);
         attr = true;
     }
-    const int nwg = (a.mrows - a.c1 + GH_ROWS - 1) / GH_ROWS;
+    const int nwg = (a.mrows - a.c0 + GH_ROWS - 1) / GH_ROWS;
     hipLaunchKernelGGL(gh_gram_kernel, dim3(2 * nwg), dim3(256), GH_ROWS * GH_TS * 4, s, a, Gp);
     hipLaunchKernelGGL(gh_reduce_kernel, dim3(64), dim3(256), 0, s, Gp, nwg, G);
-    hipLaunchKernelGGL(gh_solve_kernel, dim3(1), dim3(512), GW * GH_TS * 4, s, a, G, Cv, flag);
+    static const int dbg = []() { const char* e = getenv("MPQR_DBG_SOLVE"); return e ? atoi(e) : 0; }();
+    hipLaunchKernelGGL(gh_solve_kernel, dim3(1), dim3(512), GW * GH_TS * 4, s, a, G, Cv, flag, dbg);
     const int nwa = (a.mrows - a.c1 + 63) / 64;
     hipLaunchKernelGGL(gh_apply_kernel, dim3(nwa), dim3(256), (8256 + GW * GH_TS) * 4, s, a, Cv);
 }
