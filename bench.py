@@ -76,7 +76,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     m, n, r = CONFIGS[args.config]
-    if world > 1:
+    if world > 1 or os.environ.get("MPQR_FORCE_DIST") == "1":     # the env switch lets a 1-GPU box exercise the RCCL leg
         from mixedprecisionblockqr_amd import dist as mpdist
         return mpdist.bench_main(args, m, n, r, world, rank, local_rank)
 

@@ -288,8 +288,9 @@ constexpr int GW = 128;          // window width
 constexpr int GH_TS = 132;       // LDS row stride (floats) of a staged 128-column tile
 constexpr int GH_ROWS = 128;     // rows per workgroup in gh_gram
 
+constexpr int GH_TD = 130;       // LDS row stride (doubles) of the staged tile
 __global__ __launch_bounds__(256) void gh_gram_kernel(LeafArgs a, double* __restrict__ Gp) {
-    float* tile = (float*)gh_smem;                       // [GH_ROWS][GH_TS]
+    double* tile = (double*)gh_smem;                      // [GH_ROWS][GH_TD] doubles: converted once while staging
     const int tid = threadIdx.x;
     const int row0 = a.c0 + (blockIdx.x >> 1) * GH_ROWS;   // ALL leaf rows, top block included: G = Gram of the remaining rows at k = c0
     const int hb = blockIdx.x & 1;                        // which half of G's rows this workgroup produces
@@ -298,7 +299,9 @@ __global__ __launch_bounds__(256) void gh_gram_kernel(LeafArgs a, double* __rest
         const int id = tid + 256 * i, lr = id >> 5, c4 = id & 31, row = row0 + lr;
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         if (row < a.mrows) v = *(const float4*)(a.A + (long)row * a.lda + a.cb + 4 * c4);
-        *(float4*)&tile[lr * GH_TS + 4 * c4] = v;
+        double* d = &tile[lr * GH_TD + 4 * c4];
+        *(double2*)d = make_double2((double)v.x, (double)v.y);
+        *(double2*)(d + 2) = make_double2((double)v.z, (double)v.w);
     }
     __syncthreads();
     // thread -> 4 x 8 block: rows 64*hb + 4*(tid>>4) .. +3, columns 8*(tid&15) .. +7 of the 128 x 128 Gram
@@ -311,14 +314,16 @@ __global__ __launch_bounds__(256) void gh_gram_kernel(LeafArgs a, double* __rest
         for (int y = 0; y < 8; y++) acc[x][y] = 0.0;
 #pragma unroll 2
     for (int r = 0; r < GH_ROWS; r++) {
-        const float4 a0 = *(const float4*)&tile[r * GH_TS + i0];
-        const float4 b0 = *(const float4*)&tile[r * GH_TS + 8 * bj], b1 = *(const float4*)&tile[r * GH_TS + 8 * bj + 4];
-        const double av[4] = {a0.x, a0.y, a0.z, a0.w};
-        const double bv[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+        const double* tr = &tile[r * GH_TD];
+        const double2 a0 = *(const double2*)(tr + i0), a1 = *(const double2*)(tr + i0 + 2);
+        const double2 b0 = *(const double2*)(tr + 8 * bj), b1 = *(const double2*)(tr + 8 * bj + 2);
+        const double2 b2 = *(const double2*)(tr + 8 * bj + 4), b3 = *(const double2*)(tr + 8 * bj + 6);
+        const double av[4] = {a0.x, a0.y, a1.x, a1.y};
+        const double bv[8] = {b0.x, b0.y, b1.x, b1.y, b2.x, b2.y, b3.x, b3.y};
 #pragma unroll
         for (int x = 0; x < 4; x++)
 #pragma unroll
-            for (int y = 0; y < 8; y++) acc[x][y] += av[x] * bv[y];
+            for (int y = 0; y < 8; y++) acc[x][y] = fma(av[x], bv[y], acc[x][y]);
     }
     double* out = Gp + (long)(blockIdx.x >> 1) * (GW * GW);
 #pragma unroll
@@ -327,11 +332,17 @@ __global__ __launch_bounds__(256) void gh_gram_kernel(LeafArgs a, double* __rest
         for (int y = 0; y < 8; y++) out[(i0 + x) * GW + 8 * bj + y] = acc[x][y];
 }
 
+// G = sum of the partials in slab order.  256 workgroups: workgroup b owns 64 consecutive entries, its 4 waves
+// take interleaved quarters of the partials, combined through LDS in a fixed order (deterministic).
 __global__ __launch_bounds__(256) void gh_reduce_kernel(const double* __restrict__ Gp, int nwg, double* __restrict__ G) {
-    const int e = blockIdx.x * 256 + threadIdx.x;        // 64 blocks x 256 = 16384 entries
+    __shared__ double part[4][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int e = blockIdx.x * 64 + lane;
     double s = 0;
-    for (int q = 0; q < nwg; q++) s += Gp[(long)q * (GW * GW) + e];
-    G[e] = s;
+    for (int q = wave; q < nwg; q += 4) s += Gp[(long)q * (GW * GW) + e];
+    part[wave][lane] = s;
+    __syncthreads();
+    if (wave == 0) G[e] = (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
 }
 
 // 1/sqrt(x) in fp64 from an fp32 seed and two Newton steps (2^-23 -> 2^-46 -> 2^-92); x outside the fp32 range
@@ -507,7 +518,12 @@ __global__ __launch_bounds__(256) void gh_apply_kernel(LeafArgs a, const float* 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int row0 = a.c1 + blockIdx.x * 64;
     const int off = a.c0 - a.cb, w = a.c1 - a.c0;
-    for (int e = tid; e < GW * GH_TS; e += 256) Cs[e] = 0.f;
+    // C at window coordinates, zero outside the leaf and below the diagonal: one pass, no separate clear
+    for (int e = tid; e < GW * GW; e += 256) {
+        const int wi = e >> 7, wk = e & 127;               // window coordinates
+        const int i = wi - off, k = wk - off;
+        Cs[wi * GH_TS + wk] = (i >= 0 && k >= 0 && i < w && k < w && i <= k) ? Cv[i * GW + k] : 0.f;
+    }
 #pragma unroll
     for (int i = 0; i < 8; i++) {
         const int id = tid + 256 * i, lr = id >> 5, c4 = id & 31, row = row0 + lr;
@@ -515,11 +531,6 @@ __global__ __launch_bounds__(256) void gh_apply_kernel(LeafArgs a, const float* 
         if (row < a.mrows) v = *(const float4*)(a.A + (long)row * a.lda + a.cb + 4 * c4);
         float* d = &As[lr * 129 + 4 * c4];
         d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
-    }
-    __syncthreads();
-    for (int e = tid; e < GW * GW; e += 256) {
-        const int i = e >> 7, k = e & 127;
-        if (i < w && k < w && i <= k) Cs[(off + i) * GH_TS + off + k] = Cv[e];
     }
     __syncthreads();
     floatx16p acc0, acc1;
@@ -570,14 +581,14 @@ __global__ __launch_bounds__(256) void gh_apply_kernel(LeafArgs a, const float* 
 void launch_leaf_gram_householder(const LeafArgs& a, double* Gp, double* G, float* Cv, int* flag, hipStream_t s) {
     static bool attr = false;
     if (!attr) {
-        (void)hipFuncSetAttribute((const void*)gh_gram_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, GH_ROWS * GH_TS * 4);
+        (void)hipFuncSetAttribute((const void*)gh_gram_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, GH_ROWS * GH_TD * 8);
         (void)hipFuncSetAttribute((const void*)gh_solve_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, GW * GH_TS * 4);
         (void)hipFuncSetAttribute((const void*)gh_apply_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (8256 + GW * GH_TS) * 4);
         attr = true;
     }
     const int nwg = (a.mrows - a.c0 + GH_ROWS - 1) / GH_ROWS;
-    hipLaunchKernelGGL(gh_gram_kernel, dim3(2 * nwg), dim3(256), GH_ROWS * GH_TS * 4, s, a, Gp);
-    hipLaunchKernelGGL(gh_reduce_kernel, dim3(64), dim3(256), 0, s, Gp, nwg, G);
+    hipLaunchKernelGGL(gh_gram_kernel, dim3(2 * nwg), dim3(256), GH_ROWS * GH_TD * 8, s, a, Gp);
+    hipLaunchKernelGGL(gh_reduce_kernel, dim3(256), dim3(256), 0, s, Gp, nwg, G);
     static const int dbg = []() { const char* e = getenv("MPQR_DBG_SOLVE"); return e ? atoi(e) : 0; }();
     hipLaunchKernelGGL(gh_solve_kernel, dim3(1), dim3(512), GW * GH_TS * 4, s, a, G, Cv, flag, dbg);
     const int nwa = (a.mrows - a.c1 + 63) / 64;
