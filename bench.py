@@ -101,12 +101,13 @@ def main():
     fl = mp.flops(m, n, r)
     tm = h.timings()                      # HIP-event timings of the LAST step, on the library's own stream
     mt = h.metrics()
-    # dominant kernel: the far trailing-update GEMM  A2 -= V Y^T  (fp16 MFMA, K = outer block)
+    # dominant kernel: the far trailing-update GEMM  A2 -= V Y^T  (fp16 MFMA, K = outer block); achieved =
+    # algorithmic flops (2 M N K summed over its launches) / their HIP-event time on the library's update stream
     nn_t = tm["ms_far_nn"] * 1e-3
     roof = None
     if tm["n_far_launches"] > 0 and nn_t > 0:
         ach = tm["flops_far_nn"] / nn_t / 1e12
-        roof = {"bound": "mfma", "kernel": "gemm_f16_kernel<A_H16,E_SUB_F32> (far A2 -= V*Y^T)",
+        roof = {"bound": "mfma", "kernel": "gemm3_f16_kernel<E_SUB_F32> (far A2 -= V*Y^T, fp16 x fp16 -> fp32, K = outer block)",
                 "achieved": ach, "peak": PEAK_FP16_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_FP16_TFLOPS,
                 "traffic": _pmc_traffic(), "launches": tm["n_far_launches"],
                 "avg_launch_ms": tm["ms_far_nn"] / tm["n_far_launches"],
