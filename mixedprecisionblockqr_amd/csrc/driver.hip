@@ -73,7 +73,7 @@ struct mpqr_handle_s {
     double* Gp = nullptr; double* Gs = nullptr; float* Cv = nullptr; int* dflag = nullptr;   // Gram-Householder leaf workspace
     bool robust = false;          // true: tall leaves are factored column by column instead of by Gram-Householder
     bool force32 = false;         // tree building: only 32-column leaves (sub-tree of a robustly factored tall leaf)
-    int gh_min_rows = 1024;       // leaves with more rows than this use Gram-Householder
+    int gh_min_rows = 128;        // leaves with more rows than this below their first column use Gram-Householder
     float* tmp1 = nullptr; float* tmp2 = nullptr; size_t tmp_elems = 0;
     float* Tf = nullptr; half_t* Th = nullptr; half_t* Tth = nullptr; size_t t_elems = 0;
     double* dmetric = nullptr;   // 8 doubles
@@ -533,6 +533,7 @@ static int plan_common(mpqr_handle_t h, int m, int n, int r, const mpqr_opts* op
     HIPCHK(h, hipStreamSynchronize(h->s0));
     free_plan(h);
     h->m = m; h->n = n; h->r = r; h->opts = o; h->world = world; h->rank = rank;
+    if (const char* e = getenv("MPQR_GH_MIN_ROWS")) h->gh_min_rows = atoi(e);      // tuning hook
     h->m_pad = rup(m, 256); h->n_pad = rup(n, 256);
     int Ko = o.outer_block > 0 ? o.outer_block : 1024;
     Ko = std::max(Ko, 32);
