@@ -255,9 +255,9 @@ __global__ __launch_bounds__(512) void gemm3_f16_kernel(GemmArgs g, int tilesM, 
     const half_t* const A = (const half_t*)g.A;
 
     // lane l of wave-instruction (i, wave) lands on row rb + l/4, physical chunk l%4 of a 16-row slab
-    auto issue = [&](int kt) {
+    auto issue = [&](int kt) {                              // kt past the end re-fetches the last tile into a free stage
         char* base = g2_smem + (kt & (NS - 1)) * STAGE;
-        const int k = kt * BK;
+        const int k = min(kt, ktiles - 1) * BK;
 #pragma unroll
         for (int i = 0; i < 2; i++) {
             const int rb = (i * 8 + wave) * 16;
@@ -279,32 +279,42 @@ __global__ __launch_bounds__(512) void gemm3_f16_kernel(GemmArgs g, int tilesM, 
             for (int e = 0; e < 16; e++) acc[i][j][e] = 0.f;
     const int wm = (wave >> 2) * 128, wn = (wave & 3) * 64;
 
-    for (int s = 0; s < 3 && s < ktiles; s++) issue(s);
+    for (int s = 0; s < 3; s++) issue(s);
     for (int kt = 0; kt < ktiles; kt++) {
-        const int ahead = min(2, ktiles - 1 - kt);          // tiles issued after kt that may stay in flight
-        if (ahead == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        else if (ahead == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");     // exactly three tiles are always in flight: kt has landed
         __builtin_amdgcn_s_barrier();                        // tile kt landed everywhere; stage (kt-1)&3 is free
-        if (kt + 3 < ktiles) issue(kt + 3);
         const char* As = g2_smem + (kt & (NS - 1)) * STAGE;
         const char* Bs = As + A_BYTES;
+        half8 a[2][4], b[2][2];
 #pragma unroll
         for (int ks = 0; ks < 2; ks++) {
-            half8 a[4], b[2];
 #pragma unroll
-            for (int i = 0; i < 4; i++) a[i] = *(const half8*)(As + swz(wm + i * 32 + r, ks * 2 + h));
+            for (int i = 0; i < 4; i++) a[ks][i] = *(const half8*)(As + swz(wm + i * 32 + r, ks * 2 + h));
 #pragma unroll
-            for (int j = 0; j < 2; j++) b[j] = *(const half8*)(Bs + swz(wn + j * 32 + r, ks * 2 + h));
+            for (int j = 0; j < 2; j++) b[ks][j] = *(const half8*)(Bs + swz(wn + j * 32 + r, ks * 2 + h));
+        }
+        issue(kt + 3);                                       // unconditional: keeps the loop body one basic block
+#pragma unroll
+        for (int ks = 0; ks < 2; ks++)
 #pragma unroll
             for (int i = 0; i < 4; i++)
 #pragma unroll
                 for (int j = 0; j < 2; j++)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i], b[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[ks][i], b[ks][j], acc[i][j], 0, 0, 0);
+        // issue order: the 12 fragment reads, then one LDS-DMA after every 4 MFMAs (its ~60-100 issue cycles hide in
+        // the matrix pipe's shadow instead of stalling both waves of the SIMD right after the barrier)
+        __builtin_amdgcn_sched_group_barrier(0x100, 12, 0);
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
         }
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // the three trailing (redundant) tiles
+    __builtin_amdgcn_s_barrier();
     const float alpha = g.alpha;
     if (EM == E_SUB_F32) {
+        // (an LDS-staged variant with 16-B accesses along full rows was measured: 527 vs 559 TFLOP/s -- not kept)
         epilogue_sub_f32<4, 2>(acc, (float*)g.C, g.ldc, g.M, g.N, g.col_lo, alpha, bm + wm, bn + wn, r, h);
         return;
     }
