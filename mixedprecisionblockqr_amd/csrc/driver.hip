@@ -198,7 +198,8 @@ void gemm_dispatch(AMode am, EMode em, const GemmArgs& g, hipStream_t s) {
         return e ? atol(e) : 48L;
     }();
     const long tiles = (long)(g.M / 256) * (g.N / 256);
-    if (g.nsplit <= 1 && (g.nslab_in <= 1) && g.M >= 256 && g.N >= 256 && tiles >= min_tiles && (g.K % 64) == 0 &&
+    if ((g.nsplit <= 1 || (em == E_STORE_F32 && am == A_F32T)) && (g.nslab_in <= 1) && g.M >= 256 && g.N >= 256 &&
+        tiles >= min_tiles && (g.K % 64) == 0 &&
         launch_gemm2_f16(am, em, g, s, gemm2_config()))
         return;
     launch_gemm_f16(am, em, g, s);
@@ -209,6 +210,11 @@ int choose_split(int M, int N, int K, size_t cap_elems, long slab) {
     const int ktiles = K / 64;
     int ns = 1;
     if (tiles < 128) ns = std::min(ktiles / 2, std::max(1, 512 / tiles));   // >= 2 k-tiles per slice, ~2 workgroups per CU
+    else {
+        // large-tile (256 x 256, one workgroup per CU) regime: keep every CU busy when the output has few tiles
+        const long t256 = (long)((M + 255) / 256) * ((N + 255) / 256);
+        if (t256 < 192) ns = (int)std::min<long>(ktiles / 16, (256 + t256 - 1) / t256);
+    }
     ns = std::min(ns, 64);   // slabs are summed by launch_slab_reduce right after the producer
     while (ns > 1 && (size_t)ns * (size_t)slab > cap_elems) ns--;
     return std::max(ns, 1);

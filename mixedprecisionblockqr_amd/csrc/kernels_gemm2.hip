@@ -62,7 +62,11 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm2_f16_kernel(GemmArgs g, int
     if (tm >= tilesM || tn >= tilesN) return;
     const int bm = tm * BM, bn = tn * BN;
 
-    const int ktiles = g.K / BK;
+    // split-K over blockIdx.y (E_STORE_F32 only): slice z covers K-tiles [kt0, kt1) and writes slab z
+    const int ktiles_all = g.K / BK;
+    const int z = blockIdx.y;
+    const int per = (ktiles_all + g.nsplit - 1) / g.nsplit;
+    const int kt0 = z * per, kt1 = min(ktiles_all, kt0 + per);
     char* const As0 = g2_smem;
     char* const Bs0 = g2_smem + A_BYTES;
 
@@ -160,14 +164,16 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm2_f16_kernel(GemmArgs g, int
 
     const int wm = (wave / WN) * 128, wn = (wave % WN) * 64;
 
-    stage_B(0, 0);
-    load_A(0);
-    store_A(0);
+    if (kt0 < kt1) {
+        stage_B(kt0 & 1, kt0);
+        load_A(kt0);
+        store_A(kt0 & 1);
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    for (int kt = 0; kt < ktiles; kt++) {
+    for (int kt = kt0; kt < kt1; kt++) {
         const int cur = kt & 1;
-        const bool more = kt + 1 < ktiles;
+        const bool more = kt + 1 < kt1;
         if (more) { stage_B(cur ^ 1, kt + 1); load_A(kt + 1); }
         const char* As = As0 + cur * STAGE;
         const char* Bs = Bs0 + cur * STAGE;
@@ -204,7 +210,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm2_f16_kernel(GemmArgs g, int
                 const int m = bm + wm + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
                 if (m < g.M && n < g.N) {
                     const float v = alpha * acc[i][j][e];
-                    if (EM == E_STORE_F32) ((float*)g.C)[(long)m * g.ldc + n] = v;
+                    if (EM == E_STORE_F32) ((float*)g.C)[(long)z * g.slab_out_stride + (long)m * g.ldc + n] = v;
                     else ((half_t*)g.C)[(long)m * g.ldc + n] = (half_t)v;
                 }
             }
@@ -224,7 +230,8 @@ static void launch2(const GemmArgs& g, hipStream_t s) {
     const int groups = ((tilesM + 3) / 4) * ((tilesN + 7) / 8);
     GemmArgs a = g;
     if (a.nslab_in < 1) a.nslab_in = 1;
-    hipLaunchKernelGGL((gemm2_f16_kernel<AM, EM, WM, WN, BK>), dim3(groups * 32), dim3(NT), LDS, s, a, tilesM, tilesN);
+    if (a.nsplit < 1 || EM != E_STORE_F32) a.nsplit = 1;
+    hipLaunchKernelGGL((gemm2_f16_kernel<AM, EM, WM, WN, BK>), dim3(groups * 32, a.nsplit), dim3(NT), LDS, s, a, tilesM, tilesN);
 }
 
 // ------------------------------------------------------------------ all-DMA 4-stage ring (both operands fp16)

@@ -32,15 +32,15 @@ void launch_generate(float* A, long lda, int m, int n, uint64_t seed, int nglob,
                        splitmix64(seed), block, world, rank);
 }
 
-__global__ void identity_kernel(float* Q, long ldq, int rows, int cols, int diag_off) {
-    const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= (long)rows * cols) return;
-    const int i = (int)(e / cols), j = (int)(e % cols);
-    Q[(long)i * ldq + j] = (i == j + diag_off) ? 1.f : 0.f;
+// the caller has zeroed Q (hipMemsetAsync); only the diagonal is written (a full-matrix elementwise launch would
+// need >= 2^32 threads at m = 65536, which HIP rejects)
+__global__ void identity_kernel(float* Q, long ldq, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) Q[(long)i * ldq + i] = 1.f;
 }
 void launch_set_identity(float* Q, long ldq, int rows, int cols, hipStream_t s) {
-    const long tot = (long)rows * cols;
-    hipLaunchKernelGGL(identity_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, Q, ldq, rows, cols, 0);
+    const int n = rows < cols ? rows : cols;
+    hipLaunchKernelGGL(identity_kernel, dim3((n + 255) / 256), dim3(256), 0, s, Q, ldq, n);
 }
 
 // ------------------------------------------------------------------ boundary layout (Cuda/qr.cu:283-285)
