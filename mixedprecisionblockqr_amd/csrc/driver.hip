@@ -71,6 +71,7 @@ struct mpqr_handle_s {
     float* S = nullptr;    size_t s_elems = 0;
     float* P = nullptr;    int maxwg = 0;
     double* Gp = nullptr; double* Gs = nullptr; float* Cv = nullptr; int* dflag = nullptr;   // Gram-Householder leaf workspace
+    float* Sp = nullptr;          // per-workgroup partial Grams of the fp16 reflectors (fused into gh_apply)
     bool robust = false;          // true: tall leaves are factored column by column instead of by Gram-Householder
     bool force32 = false;         // tree building: only 32-column leaves (sub-tree of a robustly factored tall leaf)
     int gh_min_rows = 128;        // leaves with more rows than this below their first column use Gram-Householder
@@ -131,13 +132,13 @@ int dalloc(mpqr_handle_t h, T** p, size_t elems) {
 
 void free_plan(mpqr_handle_t h) {
     void* ptrs[] = {h->dA, h->dA0, h->dQ, h->Vh, h->Vt, h->vdiag, h->Xt, h->Yt, h->S, h->P, h->tmp1, h->tmp2,
-                    h->Tf, h->Th, h->Tth, h->dstage, h->Gp, h->Gs, h->Cv, h->dflag, h->Vf, h->Yf, h->Xt1, h->Yt1};
+                    h->Tf, h->Th, h->Tth, h->dstage, h->Gp, h->Gs, h->Cv, h->dflag, h->Vf, h->Yf, h->Xt1, h->Yt1, h->Sp};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     h->dA = h->dA0 = h->dQ = nullptr; h->Vh = h->Vt = nullptr; h->vdiag = nullptr; h->Xt = nullptr; h->Yt = nullptr;
     h->S = nullptr; h->P = nullptr; h->tmp1 = h->tmp2 = nullptr; h->Tf = nullptr; h->Th = h->Tth = nullptr;
     h->dstage = nullptr; h->stage_elems = 0;
     h->Gp = nullptr; h->Gs = nullptr; h->Cv = nullptr; h->dflag = nullptr; h->Vf = nullptr; h->Yf = nullptr;
-    h->Xt1 = nullptr; h->Yt1 = nullptr;
+    h->Xt1 = nullptr; h->Yt1 = nullptr; h->Sp = nullptr;
     for (hipEvent_t e : h->ev_node) (void)hipEventDestroy(e);
     for (hipEvent_t e : h->ev_cols) (void)hipEventDestroy(e);
     h->ev_node.clear(); h->ev_cols.clear();
@@ -366,9 +367,17 @@ void factor_node(mpqr_handle_t h, int id, bool do_panel) {
             a.A = h->Aeff; a.lda = h->lda; a.mrows = h->m; a.cb = rdown(nd.c0, tall ? 128 : 32); a.c0 = nd.c0; a.c1 = nd.c1;
             a.Vh = h->Vh; a.ldvh = h->ldvh; a.Vt = h->Vt; a.ldvt = h->ldvt; a.vdiag = h->vdiag;
             a.P = h->P; a.maxwg = h->maxwg;
-            if (tall) launch_leaf_gram_householder(a, h->Gp, h->Gs, h->Cv, h->dflag, h->s0);
+            const bool fused = tall && !h->Vf;    // fp16 mode: the Gram of the rounded reflectors comes out of gh_apply
+            if (tall) launch_leaf_gram_householder(a, h->Gp, h->Gs, h->Cv, h->dflag, fused ? h->Sp : nullptr, h->S, h->s0);
             else launch_leaf_factor(a, h->s0);
             if (h->Vf) launch_extract_vf(h->Aeff, h->lda, h->vdiag, h->Vf, h->n_pad, h->m, nd.c0, nd.c1, h->s0);
+            if (fused) {
+                // S is in window coordinates (128 x 128 from a.cb); the node's aligned range starts at a0 >= cb
+                const int sh = nd.a0 - a.cb;
+                launch_t_leaf(h->S + (long)sh * 128 + sh, 1, 0, 128, nd.a0, nd.c0, nd.c1, h->Tf + nd.toff, h->Th + nd.toff,
+                              h->Tth + nd.toff, nd.ldt, h->s0);
+                return;
+            }
         }
         int nslab; long slab;
         gram(h, nd, nd, &nslab, &slab);
@@ -591,6 +600,7 @@ static int plan_common(mpqr_handle_t h, int m, int n, int r, const mpqr_opts* op
     if ((rc = dalloc(h, &h->P, (size_t)2 * h->maxwg * 32))) return rc;
     if ((rc = dalloc(h, &h->Gp, (size_t)(h->m_pad / 128 + 2) * 16384))) return rc;
     if ((rc = dalloc(h, &h->Gs, (size_t)16384))) return rc;
+    if ((rc = dalloc(h, &h->Sp, (size_t)(h->m_pad / 64 + 4) * 16384))) return rc;
     if ((rc = dalloc(h, &h->Cv, (size_t)16384))) return rc;
     if ((rc = dalloc(h, &h->dflag, (size_t)4))) return rc;
     if ((rc = dalloc(h, &h->dA0, (size_t)h->m_pad * h->lda + 1024))) return rc;

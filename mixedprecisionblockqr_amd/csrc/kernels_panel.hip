@@ -508,14 +508,54 @@ __global__ __launch_bounds__(512) void gh_solve_kernel(LeafArgs a, const double*
         }
 }
 
+typedef float floatx16p __attribute__((ext_vector_type(16)));
 // V_low = A_low C for 64 rows per workgroup on v_mfma_f32_32x32x2_f32 (exact f32).  LDS: the 64 x 128 row
 // tile (stride 129: conflict-free fragment reads) and C at window coordinates (zero outside the leaf).
-typedef float floatx16p __attribute__((ext_vector_type(16)));
-__global__ __launch_bounds__(256) void gh_apply_kernel(LeafArgs a, const float* __restrict__ Cv) {
+typedef half_t half8p __attribute__((ext_vector_type(8)));
+// partial Gram of the fp16 reflectors held in Ts ([128 columns][72]: the 64 rows of this workgroup, k contiguous):
+// upper 32 x 32 tiles of Ts Ts^T on v_mfma_f32_32x32x16_f16, written to Sp (fp32, 128 x 128, window coordinates)
+__device__ __forceinline__ void gh_partial_gram(const half_t* Ts, float* __restrict__ Sp, int lane, int wave) {
+    const int r = lane & 31, h = lane >> 5;
+    int t = 0;
+#pragma unroll
+    for (int ti = 0; ti < 4; ti++)
+#pragma unroll
+        for (int tj = ti; tj < 4; tj++, t++) {
+            if ((t & 3) != wave) continue;               // 10 upper tiles dealt to the 4 waves
+            floatx16p acc;
+#pragma unroll
+            for (int e = 0; e < 16; e++) acc[e] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < 4; ks++) {
+                const half8p av = *(const half8p*)&Ts[(ti * 32 + r) * 72 + ks * 16 + 8 * h];
+                const half8p bv = *(const half8p*)&Ts[(tj * 32 + r) * 72 + ks * 16 + 8 * h];
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, bv, acc, 0, 0, 0);
+            }
+#pragma unroll
+            for (int e = 0; e < 16; e++)
+                Sp[(ti * 32 + (e & 3) + 8 * (e >> 2) + 4 * h) * GW + tj * 32 + r] = acc[e];
+        }
+}
+
+// blockIdx < nlow: rows c1 + 64 b .. of A_low (apply, and the partial Gram when Sp is given);  blockIdx >= nlow:
+// 64 rows of the TOP block (final already, written by gh_solve): partial Gram only.
+__global__ __launch_bounds__(256) void gh_apply_kernel(LeafArgs a, const float* __restrict__ Cv, float* __restrict__ Sp, int nlow) {
     float* As = (float*)gh_smem;                         // [64][129] = 8256 floats
     float* Cs = (float*)gh_smem + 8256;                  // [128][GH_TS], 16-B aligned
     half_t* Ts = (half_t*)gh_smem;                       // [128][72] halves, reuses the As region after the MFMAs
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if ((int)blockIdx.x >= nlow) {                        // top-block rows: V^T tile straight from the fp16 copy
+        const int trow0 = a.c0 + ((int)blockIdx.x - nlow) * 64;
+        for (int e = tid; e < GW * 64; e += 256) {
+            const int c = e & 127, lr = e >> 7, row = trow0 + lr, gc = a.cb + c;
+            half_t v = (half_t)0.f;
+            if (row < a.c1 && gc >= a.c0 && gc < a.c1 && row >= gc) v = a.Vh[(long)row * a.ldvh + gc];
+            Ts[c * 72 + lr] = v;
+        }
+        __syncthreads();
+        gh_partial_gram(Ts, Sp + (long)blockIdx.x * (GW * GW), lane, wave);
+        return;
+    }
     const int row0 = a.c1 + blockIdx.x * 64;
     const int off = a.c0 - a.cb, w = a.c1 - a.c0;
     // C at window coordinates, zero outside the leaf and below the diagonal: one pass, no separate clear
@@ -562,6 +602,7 @@ __global__ __launch_bounds__(256) void gh_apply_kernel(LeafArgs a, const float* 
         }
     }
     __syncthreads();
+    if (Sp) gh_partial_gram(Ts, Sp + (long)blockIdx.x * (GW * GW), lane, wave);
     // V^T rows: 128 columns x 64 rows of this workgroup, 16-B chunks along the row index
     for (int e = tid; e < GW * 8; e += 256) {
         const int c = e >> 3, ch = e & 7;
@@ -578,7 +619,20 @@ __global__ __launch_bounds__(256) void gh_apply_kernel(LeafArgs a, const float* 
     }
 }
 
-void launch_leaf_gram_householder(const LeafArgs& a, double* Gp, double* G, float* Cv, int* flag, hipStream_t s) {
+// S = sum of nslab fp32 partials (128 x 128), fixed order; same scheme as gh_reduce_kernel
+__global__ __launch_bounds__(256) void gh_reduce_f32_kernel(const float* __restrict__ Sp, int nslab, float* __restrict__ S) {
+    __shared__ float part[4][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int e = blockIdx.x * 64 + lane;
+    float s = 0.f;
+    for (int q = wave; q < nslab; q += 4) s += Sp[(long)q * (GW * GW) + e];
+    part[wave][lane] = s;
+    __syncthreads();
+    if (wave == 0) S[e] = (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
+}
+
+void launch_leaf_gram_householder(const LeafArgs& a, double* Gp, double* G, float* Cv, int* flag, float* Sp, float* S,
+                                  hipStream_t s) {
     static bool attr = false;
     if (!attr) {
         (void)hipFuncSetAttribute((const void*)gh_gram_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, GH_ROWS * GH_TD * 8);
@@ -591,8 +645,11 @@ void launch_leaf_gram_householder(const LeafArgs& a, double* Gp, double* G, floa
     hipLaunchKernelGGL(gh_reduce_kernel, dim3(256), dim3(256), 0, s, Gp, nwg, G);
     static const int dbg = []() { const char* e = getenv("MPQR_DBG_SOLVE"); return e ? atoi(e) : 0; }();
     hipLaunchKernelGGL(gh_solve_kernel, dim3(1), dim3(512), GW * GH_TS * 4, s, a, G, Cv, flag, dbg);
-    const int nwa = (a.mrows - a.c1 + 63) / 64;
-    hipLaunchKernelGGL(gh_apply_kernel, dim3(nwa), dim3(256), (8256 + GW * GH_TS) * 4, s, a, Cv);
+    const int nlow = (a.mrows - a.c1 + 63) / 64;
+    const int ntop = Sp ? (a.c1 - a.c0 + 63) / 64 : 0;      // extra workgroups: Gram contribution of the top block
+    if (nlow + ntop == 0) return;
+    hipLaunchKernelGGL(gh_apply_kernel, dim3(nlow + ntop), dim3(256), (8256 + GW * GH_TS) * 4, s, a, Cv, Sp, nlow);
+    if (Sp) hipLaunchKernelGGL(gh_reduce_f32_kernel, dim3(256), dim3(256), 0, s, Sp, nlow + ntop, S);
 }
 
 void launch_leaf_factor(const LeafArgs& a, hipStream_t s) {
