@@ -357,29 +357,97 @@ __device__ __forceinline__ double fast_rsqrt(double x) {
     return refine_rsqrt(x, (double)rsqrtf((float)x));
 }
 
-// 512 threads as a 16 x 32 grid; thread (ti,tj) keeps the 8 x 4 blocks {8ti..8ti+7} x {4tj..4tj+3} of
-// N (fp64), B_top and M (fp32) in registers.  Per reflector: owners of row/column k publish them to LDS, every
-// thread derives alpha, inv, w, v_top redundantly and updates its own entries -- two barriers per step.
-// With u = column k over the remaining rows:  s_j = N[k][j],  w_j = 2 (s_j + alpha B[k][j]) inv,
-// v_top[t] = (B[t][k] + [t==k] alpha) inv,  v_low = A_low (M[:,k] inv).  H is orthogonal, so the Gram matrix of the
-// reflected columns over the same rows is unchanged; only the now-final row k (a row of R) leaves the set:
+typedef float floatx16p __attribute__((ext_vector_type(16)));
+constexpr int TP = 128, TPS = 129;
+
+// 32 x 32 tile of A (32 x K, LDS) * B (K x 32, LDS) on the exact-f32 MFMA; odd row strides: conflict-free
+__device__ __forceinline__ floatx16p lds_mm32(const float* A, int lda, const float* B, int ldb, int K, int lane) {
+    const int r = lane & 31, kk = lane >> 5;
+    floatx16p acc;
+#pragma unroll
+    for (int e = 0; e < 16; e++) acc[e] = 0.f;
+#pragma unroll 8
+    for (int k0 = 0; k0 < K; k0 += 2)
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(A[r * lda + k0 + kk], B[(k0 + kk) * ldb + r], acc, 0, 0, 0);
+    return acc;
+}
+__device__ __forceinline__ void lds_store32(float* C, int ldc, const floatx16p& acc, float scale, int lane) {
+    const int r = lane & 31, kk = lane >> 5;
+#pragma unroll
+    for (int e = 0; e < 16; e++) C[((e & 3) + 8 * (e >> 2) + 4 * kk) * ldc + r] = scale * acc[e];
+}
+
+// Ts = X^{-1} for the upper-triangular X = striu(Ss) + diag(1 / tdiag), 128 x 128 in LDS (stride TPS), Ts zero on
+// entry.  nblk = active 32-blocks.  Diagonal blocks: row a of the inverse depends on row a only, lane a runs the
+// column recurrence in registers.  Then two merge levels X_LR -> -T_L (X_LR T_R) on the MFMA; the intermediate
+// product overwrites X_LR in Ss, so the lower triangle of Ts stays zero.  Needs >= 4 waves; ends with a barrier.
+__device__ __forceinline__ void tri_inverse_128(float* Ss, const float* tdiag, float* Ts, int nblk, int tid) {
+    const int wave = tid >> 6, lane = tid & 63;
+    if (wave < nblk && lane < 32) {
+        const int base = 32 * wave;
+        float tr[32];
+#pragma unroll
+        for (int i = 0; i < 32; i++) {
+            const float tii = tdiag[base + i];
+            float sum = 0.f;
+#pragma unroll
+            for (int q = 0; q < i; q++) sum += tr[q] * Ss[(base + q) * TPS + base + i];
+            tr[i] = (lane < i) ? -tii * sum : (lane == i ? tii : 0.f);
+        }
+#pragma unroll
+        for (int i = 0; i < 32; i++) Ts[(base + lane) * TPS + base + i] = tr[i];
+    }
+    __syncthreads();
+    for (int half = 32; half < 32 * nblk; half *= 2) {
+        const int ts = half / 32, npair = TP / (2 * half);
+        const bool has = wave < npair * ts * ts;
+        const int p = wave / (ts * ts), t = wave % (ts * ts), bi = t / ts, bj = t % ts;
+        const int L0 = p * 2 * half, R0 = L0 + half;
+        floatx16p acc;
+        if (has) acc = lds_mm32(&Ss[(L0 + 32 * bi) * TPS + R0], TPS, &Ts[R0 * TPS + R0 + 32 * bj], TPS, half, lane);
+        __syncthreads();
+        if (has) lds_store32(&Ss[(L0 + 32 * bi) * TPS + R0 + 32 * bj], TPS, acc, 1.f, lane);
+        __syncthreads();
+        if (has) {
+            acc = lds_mm32(&Ts[(L0 + 32 * bi) * TPS + L0], TPS, &Ss[L0 * TPS + R0 + 32 * bj], TPS, half, lane);
+            lds_store32(&Ts[(L0 + 32 * bi) * TPS + R0 + 32 * bj], TPS, acc, -1.f, lane);
+        }
+        __syncthreads();
+    }
+}
+
+// 512 threads as a 16 x 32 grid; thread (ti,tj) keeps the 8 x 4 blocks {8ti..8ti+7} x {4tj..4tj+3} of N (fp64)
+// and B_top (fp32) in registers.  With u = column k over the remaining rows:  s_j = N[k][j],
+// w_j = 2 (s_j + alpha B[k][j]) inv,  v_top[t] = (B[t][k] + [t==k] alpha) inv.  H is orthogonal, so the Gram matrix
+// of the reflected columns over the same rows is unchanged; only the now-final row k (a row of R) leaves the set:
 // N'_ij = N_ij - R[k][i] R[k][j].
+// The loop is software-pipelined: iteration s first brings row/column s of N and B up to date from the vectors of
+// step s-1 (a handful of FMAs by their owners) and publishes them; after the barrier two waves derive the vectors
+// of step s (the long fp64 scalar chain) WHILE all waves apply step s-1 to their blocks.
+// The coefficient matrix (V_low = A_low C) needs no update in the loop: with M the running column map,
+// C[:,k] = M[:,k] inv_k and M[:,j] = e_j - sum_{k<j} C[:,k] w^(k)_j, i.e. C (D^-1 + W) = I with W[k][j] = w^(k)_j
+// strictly upper and D = diag(inv): one triangular inverse after the loop (MFMA merges, tri_inverse_128).
 constexpr int SR = 8, SC = 4;
-__global__ __launch_bounds__(512) void gh_solve_kernel(LeafArgs a, const double* __restrict__ G, float* __restrict__ Cv,
-                                                       int* __restrict__ flag, int dbg) {
-    float* stage = (float*)gh_smem;                       // [GW][GH_TS]: collects C during the k loop
+constexpr int GH_SOLVE_THREADS = 512;
+struct GhVec { double rk[GW]; float w[GW], vt[GW], col[GW]; };
+__global__ __launch_bounds__(GH_SOLVE_THREADS) void gh_solve_kernel(LeafArgs a, const double* __restrict__ G,
+                                                                    float* __restrict__ Cv, int* __restrict__ flag) {
+    float* Ws = (float*)gh_smem;                          // [TP][TPS]: row k = w^(k)
+    float* Ts = Ws + TP * TPS;                            // [TP][TPS]: the inverse
     __shared__ double rowN[GW], col0[GW];
-    __shared__ float rowB[GW], colB[GW], colM[GW], vdl[GW];
-    __shared__ float vw[GW], vvt[GW], vcv[GW], vcol[GW];
-    __shared__ double vrk[GW];
-    __shared__ int lflag;
+    __shared__ float rowB[GW], colB[GW], vdl[GW], tdiag[GW];
+    __shared__ GhVec vec[2];
+    __shared__ int lflag, cmask[GW];
     const int tid = threadIdx.x;
-    const int ti = tid >> 5, tj = tid & 31;
+    const int ti = tid >> 5, tj = tid & 31, wave = tid >> 6;
     const int w = a.c1 - a.c0, off = a.c0 - a.cb;
-    if (tid < GW) vdl[tid] = 0.f;
+    if (tid < GW) {
+        vdl[tid] = 0.f; tdiag[tid] = 1.f; cmask[tid] = 0;
+        vec[0].rk[tid] = 0.0; vec[0].w[tid] = 0.f; vec[0].vt[tid] = 0.f; vec[0].col[tid] = 0.f;
+    }
     if (tid == 0) lflag = 0;
     double N[SR][SC];
-    float B[SR][SC], M[SR][SC];
+    float B[SR][SC];
 #pragma unroll
     for (int x = 0; x < SR; x++)
 #pragma unroll
@@ -390,99 +458,123 @@ __global__ __launch_bounds__(512) void gh_solve_kernel(LeafArgs a, const double*
                 g = G[(off + i) * GW + off + j];
                 b = a.A[(long)(a.c0 + i) * a.lda + a.c0 + j];
             }
-            N[x][y] = g; B[x][y] = b; M[x][y] = (i == j) ? 1.f : 0.f;
-            if (i == j) col0[i] = g;                       // ||a_j||^2 over all leaf rows
+            N[x][y] = g; B[x][y] = b;
+            if (i == j) col0[i] = g;                // ||a_j||^2 over all leaf rows
         }
-    // C is collected in LDS (no global stores inside the k loop -- a barrier would have to wait for them to drain)
-    float* Cs = stage;
-    for (int e = tid; e < GW * GH_TS; e += 512) Cs[e] = 0.f;
+    for (int e = tid; e < 2 * TP * TPS; e += GH_SOLVE_THREADS) Ws[e] = 0.f;
     __syncthreads();
-    for (int kr = 0; kr < w; kr++) {
-        // (1) owners publish row kr of N, B and column kr of B, M
-        if (ti == (kr >> 3) && dbg != 3) {
+    for (int s = 0; s <= w; s++) {
+        const GhVec& pv = vec[s & 1];                      // vectors of step s-1 (all zero for s = 0)
+        // (1) look-ahead: row s of N, B and column s of B as they are AFTER step s-1, from their owners.  The
+        // owners' LDS reads are issued together (pinned in front of the select trees): one round trip.
+        if (s < w) {
+            if (ti == (s >> 3)) {
+                double r0 = pv.rk[s], rj[SC]; float v0 = pv.vt[s], wq[SC];
 #pragma unroll
-            for (int x = 0; x < SR; x++)
-                if (x == (kr & 7)) {
+                for (int y = 0; y < SC; y++) { rj[y] = pv.rk[SC * tj + y]; wq[y] = pv.w[SC * tj + y]; }
+                asm volatile("" : "+v"(r0), "+v"(v0));
 #pragma unroll
-                    for (int y = 0; y < SC; y++) { rowN[SC * tj + y] = N[x][y]; rowB[SC * tj + y] = B[x][y]; }
-                }
-        }
-        if (tj == (kr >> 2)) {
+                for (int y = 0; y < SC; y++) asm volatile("" : "+v"(rj[y]), "+v"(wq[y]));
 #pragma unroll
-            for (int y = 0; y < SC; y++)
-                if (y == (kr & 3)) {
+                for (int x = 0; x < SR; x++)
+                    if (x == (s & 7)) {
 #pragma unroll
-                    for (int x = 0; x < SR; x++) { colB[SR * ti + x] = B[x][y]; colM[SR * ti + x] = M[x][y]; }
-                }
-        }
-        __syncthreads();
-        // (2) one thread per index derives the step's vectors (zeroed outside their index ranges)
-        if (tid < GW && dbg != 2) {
-            const int i = tid;
-            const double sk = rowN[kr], u0 = (double)rowB[kr];
-            double alpha = 0, inv = 0;
-            const bool skip = !(sk > 0);
-            if (!skip) {
-                if (sk > 1e-30 && sk < 1e30) {
-                    // both fp32 seeds first (short fp32 chain), then the two fp64 refinements
-                    const float skf = (float)sk, s1 = rsqrtf(skf), nuf = skf * s1;
-                    const float s2 = rsqrtf(2.0f * (skf + fabsf((float)u0) * nuf));
-                    const double nu = sk * refine_rsqrt(sk, (double)s1);
-                    alpha = (u0 >= 0) ? nu : -nu;
-                    inv = refine_rsqrt(2.0 * (sk + fabs(u0) * nu), (double)s2);
-                } else {
-                    const double nu = sqrt(sk);
-                    alpha = (u0 >= 0) ? nu : -nu;
-                    inv = 1.0 / sqrt(2.0 * (sk + fabs(u0) * nu));
-                }
+                        for (int y = 0; y < SC; y++) {
+                            rowN[SC * tj + y] = fma(-r0, rj[y], N[x][y]);
+                            rowB[SC * tj + y] = fmaf(-v0, wq[y], B[x][y]);
+                        }
+                    }
             }
-            const double vtk = (u0 + alpha) * inv;                    // v_top[kr]
-            const double wd = (i > kr && i < w) ? 2.0 * (rowN[i] + alpha * (double)rowB[i]) * inv : 0.0;
-            vw[i] = (float)wd;                                         // w_i (0 for i <= kr)
-            vrk[i] = (i > kr) ? (double)rowB[i] - vtk * wd : 0.0;      // R[kr][i] (0 for i <= kr)
-            const float vti = (i >= kr && i < w) ? (float)(((double)colB[i] + (i == kr ? alpha : 0.0)) * inv) : 0.f;
-            vvt[i] = vti;                                              // v_top[i] (0 for i < kr)
-            const float cvi = (i <= kr) ? (float)((double)colM[i] * inv) : 0.f;
-            vcv[i] = cvi;                                              // C[i][kr] (0 for i > kr)
-            vcol[i] = skip ? colB[i] : ((i > kr) ? vti : (i == kr ? (float)(-alpha) : colB[i]));   // new column kr of B
-            Cs[i * GH_TS + kr] = cvi;
-            if (i == 0) {
-                if (!skip && sk < GH_RHO_MIN * col0[kr]) lflag = 1;
-                if (skip && col0[kr] > 0) lflag = 1;                  // cancelled to <= 0 but not an exactly-zero column
-                vdl[kr] = skip ? 0.f : (float)vtk;
-            }
-        }
-        __syncthreads();
-        // (3) every thread: three FMAs per entry (a skipped column has all-zero vectors: no-op)
-        if (dbg != 1) {
-            float wj[SC]; double rkj[SC];
+            if (tj == (s >> 2)) {
+                float ws = pv.w[s], v8[SR];
 #pragma unroll
-            for (int y = 0; y < SC; y++) { wj[y] = vw[SC * tj + y]; rkj[y] = vrk[SC * tj + y]; }
+                for (int x = 0; x < SR; x++) v8[x] = pv.vt[SR * ti + x];
+                asm volatile("" : "+v"(ws));
 #pragma unroll
-            for (int x = 0; x < SR; x++) {
-                const int i = SR * ti + x;
-                const float nvt = -vvt[i], ncv = -vcv[i];
-                const double nrk = -vrk[i];
-#pragma unroll
-                for (int y = 0; y < SC; y++) {
-                    B[x][y] = fmaf(nvt, wj[y], B[x][y]);
-                    M[x][y] = fmaf(ncv, wj[y], M[x][y]);
-                    N[x][y] = fma(nrk, rkj[y], N[x][y]);
-                }
-            }
-            if (tj == (kr >> 2)) {                                     // column kr: reflector below, R_kk on the diagonal
+                for (int x = 0; x < SR; x++) asm volatile("" : "+v"(v8[x]));
 #pragma unroll
                 for (int y = 0; y < SC; y++)
-                    if (y == (kr & 3)) {
+                    if (y == (s & 3)) {
 #pragma unroll
-                        for (int x = 0; x < SR; x++) B[x][y] = vcol[SR * ti + x];
+                        for (int x = 0; x < SR; x++) colB[SR * ti + x] = fmaf(-v8[x], ws, B[x][y]);
                     }
             }
         }
-        // the next publish overwrites rowN/rowB/colB/colM only, the vectors above are rewritten after its barrier
+        __syncthreads();
+        {
+            // (2) waves 0-1: vectors of step s (branch-free; a column that cannot be reflected gets all-zero w, v)
+            if (tid < GW && s < w) {
+                GhVec& nv = vec[(s + 1) & 1];
+                const int i = tid, kr = s;
+                const double sk = rowN[kr], rni = rowN[i], c0k = col0[kr];
+                const float u0f = rowB[kr], rbi = rowB[i], cb = colB[i];
+                const double u0 = (double)u0f;
+                const bool ok = sk > 1e-30 && sk < 1e30;   // false: exactly-zero column (skipped) or out of range (flagged)
+                const double skd = ok ? sk : 1.0;
+                // both fp32 seeds first (short fp32 chain), then the two fp64 refinements
+                const float skf = (float)skd, s1 = rsqrtf(skf), nuf = skf * s1;
+                const float s2 = rsqrtf(2.0f * (skf + fabsf(u0f) * nuf));
+                const double nu = skd * refine_rsqrt(skd, (double)s1);
+                double alpha = (u0 >= 0) ? nu : -nu;
+                double inv = refine_rsqrt(2.0 * (skd + fabs(u0) * nu), (double)s2);
+                alpha = ok ? alpha : 0.0; inv = ok ? inv : 0.0;
+                const double vtk = (u0 + alpha) * inv;                    // v_top[kr]
+                double wd = 2.0 * (rni + alpha * (double)rbi) * inv;
+                wd = (i > kr && i < w) ? wd : 0.0;
+                double rk = (double)rbi - vtk * wd;
+                rk = (i > kr) ? rk : 0.0;
+                float vt = (float)(((double)cb + (i == kr ? alpha : 0.0)) * inv);
+                vt = (i >= kr && i < w) ? vt : 0.f;
+                float nc = (i > kr) ? vt : (i == kr ? (float)(-alpha) : cb);
+                nc = ok ? nc : cb;
+                nv.w[i] = (float)wd;                                       // w_i (0 for i <= kr)
+                nv.rk[i] = rk;                                             // R[kr][i] (0 for i <= kr)
+                nv.vt[i] = vt;                                             // v_top[i] (0 for i < kr)
+                nv.col[i] = nc;                                            // new column kr of B
+                Ws[kr * TPS + i] = (float)wd;
+                if (i == 0) {
+                    if (ok ? (sk < GH_RHO_MIN * c0k) : (c0k > 0)) lflag = 1;   // cancelled, but not an exactly-zero column
+                    vdl[kr] = (float)vtk;
+                    tdiag[kr] = ok ? (float)inv : 1.f;
+                    cmask[kr] = ok ? 1 : 0;
+                }
+            }
+        }
+        if (16 * wave + 15 >= s - 1) {
+            // (3) apply step s-1 to the block (a skipped column has zero w, v: only the R row leaves N).  Rows above
+            // s-1 are final: a wave whose 16 rows are all final has nothing left to do.
+            float wj[SC], vti[SR]; double rkj[SC], rki[SR];
+#pragma unroll
+            for (int y = 0; y < SC; y++) { wj[y] = pv.w[SC * tj + y]; rkj[y] = pv.rk[SC * tj + y]; }
+#pragma unroll
+            for (int x = 0; x < SR; x++) { vti[x] = pv.vt[SR * ti + x]; rki[x] = pv.rk[SR * ti + x]; }
+#pragma unroll
+            for (int x = 0; x < SR; x++) {
+                const float nvt = -vti[x];
+                const double nrk = -rki[x];
+#pragma unroll
+                for (int y = 0; y < SC; y++) {
+                    B[x][y] = fmaf(nvt, wj[y], B[x][y]);
+                    N[x][y] = fma(nrk, rkj[y], N[x][y]);
+                }
+            }
+            if (s > 0 && tj == ((s - 1) >> 2)) {                       // column s-1: reflector below, R_kk on the diagonal
+#pragma unroll
+                for (int y = 0; y < SC; y++)
+                    if (y == ((s - 1) & 3)) {
+#pragma unroll
+                        for (int x = 0; x < SR; x++) B[x][y] = pv.col[SR * ti + x];
+                    }
+            }
+        }
+        __syncthreads();
     }
-    __syncthreads();
-    for (int e = tid; e < GW * GW; e += 512) Cv[e] = Cs[(e >> 7) * GH_TS + (e & 127)];
+    // C = (D^-1 + W)^-1, columns of skipped reflectors zeroed
+    tri_inverse_128(Ws, tdiag, Ts, (w + 31) / 32, tid);
+    for (int e = tid; e < GW * GW; e += GH_SOLVE_THREADS) {
+        const int i = e >> 7, k = e & 127;
+        Cv[e] = (i <= k && k < w && cmask[k]) ? Ts[i * TPS + k] : 0.f;
+    }
     if (tid < w) {
         const int k = a.c0 + tid;
         const float vd = vdl[tid];
@@ -508,7 +600,6 @@ __global__ __launch_bounds__(512) void gh_solve_kernel(LeafArgs a, const double*
         }
 }
 
-typedef float floatx16p __attribute__((ext_vector_type(16)));
 // V_low = A_low C for 64 rows per workgroup on v_mfma_f32_32x32x2_f32 (exact f32).  LDS: the 64 x 128 row
 // tile (stride 129: conflict-free fragment reads) and C at window coordinates (zero outside the leaf).
 typedef half_t half8p __attribute__((ext_vector_type(8)));
@@ -636,15 +727,14 @@ void launch_leaf_gram_householder(const LeafArgs& a, double* Gp, double* G, floa
     static bool attr = false;
     if (!attr) {
         (void)hipFuncSetAttribute((const void*)gh_gram_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, GH_ROWS * GH_TD * 8);
-        (void)hipFuncSetAttribute((const void*)gh_solve_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, GW * GH_TS * 4);
+        (void)hipFuncSetAttribute((const void*)gh_solve_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * TP * TPS * 4);
         (void)hipFuncSetAttribute((const void*)gh_apply_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (8256 + GW * GH_TS) * 4);
         attr = true;
     }
     const int nwg = (a.mrows - a.c0 + GH_ROWS - 1) / GH_ROWS;
     hipLaunchKernelGGL(gh_gram_kernel, dim3(2 * nwg), dim3(256), GH_ROWS * GH_TD * 8, s, a, Gp);
     hipLaunchKernelGGL(gh_reduce_kernel, dim3(256), dim3(256), 0, s, Gp, nwg, G);
-    static const int dbg = []() { const char* e = getenv("MPQR_DBG_SOLVE"); return e ? atoi(e) : 0; }();
-    hipLaunchKernelGGL(gh_solve_kernel, dim3(1), dim3(512), GW * GH_TS * 4, s, a, G, Cv, flag, dbg);
+    hipLaunchKernelGGL(gh_solve_kernel, dim3(1), dim3(GH_SOLVE_THREADS), 2 * TP * TPS * 4, s, a, G, Cv, flag);
     const int nlow = (a.mrows - a.c1 + 63) / 64;
     const int ntop = Sp ? (a.c1 - a.c0 + 63) / 64 : 0;      // extra workgroups: Gram contribution of the top block
     if (nlow + ntop == 0) return;
@@ -683,76 +773,32 @@ void launch_leaf_factor(const LeafArgs& a, hipStream_t s) {
 // of the fp16-ROUNDED reflectors, which keeps I - V T V^T orthogonal for the V the MFMA GEMMs actually use.
 // One workgroup, everything in LDS: the four 32 x 32 diagonal blocks by the column recurrence
 // (T_ii = 2/S_ii, T[:i,i] = -T_ii T[:i,:i] S[:i,i]; row a depends on row a only, so lane a runs it in registers),
-// then two levels of  T_LR = -T_L (S_LR T_R).  Indices >= w are padded with S = 2 I (T = I), which decouples.
+// then two levels of  T_LR = -T_L (S_LR T_R) on the exact-f32 MFMA.  Indices >= w are padded with T = I, which decouples.
 // Replaces the reference's dev_wy_transform loop (Cuda/qr.cu:535-600: r rounds of three kernels, dense (m-l)^2).
-constexpr int TP = 128, TPS = 129;
 __global__ __launch_bounds__(1024) void t_panel_kernel(const float* __restrict__ S, int nslab, long slab_stride, int lds_,
                                                        int a0, int c0, int c1, float* __restrict__ T,
                                                        half_t* __restrict__ Th, half_t* __restrict__ Tth, int ldt) {
     float* Ss = (float*)gh_smem;             // [TP][TPS]
     float* Ts = Ss + TP * TPS;               // [TP][TPS]
+    __shared__ float tdiag[TP];
     const int tid = threadIdx.x;
     const int w = c1 - c0, off = c0 - a0;
     const int nblk = (w + 31) / 32;          // active 32-blocks
-    for (int e = tid; e < TP * TP; e += 1024) {
+#pragma unroll
+    for (int q = 0; q < TP * TP / 1024; q++) {              // fully unrolled: the 16 loads of a thread are in flight together
+        const int e = tid + 1024 * q;
         const int i = e >> 7, j = e & 127;
-        float v = (i == j) ? 2.f : 0.f;
-        if (i < w && j < w) {
-            v = 0.f;
-            if (j >= i) for (int sl = 0; sl < nslab; sl++) v += S[(long)sl * slab_stride + (long)(off + i) * lds_ + off + j];
+        float v = 0.f;
+        if (i < w && j < w && j >= i) {
+            v = S[(long)(off + i) * lds_ + off + j];
+            for (int sl = 1; sl < nslab; sl++) v += S[(long)sl * slab_stride + (long)(off + i) * lds_ + off + j];
         }
+        if (i == j) { tdiag[i] = (i < w) ? (v > 0.f ? 2.0f / v : 0.f) : 1.f; v = 0.f; }
         Ss[i * TPS + j] = v;
         Ts[i * TPS + j] = 0.f;
     }
     __syncthreads();
-    {   // diagonal blocks: wave b <-> block b, lane a <-> row a of the block
-        const int b = tid >> 6, la = tid & 63;
-        if (b < nblk && la < 32) {
-            const int base = 32 * b;
-            float tr[32];
-#pragma unroll
-            for (int i = 0; i < 32; i++) {
-                const float sii = Ss[(base + i) * TPS + base + i];
-                const float tii = sii > 0.f ? 2.0f / sii : 0.f;
-                float sum = 0.f;
-#pragma unroll
-                for (int q = 0; q < i; q++) sum += tr[q] * Ss[(base + q) * TPS + base + i];
-                tr[i] = (la < i) ? -tii * sum : (la == i ? tii : 0.f);
-            }
-#pragma unroll
-            for (int i = 0; i < 32; i++) Ts[(base + la) * TPS + base + i] = tr[i];
-        }
-    }
-    __syncthreads();
-    // merge levels: half = 32 (pairs of 32-blocks), then 64.  X = S_LR T_R is parked in the (unused) lower-left block.
-    for (int half = 32; half < 32 * nblk; half *= 2) {
-        const int span = 2 * half, npair = TP / span;
-        for (int e = tid; e < npair * half * half; e += 1024) {
-            const int p = e / (half * half), rem = e % (half * half), i = rem / half, j = rem % half;
-            const int L0 = p * span, R0 = L0 + half;
-            if (R0 >= 32 * nblk) continue;
-            float x = 0.f;
-            for (int k = 0; k <= j; k++) x += Ss[(L0 + i) * TPS + R0 + k] * Ts[(R0 + k) * TPS + R0 + j];   // T_R upper
-            Ts[(R0 + i) * TPS + L0 + j] = x;                  // X[i][j] parked at (R0+i, L0+j)
-        }
-        __syncthreads();
-        for (int e = tid; e < npair * half * half; e += 1024) {
-            const int p = e / (half * half), rem = e % (half * half), i = rem / half, j = rem % half;
-            const int L0 = p * span, R0 = L0 + half;
-            if (R0 >= 32 * nblk) continue;
-            float t = 0.f;
-            for (int k = i; k < half; k++) t += Ts[(L0 + i) * TPS + L0 + k] * Ts[(R0 + k) * TPS + L0 + j];  // T_L upper
-            Ss[(L0 + i) * TPS + R0 + j] = -t;                 // T_LR staged in Ss (S_LR is no longer needed)
-        }
-        __syncthreads();
-        for (int e = tid; e < npair * half * half; e += 1024) {
-            const int p = e / (half * half), rem = e % (half * half), i = rem / half, j = rem % half;
-            const int L0 = p * span, R0 = L0 + half;
-            if (R0 >= 32 * nblk) continue;
-            Ts[(L0 + i) * TPS + R0 + j] = Ss[(L0 + i) * TPS + R0 + j];
-        }
-        __syncthreads();
-    }
+    tri_inverse_128(Ss, tdiag, Ts, nblk, tid);
     for (int e = tid; e < ldt * ldt; e += 1024) {
         const int i = e / ldt, j = e % ldt;
         const int li = i - off, lj = j - off;
