@@ -416,98 +416,98 @@ __device__ __forceinline__ void tri_inverse_128(float* Ss, const float* tdiag, f
     }
 }
 
-// 512 threads as a 16 x 32 grid; thread (ti,tj) keeps the 8 x 4 blocks {8ti..8ti+7} x {4tj..4tj+3} of N (fp64)
-// and B_top (fp32) in registers.  With u = column k over the remaining rows:  s_j = N[k][j],
-// w_j = 2 (s_j + alpha B[k][j]) inv,  v_top[t] = (B[t][k] + [t==k] alpha) inv.  H is orthogonal, so the Gram matrix
-// of the reflected columns over the same rows is unchanged; only the now-final row k (a row of R) leaves the set:
-// N'_ij = N_ij - R[k][i] R[k][j].
-// The loop is software-pipelined: iteration s first brings row/column s of N and B up to date from the vectors of
-// step s-1 (a handful of FMAs by their owners) and publishes them; after the barrier two waves derive the vectors
-// of step s (the long fp64 scalar chain) WHILE all waves apply step s-1 to their blocks.
+// 640 threads.  Waves 0-7 ("update", a 16 x 32 grid): thread (ti,tj) keeps the CYCLIC entries {ti + 16x} x {tj + 32y},
+// x < 8, y < 4, of B_top (fp32) and of N (fp64) in registers.  N is symmetric and only rows <= columns are ever
+// read, so the 16 x 32 blocks entirely below the diagonal (x > 2y+1) are not kept: 20 of 32.  Waves 8-9 ("scalar")
+// own no entries.  With u = column k over the remaining rows:  s_j = N[k][j],  w_j = 2 (s_j + alpha B[k][j]) inv,
+// v_top[t] = (B[t][k] + [t==k] alpha) inv.  H is orthogonal, so the Gram matrix of the reflected columns over the
+// same rows is unchanged; only the now-final row k (a row of R) leaves the set:  N'_ij = N_ij - R[k][i] R[k][j].
+// The loop is software-pipelined with ONE barrier per reflector.  Iteration t:
+//   scalar waves: take row/column t as published one iteration earlier (state after step t-2), apply step t-1 to
+//             just those entries (same FMAs as the update), run the fp64 scalar chain, write the vectors of step t
+//             and the final column t of the top block (R above the diagonal, R_tt, v below) to LDS;
+//   update waves: apply step t-1 to their entries (straight-line: vectors are zero where nothing changes), then
+//             the owners publish row/column t+1.
+// Neither side waits for the other inside an iteration.
 // The coefficient matrix (V_low = A_low C) needs no update in the loop: with M the running column map,
 // C[:,k] = M[:,k] inv_k and M[:,j] = e_j - sum_{k<j} C[:,k] w^(k)_j, i.e. C (D^-1 + W) = I with W[k][j] = w^(k)_j
 // strictly upper and D = diag(inv): one triangular inverse after the loop (MFMA merges, tri_inverse_128).
+#ifndef TRACE_TID
+#define TRACE_TID 0
+#endif
 constexpr int SR = 8, SC = 4;
-constexpr int GH_SOLVE_THREADS = 512;
-struct GhVec { double rk[GW]; float w[GW], vt[GW], col[GW]; };
+constexpr int GH_UPD_THREADS = 512, GH_SOLVE_THREADS = 640;
+struct GhVec { double rk[GW]; float w[GW], vt[GW]; };               // vectors of one step
+struct GhPre { double N[GW]; float B[GW], C[GW]; };                 // row t of N, B and column t of B, one step behind
 __global__ __launch_bounds__(GH_SOLVE_THREADS) void gh_solve_kernel(LeafArgs a, const double* __restrict__ G,
-                                                                    float* __restrict__ Cv, int* __restrict__ flag) {
+                                                                    float* __restrict__ Cv, int* __restrict__ flag, int trace) {
+    long tq[24]; int nt = 0;
+#define TSTAMP() do { if (trace && threadIdx.x == TRACE_TID) tq[nt++] = clock64(); } while (0)
+    TSTAMP();
     float* Ws = (float*)gh_smem;                          // [TP][TPS]: row k = w^(k)
-    float* Ts = Ws + TP * TPS;                            // [TP][TPS]: the inverse
-    __shared__ double rowN[GW], col0[GW];
-    __shared__ float rowB[GW], colB[GW], vdl[GW], tdiag[GW];
+    float* Ts = Ws + TP * TPS;                            // [TP][TPS]: final columns of the top block, then the inverse
+    __shared__ double col0[GW];
+    __shared__ float vdl[GW], tdiag[GW];
     __shared__ GhVec vec[2];
+    __shared__ GhPre pre[2];
     __shared__ int lflag, cmask[GW];
     const int tid = threadIdx.x;
-    const int ti = tid >> 5, tj = tid & 31, wave = tid >> 6;
+    const bool upd = tid < GH_UPD_THREADS;
+    const int ti = (tid >> 5) & 15, tj = tid & 31;
     const int w = a.c1 - a.c0, off = a.c0 - a.cb;
-    if (tid < GW) {
-        vdl[tid] = 0.f; tdiag[tid] = 1.f; cmask[tid] = 0;
-        vec[0].rk[tid] = 0.0; vec[0].w[tid] = 0.f; vec[0].vt[tid] = 0.f; vec[0].col[tid] = 0.f;
-    }
-    if (tid == 0) lflag = 0;
-    double N[SR][SC];
+    double N[SR][SC];                                     // x <= 2y+1 used
     float B[SR][SC];
 #pragma unroll
     for (int x = 0; x < SR; x++)
 #pragma unroll
         for (int y = 0; y < SC; y++) {
-            const int i = SR * ti + x, j = SC * tj + y;
+            const int i = ti + 16 * x, j = tj + 32 * y;
             double g = 0; float b = 0.f;
-            if (i < w && j < w) {
-                g = G[(off + i) * GW + off + j];
+            if (upd && i < w && j < w) {
+                if (x <= 2 * y + 1) g = G[(off + i) * GW + off + j];
                 b = a.A[(long)(a.c0 + i) * a.lda + a.c0 + j];
             }
             N[x][y] = g; B[x][y] = b;
-            if (i == j) col0[i] = g;                // ||a_j||^2 over all leaf rows
         }
-    for (int e = tid; e < 2 * TP * TPS; e += GH_SOLVE_THREADS) Ws[e] = 0.f;
+    // LDS set-up while the loads above are in flight
+    for (int e = tid; e < TP * TPS; e += GH_SOLVE_THREADS) Ws[e] = 0.f;
+    if (!upd) {
+        const int i = tid - GH_UPD_THREADS;
+        vdl[i] = 0.f; tdiag[i] = 1.f; cmask[i] = 0;
+        col0[i] = (i < w) ? G[(off + i) * GW + off + i] : 0.0;     // ||a_j||^2 over all leaf rows
+#pragma unroll
+        for (int q = 0; q < 2; q++) { vec[q].rk[i] = 0.0; vec[q].w[i] = 0.f; vec[q].vt[i] = 0.f; }
+        if (i == 0) lflag = 0;
+    } else {
+        if (ti == 0) {
+#pragma unroll
+            for (int y = 0; y < SC; y++) { pre[0].N[tj + 32 * y] = N[0][y]; pre[0].B[tj + 32 * y] = B[0][y]; }
+        }
+        if (tj == 0) {
+#pragma unroll
+            for (int x = 0; x < SR; x++) pre[0].C[ti + 16 * x] = B[x][0];
+        }
+    }
+    // the scalar chain is the critical path: its waves issue first
+    if (!upd) __builtin_amdgcn_s_setprio(3);
     __syncthreads();
-    for (int s = 0; s <= w; s++) {
-        const GhVec& pv = vec[s & 1];                      // vectors of step s-1 (all zero for s = 0)
-        // (1) look-ahead: row s of N, B and column s of B as they are AFTER step s-1, from their owners.  The
-        // owners' LDS reads are issued together (pinned in front of the select trees): one round trip.
-        if (s < w) {
-            if (ti == (s >> 3)) {
-                double r0 = pv.rk[s], rj[SC]; float v0 = pv.vt[s], wq[SC];
-#pragma unroll
-                for (int y = 0; y < SC; y++) { rj[y] = pv.rk[SC * tj + y]; wq[y] = pv.w[SC * tj + y]; }
-                asm volatile("" : "+v"(r0), "+v"(v0));
-#pragma unroll
-                for (int y = 0; y < SC; y++) asm volatile("" : "+v"(rj[y]), "+v"(wq[y]));
-#pragma unroll
-                for (int x = 0; x < SR; x++)
-                    if (x == (s & 7)) {
-#pragma unroll
-                        for (int y = 0; y < SC; y++) {
-                            rowN[SC * tj + y] = fma(-r0, rj[y], N[x][y]);
-                            rowB[SC * tj + y] = fmaf(-v0, wq[y], B[x][y]);
-                        }
-                    }
-            }
-            if (tj == (s >> 2)) {
-                float ws = pv.w[s], v8[SR];
-#pragma unroll
-                for (int x = 0; x < SR; x++) v8[x] = pv.vt[SR * ti + x];
-                asm volatile("" : "+v"(ws));
-#pragma unroll
-                for (int x = 0; x < SR; x++) asm volatile("" : "+v"(v8[x]));
-#pragma unroll
-                for (int y = 0; y < SC; y++)
-                    if (y == (s & 3)) {
-#pragma unroll
-                        for (int x = 0; x < SR; x++) colB[SR * ti + x] = fmaf(-v8[x], ws, B[x][y]);
-                    }
-            }
-        }
-        __syncthreads();
-        {
-            // (2) waves 0-1: vectors of step s (branch-free; a column that cannot be reflected gets all-zero w, v)
-            if (tid < GW && s < w) {
-                GhVec& nv = vec[(s + 1) & 1];
-                const int i = tid, kr = s;
-                const double sk = rowN[kr], rni = rowN[i], c0k = col0[kr];
-                const float u0f = rowB[kr], rbi = rowB[i], cb = colB[i];
+    TSTAMP();
+    for (int t = 0; t <= w; t++) {
+        const bool tr = trace && (t == 8 || t == 100);
+        if (tr) TSTAMP();
+        const GhVec& pv = vec[(t + 1) & 1];                // vectors of step t-1 (all zero for t = 0)
+        if (!upd) {
+            if (t < w) {
+                // vectors of step t (branch-free; a column that cannot be reflected gets all-zero w, v)
+                GhVec& nv = vec[t & 1];
+                const GhPre& pr = pre[t & 1];
+                const int i = tid - GH_UPD_THREADS, kr = t;
+                const double pk_rk = pv.rk[kr], pi_rk = pv.rk[i], pN_t = pr.N[kr], pN_i = pr.N[i], c0k = col0[kr];
+                const float pk_vt = pv.vt[kr], pk_w = pv.w[kr], pi_w = pv.w[i], pi_vt = pv.vt[i];
+                const float pB_t = pr.B[kr], pB_i = pr.B[i], pC_i = pr.C[i];
+                // row/column t after step t-1: the same FMAs the owners of these entries execute in their update
+                const double sk = fma(-pk_rk, pk_rk, pN_t), rni = fma(-pk_rk, pi_rk, pN_i);
+                const float u0f = fmaf(-pk_vt, pk_w, pB_t), rbi = fmaf(-pk_vt, pi_w, pB_i), cb = fmaf(-pi_vt, pk_w, pC_i);
                 const double u0 = (double)u0f;
                 const bool ok = sk > 1e-30 && sk < 1e30;   // false: exactly-zero column (skipped) or out of range (flagged)
                 const double skd = ok ? sk : 1.0;
@@ -530,7 +530,7 @@ __global__ __launch_bounds__(GH_SOLVE_THREADS) void gh_solve_kernel(LeafArgs a, 
                 nv.w[i] = (float)wd;                                       // w_i (0 for i <= kr)
                 nv.rk[i] = rk;                                             // R[kr][i] (0 for i <= kr)
                 nv.vt[i] = vt;                                             // v_top[i] (0 for i < kr)
-                nv.col[i] = nc;                                            // new column kr of B
+                Ts[kr * TPS + i] = nc;                                     // final column kr of the top block
                 Ws[kr * TPS + i] = (float)wd;
                 if (i == 0) {
                     if (ok ? (sk < GH_RHO_MIN * c0k) : (c0k > 0)) lflag = 1;   // cancelled, but not an exactly-zero column
@@ -539,41 +539,62 @@ __global__ __launch_bounds__(GH_SOLVE_THREADS) void gh_solve_kernel(LeafArgs a, 
                     cmask[kr] = ok ? 1 : 0;
                 }
             }
-        }
-        if (16 * wave + 15 >= s - 1) {
-            // (3) apply step s-1 to the block (a skipped column has zero w, v: only the R row leaves N).  Rows above
-            // s-1 are final: a wave whose 16 rows are all final has nothing left to do.
+        } else {
+            // apply step t-1 (a skipped column has zero w, v: only the R row leaves N)
             float wj[SC], vti[SR]; double rkj[SC], rki[SR];
 #pragma unroll
-            for (int y = 0; y < SC; y++) { wj[y] = pv.w[SC * tj + y]; rkj[y] = pv.rk[SC * tj + y]; }
+            for (int y = 0; y < SC; y++) { wj[y] = pv.w[tj + 32 * y]; rkj[y] = pv.rk[tj + 32 * y]; }
 #pragma unroll
-            for (int x = 0; x < SR; x++) { vti[x] = pv.vt[SR * ti + x]; rki[x] = pv.rk[SR * ti + x]; }
+            for (int x = 0; x < SR; x++) { vti[x] = pv.vt[ti + 16 * x]; rki[x] = pv.rk[ti + 16 * x]; }
 #pragma unroll
-            for (int x = 0; x < SR; x++) {
-                const float nvt = -vti[x];
-                const double nrk = -rki[x];
+            for (int x = 0; x < SR; x++)
 #pragma unroll
                 for (int y = 0; y < SC; y++) {
-                    B[x][y] = fmaf(nvt, wj[y], B[x][y]);
-                    N[x][y] = fma(nrk, rkj[y], N[x][y]);
+                    B[x][y] = fmaf(-vti[x], wj[y], B[x][y]);
+                    if (x <= 2 * y + 1) N[x][y] = fma(-rki[x], rkj[y], N[x][y]);
+                }
+            // publish row/column t+1 (state after step t-1) for the scalar waves of the next iteration
+            const int t1 = t + 1;
+            if (t1 < w) {
+                GhPre& nx = pre[t1 & 1];
+                if (ti == (t1 & 15)) {
+#pragma unroll
+                    for (int x = 0; x < SR; x++)
+                        if (x == (t1 >> 4)) {
+#pragma unroll
+                            for (int y = 0; y < SC; y++) {
+                                if (x <= 2 * y + 1) nx.N[tj + 32 * y] = N[x][y];
+                                nx.B[tj + 32 * y] = B[x][y];
+                            }
+                        }
+                }
+                if (tj == (t1 & 31)) {
+#pragma unroll
+                    for (int y = 0; y < SC; y++)
+                        if (y == (t1 >> 5)) {
+#pragma unroll
+                            for (int x = 0; x < SR; x++) nx.C[ti + 16 * x] = B[x][y];
+                        }
                 }
             }
-            if (s > 0 && tj == ((s - 1) >> 2)) {                       // column s-1: reflector below, R_kk on the diagonal
-#pragma unroll
-                for (int y = 0; y < SC; y++)
-                    if (y == ((s - 1) & 3)) {
-#pragma unroll
-                        for (int x = 0; x < SR; x++) B[x][y] = pv.col[SR * ti + x];
-                    }
-            }
         }
+        if (tr) TSTAMP();
         __syncthreads();
     }
-    // C = (D^-1 + W)^-1, columns of skipped reflectors zeroed
-    tri_inverse_128(Ws, tdiag, Ts, (w + 31) / 32, tid);
+    if (!upd) __builtin_amdgcn_s_setprio(0);
+    TSTAMP();
+    // R and the top block of V go out first (from the LDS columns): the stores drain while the inverse below runs
     for (int e = tid; e < GW * GW; e += GH_SOLVE_THREADS) {
-        const int i = e >> 7, k = e & 127;
-        Cv[e] = (i <= k && k < w && cmask[k]) ? Ts[i * TPS + k] : 0.f;
+        const int i = e >> 7, k = e & 127;                 // k fastest: rows of A and Vh
+        if (i < w && k < w) {
+            const float v = Ts[k * TPS + i];
+            a.A[(long)(a.c0 + i) * a.lda + a.c0 + k] = v;
+            if (i > k) a.Vh[(long)(a.c0 + i) * a.ldvh + a.c0 + k] = (half_t)v;
+        }
+    }
+    for (int e = tid; e < GW * GW; e += GH_SOLVE_THREADS) {
+        const int k = e >> 7, i = e & 127;                 // i fastest: rows of V^T
+        if (i < w && k < w && i > k) a.Vt[(long)(a.c0 + k) * a.ldvt + a.c0 + i] = (half_t)Ts[k * TPS + i];
     }
     if (tid < w) {
         const int k = a.c0 + tid;
@@ -583,25 +604,26 @@ __global__ __launch_bounds__(GH_SOLVE_THREADS) void gh_solve_kernel(LeafArgs a, 
         a.Vt[(long)k * a.ldvt + k] = (half_t)vd;
     }
     if (tid == 0 && lflag) atomicOr(flag, 1);
-#pragma unroll
-    for (int x = 0; x < SR; x++)
-#pragma unroll
-        for (int y = 0; y < SC; y++) {
-            const int i = SR * ti + x, j = SC * tj + y;
-            if (i < w && j < w) {
-                const float v = B[x][y];
-                const int row = a.c0 + i, col = a.c0 + j;
-                a.A[(long)row * a.lda + col] = v;
-                if (i > j) {
-                    a.Vh[(long)row * a.ldvh + col] = (half_t)v;
-                    a.Vt[(long)col * a.ldvt + row] = (half_t)v;
-                }
-            }
-        }
+    __syncthreads();
+    for (int e = tid; e < TP * TPS; e += GH_SOLVE_THREADS) Ts[e] = 0.f;
+    __syncthreads();
+    TSTAMP();
+    // C = (D^-1 + W)^-1, columns of skipped reflectors zeroed
+    tri_inverse_128(Ws, tdiag, Ts, (w + 31) / 32, tid);
+    TSTAMP();
+    for (int e = tid; e < GW * GW; e += GH_SOLVE_THREADS) {
+        const int i = e >> 7, k = e & 127;
+        Cv[e] = (i <= k && k < w && cmask[k]) ? Ts[i * TPS + k] : 0.f;
+    }
+    if (trace && threadIdx.x == TRACE_TID) {
+        tq[nt++] = clock64();
+        printf("gh_solve tid %d:", TRACE_TID);
+        for (int q = 1; q < nt; q++) printf(" %ld", tq[q] - tq[q - 1]);
+        printf("\n");
+    }
+#undef TSTAMP
 }
 
-// V_low = A_low C for 64 rows per workgroup on v_mfma_f32_32x32x2_f32 (exact f32).  LDS: the 64 x 128 row
-// tile (stride 129: conflict-free fragment reads) and C at window coordinates (zero outside the leaf).
 typedef half_t half8p __attribute__((ext_vector_type(8)));
 // partial Gram of the fp16 reflectors held in Ts ([128 columns][72]: the 64 rows of this workgroup, k contiguous):
 // upper 32 x 32 tiles of Ts Ts^T on v_mfma_f32_32x32x16_f16, written to Sp (fp32, 128 x 128, window coordinates)
@@ -734,7 +756,9 @@ void launch_leaf_gram_householder(const LeafArgs& a, double* Gp, double* G, floa
     const int nwg = (a.mrows - a.c0 + GH_ROWS - 1) / GH_ROWS;
     hipLaunchKernelGGL(gh_gram_kernel, dim3(2 * nwg), dim3(256), GH_ROWS * GH_TD * 8, s, a, Gp);
     hipLaunchKernelGGL(gh_reduce_kernel, dim3(256), dim3(256), 0, s, Gp, nwg, G);
-    hipLaunchKernelGGL(gh_solve_kernel, dim3(1), dim3(GH_SOLVE_THREADS), 2 * TP * TPS * 4, s, a, G, Cv, flag);
+    static int trace_left = []() { const char* e = getenv("MPQR_TRACE"); return e ? atoi(e) : 0; }();
+    const int trace = trace_left > 0 ? (trace_left--, 1) : 0;
+    hipLaunchKernelGGL(gh_solve_kernel, dim3(1), dim3(GH_SOLVE_THREADS), 2 * TP * TPS * 4, s, a, G, Cv, flag, trace);
     const int nlow = (a.mrows - a.c1 + 63) / 64;
     const int ntop = Sp ? (a.c1 - a.c0 + 63) / 64 : 0;      // extra workgroups: Gram contribution of the top block
     if (nlow + ntop == 0) return;
