@@ -22,7 +22,7 @@ typedef float floatx16 __attribute__((ext_vector_type(16)));
 constexpr int BM = 128, BN = 128, BK = 64;
 constexpr int LDSP = BK + 8;   // padded LDS row (halves): 144-B stride is conflict-free for ds_read_b128
 
-struct alignas(16) U4 { uint32_t x, y, z, w; };
+typedef uint32_t U4 __attribute__((ext_vector_type(4)));   // a first-class vector: staging arrays of it stay in registers
 
 __device__ __forceinline__ uint32_t pack2(float a, float b) {
     typedef half_t half2v __attribute__((ext_vector_type(2)));

@@ -441,8 +441,12 @@ struct GhVec { double rk[GW]; float w[GW], vt[GW]; };               // vectors o
 struct GhPre { double N[GW]; float B[GW], C[GW]; };                 // row t of N, B and column t of B, one step behind
 __global__ __launch_bounds__(GH_SOLVE_THREADS) void gh_solve_kernel(LeafArgs a, const double* __restrict__ G,
                                                                     float* __restrict__ Cv, int* __restrict__ flag, int trace) {
+#ifdef MPQR_SOLVE_TRACE
     long tq[24]; int nt = 0;
 #define TSTAMP() do { if (trace && threadIdx.x == TRACE_TID) tq[nt++] = clock64(); } while (0)
+#else
+#define TSTAMP() do {} while (0)
+#endif
     TSTAMP();
     float* Ws = (float*)gh_smem;                          // [TP][TPS]: row k = w^(k)
     float* Ts = Ws + TP * TPS;                            // [TP][TPS]: final columns of the top block, then the inverse
@@ -615,12 +619,14 @@ __global__ __launch_bounds__(GH_SOLVE_THREADS) void gh_solve_kernel(LeafArgs a, 
         const int i = e >> 7, k = e & 127;
         Cv[e] = (i <= k && k < w && cmask[k]) ? Ts[i * TPS + k] : 0.f;
     }
+#ifdef MPQR_SOLVE_TRACE
     if (trace && threadIdx.x == TRACE_TID) {
         tq[nt++] = clock64();
         printf("gh_solve tid %d:", TRACE_TID);
         for (int q = 1; q < nt; q++) printf(" %ld", tq[q] - tq[q - 1]);
         printf("\n");
     }
+#endif
 #undef TSTAMP
 }
 
