@@ -392,6 +392,12 @@ void factor_node(mpqr_handle_t h, int id, bool do_panel) {
     // T_LR = -T_L (V_L^T V_R) T_R
     int nslab; long slab;
     gram(h, L, R, &nslab, &slab);
+    if (L.ldt <= 128 && R.ldt <= 128) {
+        launch_t_merge(h->S, L.ldt, R.ldt, h->Tf + L.toff, h->Tf + R.toff, h->tmp2, h->s0);
+        launch_t_assemble(h->Tf + nd.toff, h->Th + nd.toff, h->Tth + nd.toff, nd.ldt, nd.a0, h->Tf + L.toff, L.ldt, L.a0,
+                          nd.c0, L.c1, h->Tf + R.toff, R.ldt, R.a0, nd.c1, h->tmp2, R.ldt, h->s0);
+        return;
+    }
     SgemmArgs s1{};
     s1.A = h->S; s1.lda = R.ldt; s1.transA = 0; s1.nslab_a = nslab; s1.slab_a = slab;
     s1.B = h->Tf + R.toff; s1.ldb = R.ldt; s1.transB = 0;

@@ -366,9 +366,13 @@ __device__ __forceinline__ floatx16p lds_mm32(const float* A, int lda, const flo
     floatx16p acc;
 #pragma unroll
     for (int e = 0; e < 16; e++) acc[e] = 0.f;
-#pragma unroll 8
-    for (int k0 = 0; k0 < K; k0 += 2)
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(A[r * lda + k0 + kk], B[(k0 + kk) * ldb + r], acc, 0, 0, 0);
+    for (int k1 = 0; k1 < K; k1 += 16) {                 // K is a multiple of 16; 8 steps' LDS reads in flight together
+        float av[8], bv[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) { av[u] = A[r * lda + k1 + 2 * u + kk]; bv[u] = B[(k1 + 2 * u + kk) * ldb + r]; }
+#pragma unroll
+        for (int u = 0; u < 8; u++) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u], bv[u], acc, 0, 0, 0);
+    }
     return acc;
 }
 __device__ __forceinline__ void lds_store32(float* C, int ldc, const floatx16p& acc, float scale, int lane) {
@@ -389,9 +393,10 @@ __device__ __forceinline__ void tri_inverse_128(float* Ss, const float* tdiag, f
 #pragma unroll
         for (int i = 0; i < 32; i++) {
             const float tii = tdiag[base + i];
-            float sum = 0.f;
+            float ps[4] = {0.f, 0.f, 0.f, 0.f};            // four partial sums: a quarter of the dependent chain
 #pragma unroll
-            for (int q = 0; q < i; q++) sum += tr[q] * Ss[(base + q) * TPS + base + i];
+            for (int q = 0; q < i; q++) ps[q & 3] += tr[q] * Ss[(base + q) * TPS + base + i];
+            const float sum = (ps[0] + ps[1]) + (ps[2] + ps[3]);
             tr[i] = (lane < i) ? -tii * sum : (lane == i ? tii : 0.f);
         }
 #pragma unroll
@@ -615,9 +620,9 @@ __global__ __launch_bounds__(GH_SOLVE_THREADS) void gh_solve_kernel(LeafArgs a, 
     // C = (D^-1 + W)^-1, columns of skipped reflectors zeroed
     tri_inverse_128(Ws, tdiag, Ts, (w + 31) / 32, tid);
     TSTAMP();
-    for (int e = tid; e < GW * GW; e += GH_SOLVE_THREADS) {
-        const int i = e >> 7, k = e & 127;
-        Cv[e] = (i <= k && k < w && cmask[k]) ? Ts[i * TPS + k] : 0.f;
+    for (int e = tid; e < GW * GW; e += GH_SOLVE_THREADS) {          // window coordinates (leaf index + off), zero elsewhere
+        const int i = (e >> 7) - off, k = (e & 127) - off;
+        Cv[e] = (i >= 0 && i <= k && k < w && cmask[k]) ? Ts[i * TPS + k] : 0.f;
     }
 #ifdef MPQR_SOLVE_TRACE
     if (trace && threadIdx.x == TRACE_TID) {
@@ -676,12 +681,11 @@ __global__ __launch_bounds__(256) void gh_apply_kernel(LeafArgs a, const float* 
         return;
     }
     const int row0 = a.c1 + blockIdx.x * 64;
-    const int off = a.c0 - a.cb, w = a.c1 - a.c0;
-    // C at window coordinates, zero outside the leaf and below the diagonal: one pass, no separate clear
-    for (int e = tid; e < GW * GW; e += 256) {
-        const int wi = e >> 7, wk = e & 127;               // window coordinates
-        const int i = wi - off, k = wk - off;
-        Cs[wi * GH_TS + wk] = (i >= 0 && k >= 0 && i < w && k < w && i <= k) ? Cv[i * GW + k] : 0.f;
+    // C arrives in window coordinates, zero outside the leaf and below the diagonal
+#pragma unroll
+    for (int q = 0; q < GW * GW / 4 / 256; q++) {
+        const int e4 = tid + 256 * q, wi = e4 >> 5, wk = (e4 & 31) * 4;
+        *(float4*)&Cs[wi * GH_TS + wk] = *(const float4*)&Cv[wi * GW + wk];
     }
 #pragma unroll
     for (int i = 0; i < 8; i++) {
@@ -697,11 +701,18 @@ __global__ __launch_bounds__(256) void gh_apply_kernel(LeafArgs a, const float* 
     for (int e = 0; e < 16; e++) { acc0[e] = 0.f; acc1[e] = 0.f; }
     const int n0 = 32 * wave, r = lane & 31, kk = lane >> 5;
     const int kend = min(GW, n0 + 32);                   // C is upper triangular: C[k][j] = 0 for k > j
-    for (int k0 = 0; k0 < kend; k0 += 2) {
-        const float a0 = As[r * 129 + k0 + kk], a1 = As[(32 + r) * 129 + k0 + kk];
-        const float b = Cs[(k0 + kk) * GH_TS + n0 + r];
-        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b, acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b, acc1, 0, 0, 0);
+    for (int k1 = 0; k1 < kend; k1 += 16) {              // kend is a multiple of 32; 8 steps' LDS reads in flight together
+        float a0[8], a1[8], b[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const int k = k1 + 2 * u + kk;
+            a0[u] = As[r * 129 + k]; a1[u] = As[(32 + r) * 129 + k]; b[u] = Cs[k * GH_TS + n0 + r];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[u], b[u], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[u], b[u], acc1, 0, 0, 0);
+        }
     }
     __syncthreads();                                     // As is dead: reuse as the transpose buffer
     const int gc = a.cb + n0 + r;
@@ -836,8 +847,61 @@ __global__ __launch_bounds__(1024) void t_panel_kernel(const float* __restrict__
         if (li >= 0 && li < w && lj >= li && lj < w) v = Ts[li * TPS + lj];
         T[(long)i * ldt + j] = v;
         Th[(long)i * ldt + j] = (half_t)v;
+    }
+    for (int e = tid; e < ldt * ldt; e += 1024) {          // T^T: consecutive lanes walk a column of T (odd LDS stride)
+        const int j = e / ldt, i = e % ldt;
+        const int li = i - off, lj = j - off;
+        float v = 0.f;
+        if (li >= 0 && li < w && lj >= li && lj < w) v = Ts[li * TPS + lj];
         Tth[(long)j * ldt + i] = (half_t)v;
     }
+}
+
+// T_LR = -T_L (S T_R) for two children of at most 128 reflectors each, one workgroup, products on the exact-f32 MFMA
+// out of LDS (S, T_R, then X = S T_R over S and T_L over T_R).  Replaces two small GEMM launches per merge.
+__global__ __launch_bounds__(1024) void t_merge_kernel(const float* __restrict__ S, int ldl, int ldr,
+                                                       const float* __restrict__ TL, const float* __restrict__ TR,
+                                                       float* __restrict__ TLR) {
+    float* Ss = (float*)gh_smem;             // [TP][TPS]: S, then X
+    float* Tr = Ss + TP * TPS;               // [TP][TPS]: T_R, then T_L
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+#pragma unroll
+    for (int q = 0; q < TP * TP / 1024; q++) {
+        const int e = tid + 1024 * q, i = e >> 7, j = e & 127;
+        Ss[i * TPS + j] = (i < ldl && j < ldr) ? S[(long)i * ldr + j] : 0.f;
+        Tr[i * TPS + j] = (i < ldr && j < ldr) ? TR[(long)i * ldr + j] : 0.f;
+    }
+    __syncthreads();
+    const int bi = wave >> 2, bj = wave & 3;
+    const bool has = 32 * bi < ldl && 32 * bj < ldr;
+    floatx16p acc;
+    if (has) acc = lds_mm32(&Ss[32 * bi * TPS], TPS, &Tr[32 * bj], TPS, ldr, lane);
+    __syncthreads();
+    if (has) lds_store32(&Ss[32 * bi * TPS + 32 * bj], TPS, acc, 1.f, lane);
+#pragma unroll
+    for (int q = 0; q < TP * TP / 1024; q++) {
+        const int e = tid + 1024 * q, i = e >> 7, j = e & 127;
+        Tr[i * TPS + j] = (i < ldl && j < ldl) ? TL[(long)i * ldl + j] : 0.f;
+    }
+    __syncthreads();
+    if (has) {
+        acc = lds_mm32(&Tr[32 * bi * TPS], TPS, &Ss[32 * bj], TPS, ldl, lane);
+        const int r = lane & 31, kk = lane >> 5;
+#pragma unroll
+        for (int e = 0; e < 16; e++) {
+            const int i = 32 * bi + (e & 3) + 8 * (e >> 2) + 4 * kk, j = 32 * bj + r;
+            if (i < ldl && j < ldr) TLR[(long)i * ldr + j] = -acc[e];
+        }
+    }
+}
+
+void launch_t_merge(const float* S, int ldl, int ldr, const float* TL, const float* TR, float* TLR, hipStream_t s) {
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute((const void*)t_merge_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * TP * TPS * 4);
+        attr = true;
+    }
+    hipLaunchKernelGGL(t_merge_kernel, dim3(1), dim3(1024), 2 * TP * TPS * 4, s, S, ldl, ldr, TL, TR, TLR);
 }
 
 void launch_t_leaf(const float* S, int nslab, long slab_stride, int lds_, int a0, int c0, int c1, float* T, half_t* Th,
@@ -869,7 +933,16 @@ __global__ __launch_bounds__(256) void t_assemble_kernel(float* __restrict__ T, 
     else if (iL && jR) v = TLR[(long)(gi - aL0) * ldlr + (gj - aR0)];
     T[(long)i * ldt + j] = v;
     Th[(long)i * ldt + j] = (half_t)v;
-    Tth[(long)j * ldt + i] = (half_t)v;
+    {   // T^T entry (i, j) = T[j][i]: the same thread index walks T^T row-major, so this store is coalesced too
+        const int gj2 = A0 + i, gi2 = A0 + j;             // T row gi2, column gj2
+        float u = 0.f;
+        const bool iL2 = gi2 >= c0 && gi2 < cm, jL2 = gj2 >= c0 && gj2 < cm;
+        const bool iR2 = gi2 >= cm && gi2 < c1, jR2 = gj2 >= cm && gj2 < c1;
+        if (iL2 && jL2) u = TL[(long)(gi2 - aL0) * ldl + (gj2 - aL0)];
+        else if (iR2 && jR2) u = TR[(long)(gi2 - aR0) * ldr + (gj2 - aR0)];
+        else if (iL2 && jR2) u = TLR[(long)(gi2 - aL0) * ldlr + (gj2 - aR0)];
+        Tth[(long)i * ldt + j] = (half_t)u;
+    }
 }
 
 void launch_t_assemble(float* T, half_t* Th, half_t* Tth, int ldt, int A0, const float* TL, int ldl, int aL0, int c0,
