@@ -283,6 +283,19 @@ __global__ __launch_bounds__(1024) void leaf_wg_kernel(LeafArgs a) {
 //   gh_apply   : V_low = A_low C on the exact-f32 MFMA, written over A_low, plus fp16 copies V and V^T
 // No pass over the tall data is sequential in k.  V differs from Householder's by O(2^-24 / sqrt(rho)); a leaf
 // with rho < GH_RHO_MIN raises a flag and the driver redoes the work on the column-by-column kernels above.
+// optional in-kernel phase timing (make EXTRA=-DMPQR_KTRACE): thread 0 of block 0 stamps s_memtime at phase
+// boundaries and prints the deltas for the first few launches of each kernel
+#ifdef MPQR_KTRACE
+__device__ int g_ktrace_left[8] = {3, 3, 3, 3, 3, 3, 3, 3};
+#define KT_DECL long kt_[16]; int kn_ = 0; const bool kon_ = (threadIdx.x == 0 && blockIdx.x == 0)
+#define KT() do { if (kon_ && kn_ < 16) kt_[kn_++] = clock64(); } while (0)
+#define KT_DUMP(id, name) do { if (kon_ && atomicSub(&g_ktrace_left[id], 1) > 0) { printf("ktrace %s:", name); \
+    for (int q_ = 1; q_ < kn_; q_++) printf(" %ld", kt_[q_] - kt_[q_ - 1]); printf("\n"); } } while (0)
+#else
+#define KT_DECL
+#define KT() do {} while (0)
+#define KT_DUMP(id, name) do {} while (0)
+#endif
 constexpr double GH_RHO_MIN = 1e-8;
 constexpr int GW = 128;          // window width
 constexpr int GH_TS = 132;       // LDS row stride (floats) of a staged 128-column tile
@@ -361,12 +374,13 @@ typedef float floatx16p __attribute__((ext_vector_type(16)));
 constexpr int TP = 128, TPS = 129;
 
 // 32 x 32 tile of A (32 x K, LDS) * B (K x 32, LDS) on the exact-f32 MFMA; odd row strides: conflict-free
-__device__ __forceinline__ floatx16p lds_mm32(const float* A, int lda, const float* B, int ldb, int K, int lane) {
+// k runs over [klo, khi), both multiples of 16 (callers skip the zero part of triangular factors)
+__device__ __forceinline__ floatx16p lds_mm32(const float* A, int lda, const float* B, int ldb, int klo, int khi, int lane) {
     const int r = lane & 31, kk = lane >> 5;
     floatx16p acc;
 #pragma unroll
     for (int e = 0; e < 16; e++) acc[e] = 0.f;
-    for (int k1 = 0; k1 < K; k1 += 16) {                 // K is a multiple of 16; 8 steps' LDS reads in flight together
+    for (int k1 = klo; k1 < khi; k1 += 16) {             // 8 steps' LDS reads in flight together
         float av[8], bv[8];
 #pragma unroll
         for (int u = 0; u < 8; u++) { av[u] = A[r * lda + k1 + 2 * u + kk]; bv[u] = B[(k1 + 2 * u + kk) * ldb + r]; }
@@ -409,12 +423,12 @@ __device__ __forceinline__ void tri_inverse_128(float* Ss, const float* tdiag, f
         const int p = wave / (ts * ts), t = wave % (ts * ts), bi = t / ts, bj = t % ts;
         const int L0 = p * 2 * half, R0 = L0 + half;
         floatx16p acc;
-        if (has) acc = lds_mm32(&Ss[(L0 + 32 * bi) * TPS + R0], TPS, &Ts[R0 * TPS + R0 + 32 * bj], TPS, half, lane);
+        if (has) acc = lds_mm32(&Ss[(L0 + 32 * bi) * TPS + R0], TPS, &Ts[R0 * TPS + R0 + 32 * bj], TPS, 0, 32 * (bj + 1), lane);   // T_R upper
         __syncthreads();
         if (has) lds_store32(&Ss[(L0 + 32 * bi) * TPS + R0 + 32 * bj], TPS, acc, 1.f, lane);
         __syncthreads();
         if (has) {
-            acc = lds_mm32(&Ts[(L0 + 32 * bi) * TPS + L0], TPS, &Ss[L0 * TPS + R0 + 32 * bj], TPS, half, lane);
+            acc = lds_mm32(&Ts[(L0 + 32 * bi) * TPS + L0], TPS, &Ss[L0 * TPS + R0 + 32 * bj], TPS, 32 * bi, half, lane);   // T_L upper
             lds_store32(&Ts[(L0 + 32 * bi) * TPS + R0 + 32 * bj], TPS, acc, -1.f, lane);
         }
         __syncthreads();
@@ -825,6 +839,7 @@ __global__ __launch_bounds__(1024) void t_panel_kernel(const float* __restrict__
     const int tid = threadIdx.x;
     const int w = c1 - c0, off = c0 - a0;
     const int nblk = (w + 31) / 32;          // active 32-blocks
+    KT_DECL; KT();
 #pragma unroll
     for (int q = 0; q < TP * TP / 1024; q++) {              // fully unrolled: the 16 loads of a thread are in flight together
         const int e = tid + 1024 * q;
@@ -839,7 +854,9 @@ __global__ __launch_bounds__(1024) void t_panel_kernel(const float* __restrict__
         Ts[i * TPS + j] = 0.f;
     }
     __syncthreads();
+    KT();
     tri_inverse_128(Ss, tdiag, Ts, nblk, tid);
+    KT();
     for (int e = tid; e < ldt * ldt; e += 1024) {
         const int i = e / ldt, j = e % ldt;
         const int li = i - off, lj = j - off;
@@ -855,6 +872,7 @@ __global__ __launch_bounds__(1024) void t_panel_kernel(const float* __restrict__
         if (li >= 0 && li < w && lj >= li && lj < w) v = Ts[li * TPS + lj];
         Tth[(long)j * ldt + i] = (half_t)v;
     }
+    KT(); KT_DUMP(1, "t_panel load|inverse|store");
 }
 
 // T_LR = -T_L (S T_R) for two children of at most 128 reflectors each, one workgroup, products on the exact-f32 MFMA
@@ -865,6 +883,7 @@ __global__ __launch_bounds__(1024) void t_merge_kernel(const float* __restrict__
     float* Ss = (float*)gh_smem;             // [TP][TPS]: S, then X
     float* Tr = Ss + TP * TPS;               // [TP][TPS]: T_R, then T_L
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    KT_DECL; KT();
 #pragma unroll
     for (int q = 0; q < TP * TP / 1024; q++) {
         const int e = tid + 1024 * q, i = e >> 7, j = e & 127;
@@ -872,10 +891,12 @@ __global__ __launch_bounds__(1024) void t_merge_kernel(const float* __restrict__
         Tr[i * TPS + j] = (i < ldr && j < ldr) ? TR[(long)i * ldr + j] : 0.f;
     }
     __syncthreads();
+    KT();
     const int bi = wave >> 2, bj = wave & 3;
     const bool has = 32 * bi < ldl && 32 * bj < ldr;
     floatx16p acc;
-    if (has) acc = lds_mm32(&Ss[32 * bi * TPS], TPS, &Tr[32 * bj], TPS, ldr, lane);
+    if (has) acc = lds_mm32(&Ss[32 * bi * TPS], TPS, &Tr[32 * bj], TPS, 0, min(ldr, 32 * (bj + 1)), lane);   // T_R upper
+    KT();
     __syncthreads();
     if (has) lds_store32(&Ss[32 * bi * TPS + 32 * bj], TPS, acc, 1.f, lane);
 #pragma unroll
@@ -884,8 +905,9 @@ __global__ __launch_bounds__(1024) void t_merge_kernel(const float* __restrict__
         Tr[i * TPS + j] = (i < ldl && j < ldl) ? TL[(long)i * ldl + j] : 0.f;
     }
     __syncthreads();
+    KT();
     if (has) {
-        acc = lds_mm32(&Tr[32 * bi * TPS], TPS, &Ss[32 * bj], TPS, ldl, lane);
+        acc = lds_mm32(&Tr[32 * bi * TPS], TPS, &Ss[32 * bj], TPS, 32 * bi, ldl, lane);                          // T_L upper
         const int r = lane & 31, kk = lane >> 5;
 #pragma unroll
         for (int e = 0; e < 16; e++) {
@@ -893,6 +915,7 @@ __global__ __launch_bounds__(1024) void t_merge_kernel(const float* __restrict__
             if (i < ldl && j < ldr) TLR[(long)i * ldr + j] = -acc[e];
         }
     }
+    KT(); KT_DUMP(0, "t_merge load|mm1|store+loadTL|mm2+out");
 }
 
 void launch_t_merge(const float* S, int ldl, int ldr, const float* TL, const float* TR, float* TLR, hipStream_t s) {
