@@ -22,7 +22,7 @@ typedef half_t half8 __attribute__((ext_vector_type(8)));
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 
 namespace g2 {
-struct alignas(16) U4 { uint32_t x, y, z, w; };
+typedef uint32_t U4 __attribute__((ext_vector_type(4)));   // first-class vector (register-resident staging arrays)
 
 __device__ __forceinline__ uint32_t pack2(float a, float b) {
     typedef half_t half2v __attribute__((ext_vector_type(2)));
@@ -73,8 +73,17 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm2_f16_kernel(GemmArgs g, int
     // ---- A staging through registers
     constexpr int NA = BM * CPR / NT;                  // 16-B chunks per thread (A_H16 / A_F32)
     constexpr int NBLK = (BK / 4) * (BM / 4) / NT;     // 4 x 4 fp32 blocks per thread (A_F32T)
+    typedef float F4 __attribute__((ext_vector_type(4)));   // first-class vectors: the loads land in their final registers
     U4 ra[NA];
-    float4 raT[NBLK * 4];
+    F4 raT[NBLK * 4];
+    // A_F32T: per-thread row pointers advance by BK rows per K tile (no 64-bit multiplies in the loop)
+    const float* pT[NBLK];
+#pragma unroll
+    for (int i = 0; i < NBLK; i++) {
+        const int id = tid + NT * i, mg = id % (BM / 4), kg = id / (BM / 4);
+        pT[i] = (const float*)g.A + (long)(kt0 * BK + kg * 4) * g.lda + bm + mg * 4;
+    }
+    const long ldaT = g.lda, stepT = (long)BK * g.lda;
     auto load_A = [&](int kt) {
         const int k = kt * BK;
         if (AM == A_H16) {
@@ -85,12 +94,11 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm2_f16_kernel(GemmArgs g, int
                 ra[i] = *(const U4*)(A + (long)(bm + row) * g.lda + k + kc * 8);
             }
         } else if (AM == A_F32T) {
-            const float* A = (const float*)g.A;
 #pragma unroll
             for (int i = 0; i < NBLK; i++) {
-                const int id = tid + NT * i, mg = id % (BM / 4), kg = id / (BM / 4);
 #pragma unroll
-                for (int j = 0; j < 4; j++) raT[i * 4 + j] = *(const float4*)(A + (long)(k + kg * 4 + j) * g.lda + bm + mg * 4);
+                for (int j = 0; j < 4; j++) raT[i * 4 + j] = *(const F4*)(pT[i] + j * ldaT);
+                pT[i] += stepT;                           // load_A is called once per K tile, in order
             }
         } else {
             const float* A = (const float*)g.A;
@@ -120,7 +128,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm2_f16_kernel(GemmArgs g, int
 #pragma unroll
             for (int i = 0; i < NBLK; i++) {
                 const int id = tid + NT * i, mg = id % (BM / 4), kg = id / (BM / 4);
-                const float4 v0 = raT[i * 4 + 0], v1 = raT[i * 4 + 1], v2 = raT[i * 4 + 2], v3 = raT[i * 4 + 3];
+                const F4 v0 = raT[i * 4 + 0], v1 = raT[i * 4 + 1], v2 = raT[i * 4 + 2], v3 = raT[i * 4 + 3];
                 const int half_off = (kg & 1) * 8, chunk = kg >> 1;
                 uint2 w;
                 w.x = pack2(v0.x * sc, v1.x * sc); w.y = pack2(v2.x * sc, v3.x * sc); *(uint2*)(As + swz(mg * 4 + 0, chunk) + half_off) = w;
