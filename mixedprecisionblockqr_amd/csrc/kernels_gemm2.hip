@@ -13,6 +13,7 @@
 //     swizzled image, issued before the MFMA block of the current tile and written after it;
 //   * blockIdx -> tile map walks 4 x 8 tile groups inside each XCD's share of the grid, so the 32 workgroups
 //     sharing an L2 reuse 4 A panels and 8 B panels instead of streaming them.
+#include <type_traits>
 #include "mpqr_internal.h"
 #include "gemm_epilogue.h"
 
@@ -75,7 +76,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm2_f16_kernel(GemmArgs g, int
     constexpr int NBLK = (BK / 4) * (BM / 4) / NT;     // 4 x 4 fp32 blocks per thread (A_F32T)
     typedef float F4 __attribute__((ext_vector_type(4)));   // first-class vectors: the loads land in their final registers
     U4 ra[NA];
-    F4 raT[NBLK * 4];
+    F4 raT[2][NBLK * 4];                                 // A_F32T: two register sets, loads run two K tiles ahead
     // A_F32T: per-thread row pointers advance by BK rows per K tile (no 64-bit multiplies in the loop)
     const float* pT[NBLK];
 #pragma unroll
@@ -94,12 +95,8 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm2_f16_kernel(GemmArgs g, int
                 ra[i] = *(const U4*)(A + (long)(bm + row) * g.lda + k + kc * 8);
             }
         } else if (AM == A_F32T) {
-#pragma unroll
-            for (int i = 0; i < NBLK; i++) {
-#pragma unroll
-                for (int j = 0; j < 4; j++) raT[i * 4 + j] = *(const F4*)(pT[i] + j * ldaT);
-                pT[i] += stepT;                           // load_A is called once per K tile, in order
-            }
+            (void)k;                                      // handled by load_AT below
+
         } else {
             const float* A = (const float*)g.A;
             const float sc = g.in_scale;
@@ -121,21 +118,34 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm2_f16_kernel(GemmArgs g, int
             }
         }
     };
+    auto load_AT = [&](auto set) {                       // next K tile of the fp32 operand into register set `set`
+        constexpr int S = decltype(set)::value;
+#pragma unroll
+        for (int i = 0; i < NBLK; i++) {
+#pragma unroll
+            for (int j = 0; j < 4; j++) raT[S][i * 4 + j] = *(const F4*)(pT[i] + j * ldaT);
+            pT[i] += stepT;                               // called once per K tile, in order
+        }
+    };
+    auto store_AT = [&](auto set, int stage) {           // convert + transpose register set `set` into LDS stage `stage`
+        constexpr int S = decltype(set)::value;
+        char* As = As0 + stage * STAGE;
+        const float sc = g.in_scale;
+#pragma unroll
+        for (int i = 0; i < NBLK; i++) {
+            const int id = tid + NT * i, mg = id % (BM / 4), kg = id / (BM / 4);
+            const F4 v0 = raT[S][i * 4 + 0], v1 = raT[S][i * 4 + 1], v2 = raT[S][i * 4 + 2], v3 = raT[S][i * 4 + 3];
+            const int half_off = (kg & 1) * 8, chunk = kg >> 1;
+            uint2 w;
+            w.x = pack2(v0.x * sc, v1.x * sc); w.y = pack2(v2.x * sc, v3.x * sc); *(uint2*)(As + swz(mg * 4 + 0, chunk) + half_off) = w;
+            w.x = pack2(v0.y * sc, v1.y * sc); w.y = pack2(v2.y * sc, v3.y * sc); *(uint2*)(As + swz(mg * 4 + 1, chunk) + half_off) = w;
+            w.x = pack2(v0.z * sc, v1.z * sc); w.y = pack2(v2.z * sc, v3.z * sc); *(uint2*)(As + swz(mg * 4 + 2, chunk) + half_off) = w;
+            w.x = pack2(v0.w * sc, v1.w * sc); w.y = pack2(v2.w * sc, v3.w * sc); *(uint2*)(As + swz(mg * 4 + 3, chunk) + half_off) = w;
+        }
+    };
     auto store_A = [&](int stage) {
         char* As = As0 + stage * STAGE;
         if (AM == A_F32T) {
-            const float sc = g.in_scale;
-#pragma unroll
-            for (int i = 0; i < NBLK; i++) {
-                const int id = tid + NT * i, mg = id % (BM / 4), kg = id / (BM / 4);
-                const F4 v0 = raT[i * 4 + 0], v1 = raT[i * 4 + 1], v2 = raT[i * 4 + 2], v3 = raT[i * 4 + 3];
-                const int half_off = (kg & 1) * 8, chunk = kg >> 1;
-                uint2 w;
-                w.x = pack2(v0.x * sc, v1.x * sc); w.y = pack2(v2.x * sc, v3.x * sc); *(uint2*)(As + swz(mg * 4 + 0, chunk) + half_off) = w;
-                w.x = pack2(v0.y * sc, v1.y * sc); w.y = pack2(v2.y * sc, v3.y * sc); *(uint2*)(As + swz(mg * 4 + 1, chunk) + half_off) = w;
-                w.x = pack2(v0.z * sc, v1.z * sc); w.y = pack2(v2.z * sc, v3.z * sc); *(uint2*)(As + swz(mg * 4 + 2, chunk) + half_off) = w;
-                w.x = pack2(v0.w * sc, v1.w * sc); w.y = pack2(v2.w * sc, v3.w * sc); *(uint2*)(As + swz(mg * 4 + 3, chunk) + half_off) = w;
-            }
         } else {
 #pragma unroll
             for (int i = 0; i < NA; i++) {
@@ -172,17 +182,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm2_f16_kernel(GemmArgs g, int
 
     const int wm = (wave / WN) * 128, wn = (wave % WN) * 64;
 
-    if (kt0 < kt1) {
-        stage_B(kt0 & 1, kt0);
-        load_A(kt0);
-        store_A(kt0 & 1);
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    for (int kt = kt0; kt < kt1; kt++) {
-        const int cur = kt & 1;
-        const bool more = kt + 1 < kt1;
-        if (more) { stage_B(cur ^ 1, kt + 1); load_A(kt + 1); }
+    auto mma_tile = [&](int cur) {
         const char* As = As0 + cur * STAGE;
         const char* Bs = Bs0 + cur * STAGE;
 #pragma unroll
@@ -198,9 +198,52 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm2_f16_kernel(GemmArgs g, int
                 for (int j = 0; j < 2; j++)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i], b[j], acc[i][j], 0, 0, 0);
         }
-        if (more) store_A(cur ^ 1);          // the other stage was last read one iteration ago (barrier below)
+    };
+    if (AM == A_F32T) {
+        // fp32 operand: HBM latency is longer than one K tile of MFMA work, so its loads run TWO tiles ahead (two
+        // register sets); the fp16 operand's LDS-DMA runs one tile ahead.  vmcnt retires in issue order:
+        // [A(kt+1)] [B(kt+1)] [A(kt+2)] -- the barrier needs B(kt+1) only.
+        std::integral_constant<int, 0> S0; std::integral_constant<int, 1> S1;
+        if (kt0 < kt1) {
+            stage_B(kt0 & 1, kt0);
+            load_AT(S0);
+            if (kt0 + 1 < kt1) load_AT(S1);
+            store_AT(S0, kt0 & 1);
+        }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
+        auto step = [&](auto setp, auto setq, int kt) {    // set p held tile kt (already in LDS), set q holds tile kt+1
+            const int cur = kt & 1;
+            const bool more = kt + 1 < kt1, more2 = kt + 2 < kt1;
+            if (more) stage_B(cur ^ 1, kt + 1);
+            if (more2) load_AT(setp);
+            mma_tile(cur);
+            if (more) store_AT(setq, cur ^ 1);
+            if (more2) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NBLK * 4) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+        };
+        for (int kt = kt0; kt < kt1; kt += 2) {
+            step(S0, S1, kt);
+            if (kt + 1 < kt1) step(S1, S0, kt + 1);
+        }
+    } else {
+        if (kt0 < kt1) {
+            stage_B(kt0 & 1, kt0);
+            load_A(kt0);
+            store_A(kt0 & 1);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        for (int kt = kt0; kt < kt1; kt++) {
+            const int cur = kt & 1;
+            const bool more = kt + 1 < kt1;
+            if (more) { stage_B(cur ^ 1, kt + 1); load_A(kt + 1); }
+            mma_tile(cur);
+            if (more) store_A(cur ^ 1);          // the other stage was last read one iteration ago (barrier below)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+        }
     }
 
     const float alpha = g.alpha;

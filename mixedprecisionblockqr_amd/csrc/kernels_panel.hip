@@ -607,24 +607,57 @@ __global__ __launch_bounds__(GH_SOLVE_THREADS) void gh_solve_kernel(LeafArgs a, 
     if (!upd) __builtin_amdgcn_s_setprio(0);
     TSTAMP();
     // R and the top block of V go out first (from the LDS columns): the stores drain while the inverse below runs
-    for (int e = tid; e < GW * GW; e += GH_SOLVE_THREADS) {
-        const int i = e >> 7, k = e & 127;                 // k fastest: rows of A and Vh
-        if (i < w && k < w) {
-            const float v = Ts[k * TPS + i];
-            a.A[(long)(a.c0 + i) * a.lda + a.c0 + k] = v;
-            if (i > k) a.Vh[(long)(a.c0 + i) * a.ldvh + a.c0 + k] = (half_t)v;
+    if ((w & 7) == 0 && (a.c0 & 7) == 0) {                 // usual case: 16-byte stores (8 fp16 / 4 fp32 per thread)
+        typedef half_t half4v __attribute__((ext_vector_type(4)));
+        typedef half_t half8v __attribute__((ext_vector_type(8)));
+        for (int e = tid; e < GW * (GW / 4); e += GH_SOLVE_THREADS) {
+            const int i = e >> 5, k = (e & 31) * 4;           // 4 consecutive k: a row segment of A and Vh
+            if (i < w && k < w) {
+                float4 v; half4v hv;
+                v.x = Ts[(k + 0) * TPS + i]; v.y = Ts[(k + 1) * TPS + i]; v.z = Ts[(k + 2) * TPS + i]; v.w = Ts[(k + 3) * TPS + i];
+                *(float4*)&a.A[(long)(a.c0 + i) * a.lda + a.c0 + k] = v;
+                if (i >= k) {                                 // V: below the diagonal from the columns, v_kk on it, zero above
+                    const float vd = vdl[i];
+                    hv[0] = i > k ? (half_t)v.x : (half_t)vd;
+                    hv[1] = i > k + 1 ? (half_t)v.y : (i == k + 1 ? (half_t)vd : (half_t)0.f);
+                    hv[2] = i > k + 2 ? (half_t)v.z : (i == k + 2 ? (half_t)vd : (half_t)0.f);
+                    hv[3] = i > k + 3 ? (half_t)v.w : (i == k + 3 ? (half_t)vd : (half_t)0.f);
+                    *(half4v*)&a.Vh[(long)(a.c0 + i) * a.ldvh + a.c0 + k] = hv;
+                }
+            }
         }
-    }
-    for (int e = tid; e < GW * GW; e += GH_SOLVE_THREADS) {
-        const int k = e >> 7, i = e & 127;                 // i fastest: rows of V^T
-        if (i < w && k < w && i > k) a.Vt[(long)(a.c0 + k) * a.ldvt + a.c0 + i] = (half_t)Ts[k * TPS + i];
+        for (int e = tid; e < GW * (GW / 8); e += GH_SOLVE_THREADS) {
+            const int k = e >> 4, i = (e & 15) * 8;           // 8 consecutive i: a row segment of V^T
+            if (k < w && i < w && i + 7 >= k) {
+                half8v hv;
+                const float vd = vdl[k];
+#pragma unroll
+                for (int q = 0; q < 8; q++) hv[q] = (i + q > k) ? (half_t)Ts[k * TPS + i + q] : (i + q == k ? (half_t)vd : (half_t)0.f);
+                *(half8v*)&a.Vt[(long)(a.c0 + k) * a.ldvt + a.c0 + i] = hv;
+            }
+        }
+    } else {
+        for (int e = tid; e < GW * GW; e += GH_SOLVE_THREADS) {
+            const int i = e >> 7, k = e & 127;                 // k fastest: rows of A and Vh
+            if (i < w && k < w) {
+                const float v = Ts[k * TPS + i];
+                a.A[(long)(a.c0 + i) * a.lda + a.c0 + k] = v;
+                if (i > k) a.Vh[(long)(a.c0 + i) * a.ldvh + a.c0 + k] = (half_t)v;
+            }
+        }
+        for (int e = tid; e < GW * GW; e += GH_SOLVE_THREADS) {
+            const int k = e >> 7, i = e & 127;                 // i fastest: rows of V^T
+            if (i < w && k < w && i > k) a.Vt[(long)(a.c0 + k) * a.ldvt + a.c0 + i] = (half_t)Ts[k * TPS + i];
+        }
     }
     if (tid < w) {
         const int k = a.c0 + tid;
         const float vd = vdl[tid];
         a.vdiag[k] = vd;
-        a.Vh[(long)k * a.ldvh + k] = (half_t)vd;
-        a.Vt[(long)k * a.ldvt + k] = (half_t)vd;
+        if (!((w & 7) == 0 && (a.c0 & 7) == 0)) {          // the vector path above wrote the diagonal already
+            a.Vh[(long)k * a.ldvh + k] = (half_t)vd;
+            a.Vt[(long)k * a.ldvt + k] = (half_t)vd;
+        }
     }
     if (tid == 0 && lflag) atomicOr(flag, 1);
     __syncthreads();
