@@ -456,7 +456,9 @@ hipError_t create_update_stream(hipStream_t* st, int prio) {
     const char* e = getenv("MPQR_UPDATE_CU_MASK");
     if (e && atoi(e) == 0) return hipStreamCreateWithPriority(st, hipStreamNonBlocking, prio);
     uint32_t mask[8];
-    for (int i = 0; i < 8; i++) mask[i] = 0xEEEEEEEEu;      // CU i enabled unless i % 4 == 0
+    uint32_t pat = 0xEEEEEEEEu;                              // CU i enabled unless i % 4 == 0
+    if (e && strlen(e) > 2 && e[0] == '0' && (e[1] == 'x' || e[1] == 'X')) pat = (uint32_t)strtoul(e, nullptr, 16);
+    for (int i = 0; i < 8; i++) mask[i] = pat;
     hipError_t rc = hipExtStreamCreateWithCUMask(st, 8, mask);
     if (rc != hipSuccess) rc = hipStreamCreateWithPriority(st, hipStreamNonBlocking, prio);
     return rc;

@@ -1,0 +1,26 @@
+#!/bin/bash
+# Collects everything profiles/ holds for one round, on the GPU box:  bash tools/collect_profiles.sh <tag>
+# (kernel stats, HBM counters in two separate PMC passes, SQ stall counters, bench lines).  Outputs: gpurun_out/final/
+tag=${1:-r01}
+root=${GRAFT_REPO_ROOT:-/root/repo}
+out=$root/gpurun_out/final
+mkdir -p $out
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 --kernel-trace --stats -d $out/ks -o c4 --output-format csv -- python3 $root/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $out/ks.log 2>&1 && echo "kernel stats ok"
+rocprofv3 --pmc FETCH_SIZE -d $out/fetch -o c4 --output-format csv -- python3 $root/bench.py --steps 1 --warmup 0 --no-cpu-baseline > $out/fetch.log 2>&1 && echo "fetch ok"
+rocprofv3 --pmc WRITE_SIZE -d $out/write -o c4 --output-format csv -- python3 $root/bench.py --steps 1 --warmup 0 --no-cpu-baseline > $out/write.log 2>&1 && echo "write ok"
+cd $root
+bash tools/pmc_sq.sh c4 > $out/${tag}_c4_sq_stalls.txt 2>&1 && echo "sq ok"
+cp $(find $out/ks -name "c4_kernel_stats.csv" | head -1) $out/${tag}_c4_kernel_stats.csv
+python3 tools/trace_gaps.py $(find $out/ks -name "c4_kernel_trace.csv" | head -1) > $out/${tag}_c4_stream_gaps.txt
+F=$(find $out/fetch -name "c4_counter_collection.csv" | head -1); W=$(find $out/write -name "c4_counter_collection.csv" | head -1)
+grep -E "Kernel_Name|gemm3_f16|gemm2_f16" $F > $out/${tag}_c4_pmc_FETCH_SIZE_gemm.csv
+grep -E "Kernel_Name|gemm3_f16|gemm2_f16" $W > $out/${tag}_c4_pmc_WRITE_SIZE_gemm.csv
+python3 tools/pmc_traffic.py $F $W "gemm3_f16_kernel<2>" $out/${tag}_traffic_far_nn.json > /dev/null
+python3 tools/pmc_traffic.py $F $W "gemm2_f16_kernel<1, 0" $out/${tag}_traffic_far_tn.json > /dev/null
+cp $out/${tag}_traffic_far_nn.json profiles/${tag}_traffic_far_nn.json        # bench.py reads roofline.traffic from here
+python3 bench.py > $out/${tag}_c4_bench.json 2> $out/bench_c4.err && echo "bench c4 ok"
+python3 bench.py --config c2 --no-cpu-baseline > $out/${tag}_c2_bench.json 2> $out/bench_c2.err && echo "bench c2 ok"
+python3 bench.py --config c5 --no-cpu-baseline --steps 3 --warmup 1 > $out/${tag}_c5_bench.json 2> $out/bench_c5.err && echo "bench c5 ok"
+rm -rf $out/ks $out/fetch $out/write
+ls -la $out
