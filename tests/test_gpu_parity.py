@@ -177,6 +177,22 @@ def test_oracle_sized_block_compare_1536x768(mp, h, po):
     assert mt["backward_error"] <= 1e-3 and mt["q_error_fro"] <= 2e-3 * np.sqrt(m)
 
 
+@pytest.mark.parametrize("m,n,r", [(700, 333, 32), (1500, 250, 64), (1100, 1030, 128), (2300, 1157, 128)])
+def test_ragged_tall_leaves_match_oracle(mp, h, po, m, n, r):
+    """Tall (Gram-Householder) leaves whose width is not a multiple of 8 or 32, a partial last leaf / last 1024-column
+    block: element-level agreement with the oracle's compact-WY block loop plus the reference's three criteria."""
+    A = po.generate(m, n, seed=4321)
+    Ao, Q, R = run_gpu(mp, h, A, r)
+    A0, Q0, R0 = po.block_qr(A, r, "compact32", omp=True)
+    assert np.isfinite(Ao).all() and np.isfinite(Q).all()
+    assert relF(R, R0) <= 3e-3 and relF(Q, Q0) <= 5e-3, (relF(R, R0), relF(Q, Q0))
+    V = po.extract_V(Ao, m, n, 0, n); V0 = po.extract_V(A0, m, n, 0, n)
+    assert relF(V, V0) <= 5e-3, relF(V, V0)
+    mt = mp.qr_metrics(A, R, Q, handle=h)
+    assert mt["backward_error"] <= 1e-3 and mt["q_error_fro"] <= 2e-3 * np.sqrt(m), mt
+    assert np.all(R[np.tril_indices(n, -1)[0], np.tril_indices(n, -1)[1]] == 0)
+
+
 def test_ill_conditioned_tall_leaf_falls_back(mp, h, po):
     """A tall panel with (nearly) dependent columns must not be trusted to the Gram-Householder leaf: the driver
     detects it (rho flag) and redoes the factorisation on the column-by-column kernels.  Either way A = QR."""
