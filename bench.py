@@ -22,7 +22,8 @@ sys.path.insert(0, ROOT)
 CONFIGS = {  # name: (m, n, r)
     "c1": (256, 256, 32), "c2": (2048, 2048, 64), "c4": (16384, 16384, 128), "c5": (65536, 8192, 256),
 }
-PEAK_FP16_TFLOPS = 2500.0      # MI355X dense fp16 MFMA (MI355X_MICROARCH.md, chip-level parameters)
+PEAK_FP16_TFLOPS = 2500.0   # MI355X dense fp16 MFMA (MI355X_MICROARCH.md, chip-level parameters)
+PEAK_HBM_GBPS = 8000.0      # HBM3E, same table
 
 
 def cpu_baseline(budget_s=20.0):
@@ -112,6 +113,19 @@ def main():
                 "traffic": _pmc_traffic(), "launches": tm["n_far_launches"],
                 "avg_launch_ms": tm["ms_far_nn"] / tm["n_far_launches"],
                 "tn_achieved": (tm["flops_far_tn"] / (tm["ms_far_tn"] * 1e-3) / 1e12) if tm["ms_far_tn"] > 0 else None}
+        # The same launches against the HBM roof: algorithmic bytes = fp32 C read + write (8 M N) + both fp16 operands once
+        # (2 K (M + N)), summed over the schedule's far updates (block t updates the next block, then the rest).
+        K = args.outer_block or 1024
+        nblk = (n + K - 1) // K
+        alg = 0.0
+        for t in range(nblk - 1):
+            W = m - t * K
+            for N in (min(K, n - (t + 1) * K), n - (t + 2) * K):
+                if N > 0:
+                    alg += 8.0 * W * N + 2.0 * K * (W + N)
+        roof["hbm_view"] = {"algorithmic_bytes": alg, "achieved": alg / nn_t / 1e9, "peak": PEAK_HBM_GBPS, "unit": "GB/s",
+                            "frac": alg / nn_t / 1e9 / PEAK_HBM_GBPS, "flop_per_byte": tm["flops_far_nn"] / alg,
+                            "ridge_flop_per_byte": PEAK_FP16_TFLOPS * 1e3 / PEAK_HBM_GBPS}
     out = {
         "metric": "GFLOP/s block QR (fp16 MFMA trailing)", "value": fl["geqrf"] / dt / 1e9, "unit": "GFLOP/s",
         "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt * 1e3,

@@ -389,6 +389,131 @@ __global__ __launch_bounds__(512) void gemm3_f16_kernel(GemmArgs g, int tilesM, 
         }
 }
 
+// gemm4: the same all-DMA pipeline with a 256 x 128 x 32 tile, 256 threads (2 x 2 waves of 128 x 64) and a ring of
+// THREE stages (72 KiB), so that TWO workgroups live on a CU.  The read-modify-write epilogue of C -= V Y^T is a
+// memory phase (HBM round trips, MFMA idle) that takes about as long as the K loop at K = 1024; with one workgroup
+// per CU the two cannot overlap, with two independent workgroups one tile's epilogue runs under the other's K loop.
+template <int EM>
+__global__ __launch_bounds__(256, 2) void gemm4_f16_kernel(GemmArgs g, int tilesM, int tilesN) {
+    using namespace g2;
+    constexpr int BM = 256, BN = 128, BK = 32, NS = 3;
+    constexpr int ROWB = 64, CPR = 4, RB = 4;
+    constexpr int A_BYTES = BM * ROWB, B_BYTES = BN * ROWB, STAGE = A_BYTES + B_BYTES;
+    auto swz = [](int r, int c) -> int { return r * ROWB + ((c ^ ((r / RB) & (CPR - 1))) << 4); };
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int nwg = gridDim.x, bid = blockIdx.x;
+    const int q = nwg / 8, rem = nwg % 8, xcd = bid % 8;
+    const int seq = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + bid / 8;
+    // 64 concurrent tiles per XCD (two per CU): groups of 4 x 16 tiles = 1024 rows x 2048 columns share an L2
+    const int groupsN = (tilesN + 15) / 16;
+    const int grp = seq / 64, within = seq % 64;
+    const int tm = (grp / groupsN) * 4 + within / 16;
+    const int tn = (grp % groupsN) * 16 + within % 16;
+    if (tm >= tilesM || tn >= tilesN) return;
+    const int bm = tm * BM, bn = tn * BN;
+    const int ktiles = g.K / BK;
+    const half_t* const A = (const half_t*)g.A;
+
+    // one wave-instruction fills 1 KiB = 16 rows; A: 16 of them (4 per wave), B: 8 (2 per wave)
+    auto issue = [&](int kt) {                              // kt past the end re-fetches the last tile into a free stage
+        char* base = g2_smem + (kt % NS) * STAGE;
+        const int k = min(kt, ktiles - 1) * BK;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int rb = (i * 4 + wave) * 16;
+            const int rr = rb + (lane >> 2);
+            const int c = (lane & 3) ^ ((rr >> 2) & 3);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(A + (long)(bm + rr) * g.lda + k + c * 8),
+                                             (__attribute__((address_space(3))) void*)(base + rb * ROWB), 16, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < 2; i++) {
+            const int rb = (i * 4 + wave) * 16;
+            const int rr = rb + (lane >> 2);
+            const int c = (lane & 3) ^ ((rr >> 2) & 3);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g.Bt + (long)(bn + rr) * g.ldb + k + c * 8),
+                                             (__attribute__((address_space(3))) void*)(base + A_BYTES + rb * ROWB), 16, 0, 0);
+        }
+    };
+
+    floatx16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++)
+#pragma unroll
+            for (int e = 0; e < 16; e++) acc[i][j][e] = 0.f;
+    const int wm = (wave >> 1) * 128, wn = (wave & 1) * 64;
+
+    issue(0); issue(1);
+    for (int kt = 0; kt < ktiles; kt++) {
+        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");     // exactly two tiles (6 DMAs each) are in flight: kt has landed
+        __builtin_amdgcn_s_barrier();                        // tile kt landed everywhere; stage (kt-1)%3 is free
+        const char* As = g2_smem + (kt % NS) * STAGE;
+        const char* Bs = As + A_BYTES;
+        half8 a[2][4], b[2][2];
+#pragma unroll
+        for (int ks = 0; ks < 2; ks++) {
+#pragma unroll
+            for (int i = 0; i < 4; i++) a[ks][i] = *(const half8*)(As + swz(wm + i * 32 + r, ks * 2 + h));
+#pragma unroll
+            for (int j = 0; j < 2; j++) b[ks][j] = *(const half8*)(Bs + swz(wn + j * 32 + r, ks * 2 + h));
+        }
+        issue(kt + 2);                                       // unconditional: keeps the loop body one basic block
+#pragma unroll
+        for (int ks = 0; ks < 2; ks++)
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+#pragma unroll
+                for (int j = 0; j < 2; j++)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[ks][i], b[ks][j], acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 12, 0);
+        // issue order: the 12 fragment reads, then one LDS-DMA after every 2-3 MFMAs (6 DMAs, 16 MFMAs)
+#pragma unroll
+        for (int q2 = 0; q2 < 4; q2++) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+        }
+#pragma unroll
+        for (int q2 = 0; q2 < 2; q2++) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // the two trailing (redundant) tiles
+    __builtin_amdgcn_s_barrier();
+    const float alpha = g.alpha;
+    if (EM == E_SUB_F32) {
+        epilogue_sub_f32<4, 2>(acc, (float*)g.C, g.ldc, g.M, g.N, g.col_lo, alpha, bm + wm, bn + wn, r, h);
+        return;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+            const int n = bn + wn + j * 32 + r;
+#pragma unroll
+            for (int e = 0; e < 16; e++) {
+                const int m = bm + wm + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+                if (m < g.M && n < g.N) ((float*)g.C)[(long)m * g.ldc + n] = alpha * acc[i][j][e];
+            }
+        }
+}
+
+template <int EM>
+static void launch4(const GemmArgs& g, hipStream_t s) {
+    constexpr int LDS = 3 * (256 + 128) * 64;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)gemm4_f16_kernel<EM>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        attr_set = true;
+    }
+    const int tilesM = (g.M + 255) / 256, tilesN = (g.N + 127) / 128;
+    const int groups = ((tilesM + 3) / 4) * ((tilesN + 15) / 16);
+    hipLaunchKernelGGL((gemm4_f16_kernel<EM>), dim3(groups * 64), dim3(256), LDS, s, g, tilesM, tilesN);
+}
+
 template <int EM>
 static void launch3(const GemmArgs& g, hipStream_t s) {
     constexpr int LDS = 4 * 2 * 256 * 64;
@@ -407,6 +532,8 @@ static void launch3(const GemmArgs& g, hipStream_t s) {
 // only feed outputs that the epilogue masks).  config: 0 = 256x256x64 / 512 threads, 1 = 256x128x32 / 256 threads.
 bool launch_gemm2_f16(AMode am, EMode em, const GemmArgs& g, hipStream_t s, int config) {
     if (am == A_H16 && config != 2 && config != 1) {          // config 2 keeps the register-staged kernel (A/B comparison)
+        static const int use4 = []() { const char* e = getenv("MPQR_GEMM4"); return e ? atoi(e) : 0; }();
+        if (em == E_SUB_F32 && use4) { launch4<E_SUB_F32>(g, s); return true; }
         if (em == E_SUB_F32) { launch3<E_SUB_F32>(g, s); return true; }
         if (em == E_STORE_F32) { launch3<E_STORE_F32>(g, s); return true; }
     }
