@@ -435,19 +435,24 @@ __device__ __forceinline__ void tri_inverse_128(float* Ss, const float* tdiag, f
     }
 }
 
-// 640 threads.  Waves 0-7 ("update", a 16 x 32 grid): thread (ti,tj) keeps the CYCLIC entries {ti + 16x} x {tj + 32y},
+// 768 threads.  Waves 0-7 ("update", a 16 x 32 grid): thread (ti,tj) keeps the CYCLIC entries {ti + 16x} x {tj + 32y},
 // x < 8, y < 4, of B_top (fp32) and of N (fp64) in registers.  N is symmetric and only rows <= columns are ever
-// read, so the 16 x 32 blocks entirely below the diagonal (x > 2y+1) are not kept: 20 of 32.  Waves 8-9 ("scalar")
-// own no entries.  With u = column k over the remaining rows:  s_j = N[k][j],  w_j = 2 (s_j + alpha B[k][j]) inv,
-// v_top[t] = (B[t][k] + [t==k] alpha) inv.  H is orthogonal, so the Gram matrix of the reflected columns over the
-// same rows is unchanged; only the now-final row k (a row of R) leaves the set:  N'_ij = N_ij - R[k][i] R[k][j].
-// The loop is software-pipelined with ONE barrier per reflector.  Iteration t:
-//   scalar waves: take row/column t as published one iteration earlier (state after step t-2), apply step t-1 to
-//             just those entries (same FMAs as the update), run the fp64 scalar chain, write the vectors of step t
-//             and the final column t of the top block (R above the diagonal, R_tt, v below) to LDS;
-//   update waves: apply step t-1 to their entries (straight-line: vectors are zero where nothing changes), then
-//             the owners publish row/column t+1.
-// Neither side waits for the other inside an iteration.
+// read, so the 16 x 32 blocks entirely below the diagonal (x > 2y+1) are not kept: 20 of 32.
+//
+// The recursion splits into two chains that only meet in one direction.  With u = column k over the remaining rows,
+// s_j = N[k][j]:  the now-final row k of R leaves the set of remaining rows, N' = N - R[k] (x) R[k], and
+// R[k][j] = -sgn(u0) N[k][j] / sqrt(N[k][k]).  The sign drops out of the outer product, so N follows a plain
+// CHOLESKY recursion  c_k = N[k][:] / sqrt(N[k][k]),  N' = N - c_k (x) c_k  that never looks at B (fp64: this is
+// where cond(A)^2 lives).  The HOUSEHOLDER part -- u0 = B[k][k], nu = c_kk, alpha = sgn(u0) nu,
+// inv = 1/||u|| = rsqrt(2 nu (nu + |u0|)),  w_j = 2 nu (c_kj + sgn(u0) B[k][j]) inv,  v_top[i] = (B[i][k] + [i==k] alpha) inv,
+// B' = B - v_top (x) w -- needs c_k but is sums of like-signed terms and runs in fp32 like the reference's panel.
+// So: waves 8-9 run the Cholesky chain one step AHEAD, waves 10-11 the Householder chain, waves 0-7 apply both
+// rank-1 updates to their blocks; one barrier per reflector, nobody waits for anybody inside an iteration.  Rows and
+// columns the scalar waves need are published by their owners one iteration earlier (one step behind) and brought up
+// to date by the scalar waves themselves with the very FMAs the owners execute.  Step vectors are also stored in the
+// two permuted orders in which the update threads read them (16-byte LDS reads).
+// A column that cannot be reflected (N[k][k] <= 0: exactly zero or cancelled) raises the flag: the driver redoes the
+// work on the column-by-column kernels, which implement the reference's zero-column skip.
 // The coefficient matrix (V_low = A_low C) needs no update in the loop: with M the running column map,
 // C[:,k] = M[:,k] inv_k and M[:,j] = e_j - sum_{k<j} C[:,k] w^(k)_j, i.e. C (D^-1 + W) = I with W[k][j] = w^(k)_j
 // strictly upper and D = diag(inv): one triangular inverse after the loop (MFMA merges, tri_inverse_128).
@@ -455,27 +460,28 @@ __device__ __forceinline__ void tri_inverse_128(float* Ss, const float* tdiag, f
 #define TRACE_TID 0
 #endif
 constexpr int SR = 8, SC = 4;
-constexpr int GH_UPD_THREADS = 512, GH_SOLVE_THREADS = 640;
-struct GhVec { double rk[GW]; float w[GW], vt[GW]; };               // vectors of one step
-struct GhPre { double N[GW]; float B[GW], C[GW]; };                 // row t of N, B and column t of B, one step behind
+constexpr int GH_UPD_THREADS = 512, GH_SOLVE_THREADS = 768;
+struct GhVecA { double c[GW], c1[GW], c2[GW]; };                    // Cholesky row: natural, by-column-block, by-row-block order
+struct GhVecB { float w[GW], w1[GW], vt[GW], vt2[GW]; };           // Householder w (natural, by column block), v_top (natural, by row block)
+struct GhPreN { double N[GW]; };                                    // a row of N, one step behind
+struct GhPreB { float B[GW], C[GW]; };                              // a row and a column of B, one step behind
+__device__ __forceinline__ int gh_p1(int i) { return (i & 31) * 4 + (i >> 5); }   // thread tj reads entries tj + 32y contiguously
+__device__ __forceinline__ int gh_p2(int i) { return (i & 15) * 8 + (i >> 4); }   // thread ti reads entries ti + 16x contiguously
 __global__ __launch_bounds__(GH_SOLVE_THREADS) void gh_solve_kernel(LeafArgs a, const double* __restrict__ G,
                                                                     float* __restrict__ Cv, int* __restrict__ flag, int trace) {
-#ifdef MPQR_SOLVE_TRACE
-    long tq[24]; int nt = 0;
-#define TSTAMP() do { if (trace && threadIdx.x == TRACE_TID) tq[nt++] = clock64(); } while (0)
-#else
-#define TSTAMP() do {} while (0)
-#endif
-    TSTAMP();
+    (void)trace;
     float* Ws = (float*)gh_smem;                          // [TP][TPS]: row k = w^(k)
     float* Ts = Ws + TP * TPS;                            // [TP][TPS]: final columns of the top block, then the inverse
-    __shared__ double col0[GW];
-    __shared__ float vdl[GW], tdiag[GW];
-    __shared__ GhVec vec[2];
-    __shared__ GhPre pre[2];
+    __shared__ double col0[GW], nuv[GW];
+    __shared__ float vdl[GW], tdiag[GW], sgn[GW];
+    __shared__ GhVecA vecA[2];
+    __shared__ GhVecB vecB[2];
+    __shared__ GhPreN preN[2];
+    __shared__ GhPreB preB[2];
     __shared__ int lflag, cmask[GW];
     const int tid = threadIdx.x;
     const bool upd = tid < GH_UPD_THREADS;
+    const int role = upd ? 0 : (tid < GH_UPD_THREADS + GW ? 1 : 2);   // 0 update, 1 Cholesky chain, 2 Householder chain
     const int ti = (tid >> 5) & 15, tj = tid & 31;
     const int w = a.c1 - a.c0, off = a.c0 - a.cb;
     double N[SR][SC];                                     // x <= 2y+1 used
@@ -494,81 +500,91 @@ __global__ __launch_bounds__(GH_SOLVE_THREADS) void gh_solve_kernel(LeafArgs a, 
         }
     // LDS set-up while the loads above are in flight
     for (int e = tid; e < TP * TPS; e += GH_SOLVE_THREADS) Ws[e] = 0.f;
-    if (!upd) {
+    if (role == 1) {
         const int i = tid - GH_UPD_THREADS;
-        vdl[i] = 0.f; tdiag[i] = 1.f; cmask[i] = 0;
+        vdl[i] = 0.f; tdiag[i] = 1.f; cmask[i] = 0; sgn[i] = 1.f; nuv[i] = 0.0;
         col0[i] = (i < w) ? G[(off + i) * GW + off + i] : 0.0;     // ||a_j||^2 over all leaf rows
 #pragma unroll
-        for (int q = 0; q < 2; q++) { vec[q].rk[i] = 0.0; vec[q].w[i] = 0.f; vec[q].vt[i] = 0.f; }
+        for (int q = 0; q < 2; q++) { vecA[q].c[i] = 0.0; vecA[q].c1[i] = 0.0; vecA[q].c2[i] = 0.0; }
         if (i == 0) lflag = 0;
-    } else {
-        if (ti == 0) {
+    } else if (role == 2) {
+        const int i = tid - GH_UPD_THREADS - GW;
 #pragma unroll
-            for (int y = 0; y < SC; y++) { pre[0].N[tj + 32 * y] = N[0][y]; pre[0].B[tj + 32 * y] = B[0][y]; }
-        }
-        if (tj == 0) {
+        for (int q = 0; q < 2; q++) { vecB[q].w[i] = 0.f; vecB[q].w1[i] = 0.f; vecB[q].vt[i] = 0.f; vecB[q].vt2[i] = 0.f; }
+    } else if (ti == 0) {
 #pragma unroll
-            for (int x = 0; x < SR; x++) pre[0].C[ti + 16 * x] = B[x][0];
-        }
+        for (int y = 0; y < SC; y++) preN[0].N[tj + 32 * y] = N[0][y];   // row 0 for the first Cholesky step
     }
-    // the scalar chain is the critical path: its waves issue first
+    // the scalar chains are the critical path: their waves issue first
     if (!upd) __builtin_amdgcn_s_setprio(3);
     __syncthreads();
-    TSTAMP();
-    for (int t = 0; t <= w; t++) {
-        const bool tr = trace && (t == 8 || t == 100);
-        if (tr) TSTAMP();
-        const GhVec& pv = vec[(t + 1) & 1];                // vectors of step t-1 (all zero for t = 0)
-        if (!upd) {
-            if (t < w) {
-                // vectors of step t (branch-free; a column that cannot be reflected gets all-zero w, v)
-                GhVec& nv = vec[t & 1];
-                const GhPre& pr = pre[t & 1];
-                const int i = tid - GH_UPD_THREADS, kr = t;
-                const double pk_rk = pv.rk[kr], pi_rk = pv.rk[i], pN_t = pr.N[kr], pN_i = pr.N[i], c0k = col0[kr];
-                const float pk_vt = pv.vt[kr], pk_w = pv.w[kr], pi_w = pv.w[i], pi_vt = pv.vt[i];
-                const float pB_t = pr.B[kr], pB_i = pr.B[i], pC_i = pr.C[i];
-                // row/column t after step t-1: the same FMAs the owners of these entries execute in their update
-                const double sk = fma(-pk_rk, pk_rk, pN_t), rni = fma(-pk_rk, pi_rk, pN_i);
-                const float u0f = fmaf(-pk_vt, pk_w, pB_t), rbi = fmaf(-pk_vt, pi_w, pB_i), cb = fmaf(-pi_vt, pk_w, pC_i);
-                const double u0 = (double)u0f;
-                const bool ok = sk > 1e-30 && sk < 1e30;   // false: exactly-zero column (skipped) or out of range (flagged)
+    for (int it = 0; it <= w; it++) {
+        if (role == 1) {
+            // ---- Cholesky step a = it (one ahead of the Householder chain)
+            const int aa = it;
+            if (aa < w) {
+                const GhVecA& pc = vecA[(aa + 1) & 1];         // c^(a-1) (zero for a = 0)
+                GhVecA& nc = vecA[aa & 1];
+                const GhPreN& pr = preN[aa & 1];
+                const int i = tid - GH_UPD_THREADS;
+                const double pk = pc.c[aa], pi = pc.c[i], pN_a = pr.N[aa], pN_i = pr.N[i], c0k = col0[aa];
+                // row a after step a-1: the same FMAs its owners execute in their update
+                const double sk = fma(-pk, pk, pN_a), rni = fma(-pk, pi, pN_i);
+                const bool ok = sk > 1e-30 && sk < 1e30;       // false: zero / cancelled column or out of range -> flagged
                 const double skd = ok ? sk : 1.0;
-                // both fp32 seeds first (short fp32 chain), then the two fp64 refinements
-                const float skf = (float)skd, s1 = rsqrtf(skf), nuf = skf * s1;
-                const float s2 = rsqrtf(2.0f * (skf + fabsf(u0f) * nuf));
-                const double nu = skd * refine_rsqrt(skd, (double)s1);
-                double alpha = (u0 >= 0) ? nu : -nu;
-                double inv = refine_rsqrt(2.0 * (skd + fabs(u0) * nu), (double)s2);
-                alpha = ok ? alpha : 0.0; inv = ok ? inv : 0.0;
-                const double vtk = (u0 + alpha) * inv;                    // v_top[kr]
-                double wd = 2.0 * (rni + alpha * (double)rbi) * inv;
-                wd = (i > kr && i < w) ? wd : 0.0;
-                double rk = (double)rbi - vtk * wd;
-                rk = (i > kr) ? rk : 0.0;
-                float vt = (float)(((double)cb + (i == kr ? alpha : 0.0)) * inv);
-                vt = (i >= kr && i < w) ? vt : 0.f;
-                float nc = (i > kr) ? vt : (i == kr ? (float)(-alpha) : cb);
-                nc = ok ? nc : cb;
-                nv.w[i] = (float)wd;                                       // w_i (0 for i <= kr)
-                nv.rk[i] = rk;                                             // R[kr][i] (0 for i <= kr)
-                nv.vt[i] = vt;                                             // v_top[i] (0 for i < kr)
-                Ts[kr * TPS + i] = nc;                                     // final column kr of the top block
-                Ws[kr * TPS + i] = (float)wd;
+                double y = refine_rsqrt(skd, (double)rsqrtf((float)skd));
+                y = ok ? y : 0.0;
+                double ci = rni * y;                           // c_a[i] = N[a][i] / sqrt(N[a][a]);  c_a[a] = sqrt(N[a][a])
+                ci = (i >= aa && i < w) ? ci : 0.0;
+                nc.c[i] = ci; nc.c1[gh_p1(i)] = ci; nc.c2[gh_p2(i)] = ci;
+                if (i >= aa) Ts[i * TPS + aa] = (float)ci;     // |R[a][i]|: the sign comes from the Householder chain
                 if (i == 0) {
-                    if (ok ? (sk < GH_RHO_MIN * c0k) : (c0k > 0)) lflag = 1;   // cancelled, but not an exactly-zero column
-                    vdl[kr] = (float)vtk;
-                    tdiag[kr] = ok ? (float)inv : 1.f;
-                    cmask[kr] = ok ? 1 : 0;
+                    if (!ok || sk < GH_RHO_MIN * c0k) lflag = 1;
+                    nuv[aa] = ok ? sk * y : 0.0;
+                    cmask[aa] = ok ? 1 : 0;
+                }
+            }
+        } else if (role == 2) {
+            // ---- Householder step b = it - 1
+            const int b = it - 1;
+            if (b >= 0) {
+                const GhVecB& pb = vecB[(b + 1) & 1];          // step b-1 (zero for b = 0)
+                GhVecB& nb = vecB[b & 1];
+                const GhPreB& pr = preB[b & 1];
+                const int i = tid - GH_UPD_THREADS - GW;
+                const float pk_vt = pb.vt[b], pk_w = pb.w[b], pi_w = pb.w[i], pi_vt = pb.vt[i];
+                const float pB_b = pr.B[b], pB_i = pr.B[i], pC_i = pr.C[i];
+                const float ci = (float)vecA[b & 1].c[i], nu = (float)nuv[b];
+                const bool ok = cmask[b] != 0;
+                // row / column b after step b-1: the same FMAs their owners execute in their update
+                const float u0 = fmaf(-pk_vt, pk_w, pB_b), rbi = fmaf(-pk_vt, pi_w, pB_i), cbi = fmaf(-pi_vt, pk_w, pC_i);
+                const float s = (u0 >= 0.f) ? 1.f : -1.f, alpha = s * nu;
+                const float d = ok ? 2.f * nu * (nu + fabsf(u0)) : 1.f;
+                float inv = __builtin_amdgcn_rsqf(d);
+                inv = inv * (1.5f - 0.5f * d * inv * inv);     // one Newton step: full fp32 accuracy
+                inv = ok ? inv : 0.f;
+                float wi = 2.f * nu * (ci + s * rbi) * inv;
+                wi = (i > b && i < w) ? wi : 0.f;              // w_i (0 for i <= b)
+                float vi = (cbi + (i == b ? alpha : 0.f)) * inv;
+                vi = (i >= b && i < w) ? vi : 0.f;             // v_top[i] (0 for i < b)
+                nb.w[i] = wi; nb.w1[gh_p1(i)] = wi; nb.vt[i] = vi; nb.vt2[gh_p2(i)] = vi;
+                Ws[b * TPS + i] = wi;
+                if (i > b) Ts[b * TPS + i] = vi;               // final column b below the diagonal
+                if (i == 0) {
+                    sgn[b] = s;
+                    vdl[b] = (u0 + alpha) * inv;               // v_top[b]
+                    tdiag[b] = ok ? inv : 1.f;
                 }
             }
         } else {
-            // apply step t-1 (a skipped column has zero w, v: only the R row leaves N)
-            float wj[SC], vti[SR]; double rkj[SC], rki[SR];
+            // ---- update waves: Cholesky step it-1 on N, Householder step it-2 on B (vectors are zero before they exist)
+            const GhVecA& va = vecA[(it + 1) & 1];
+            const GhVecB& vb = vecB[it & 1];
+            double rkj[SC], rki[SR]; float wj[SC], vti[SR];
 #pragma unroll
-            for (int y = 0; y < SC; y++) { wj[y] = pv.w[tj + 32 * y]; rkj[y] = pv.rk[tj + 32 * y]; }
+            for (int y = 0; y < SC; y++) { rkj[y] = va.c1[SC * tj + y]; wj[y] = vb.w1[SC * tj + y]; }
 #pragma unroll
-            for (int x = 0; x < SR; x++) { vti[x] = pv.vt[ti + 16 * x]; rki[x] = pv.rk[ti + 16 * x]; }
+            for (int x = 0; x < SR; x++) { rki[x] = va.c2[SR * ti + x]; vti[x] = vb.vt2[SR * ti + x]; }
 #pragma unroll
             for (int x = 0; x < SR; x++)
 #pragma unroll
@@ -576,52 +592,59 @@ __global__ __launch_bounds__(GH_SOLVE_THREADS) void gh_solve_kernel(LeafArgs a, 
                     B[x][y] = fmaf(-vti[x], wj[y], B[x][y]);
                     if (x <= 2 * y + 1) N[x][y] = fma(-rki[x], rkj[y], N[x][y]);
                 }
-            // publish row/column t+1 (state after step t-1) for the scalar waves of the next iteration
-            const int t1 = t + 1;
-            if (t1 < w) {
-                GhPre& nx = pre[t1 & 1];
-                if (ti == (t1 & 15)) {
+            // publish: row it+1 of N (state after Cholesky step it-1), row / column it of B (state after Householder step it-2)
+            const int tn1 = it + 1;
+            if (tn1 < w && ti == (tn1 & 15)) {
+                GhPreN& nx = preN[tn1 & 1];
+#pragma unroll
+                for (int x = 0; x < SR; x++)
+                    if (x == (tn1 >> 4)) {
+#pragma unroll
+                        for (int y = 0; y < SC; y++)
+                            if (x <= 2 * y + 1) nx.N[tj + 32 * y] = N[x][y];
+                    }
+            }
+            if (it < w) {
+                GhPreB& nx = preB[it & 1];
+                if (ti == (it & 15)) {
 #pragma unroll
                     for (int x = 0; x < SR; x++)
-                        if (x == (t1 >> 4)) {
+                        if (x == (it >> 4)) {
 #pragma unroll
-                            for (int y = 0; y < SC; y++) {
-                                if (x <= 2 * y + 1) nx.N[tj + 32 * y] = N[x][y];
-                                nx.B[tj + 32 * y] = B[x][y];
-                            }
+                            for (int y = 0; y < SC; y++) nx.B[tj + 32 * y] = B[x][y];
                         }
                 }
-                if (tj == (t1 & 31)) {
+                if (tj == (it & 31)) {
 #pragma unroll
                     for (int y = 0; y < SC; y++)
-                        if (y == (t1 >> 5)) {
+                        if (y == (it >> 5)) {
 #pragma unroll
                             for (int x = 0; x < SR; x++) nx.C[ti + 16 * x] = B[x][y];
                         }
                 }
             }
         }
-        if (tr) TSTAMP();
         __syncthreads();
     }
     if (!upd) __builtin_amdgcn_s_setprio(0);
-    TSTAMP();
-    // R and the top block of V go out first (from the LDS columns): the stores drain while the inverse below runs
+    // R and the top block of V go out first (from the LDS columns): the stores drain while the inverse below runs.
+    // Ts[k][i] = |R[i][k]| for i <= k (sign -sgn[i]), v_top of column k for i > k.
     if ((w & 7) == 0 && (a.c0 & 7) == 0) {                 // usual case: 16-byte stores (8 fp16 / 4 fp32 per thread)
         typedef half_t half4v __attribute__((ext_vector_type(4)));
         typedef half_t half8v __attribute__((ext_vector_type(8)));
         for (int e = tid; e < GW * (GW / 4); e += GH_SOLVE_THREADS) {
             const int i = e >> 5, k = (e & 31) * 4;           // 4 consecutive k: a row segment of A and Vh
             if (i < w && k < w) {
-                float4 v; half4v hv;
-                v.x = Ts[(k + 0) * TPS + i]; v.y = Ts[(k + 1) * TPS + i]; v.z = Ts[(k + 2) * TPS + i]; v.w = Ts[(k + 3) * TPS + i];
+                const float ns = -sgn[i];
+                float t4[4]; float4 v; half4v hv;
+#pragma unroll
+                for (int q = 0; q < 4; q++) { const float t = Ts[(k + q) * TPS + i]; t4[q] = (i <= k + q) ? ns * t : t; }
+                v.x = t4[0]; v.y = t4[1]; v.z = t4[2]; v.w = t4[3];
                 *(float4*)&a.A[(long)(a.c0 + i) * a.lda + a.c0 + k] = v;
                 if (i >= k) {                                 // V: below the diagonal from the columns, v_kk on it, zero above
                     const float vd = vdl[i];
-                    hv[0] = i > k ? (half_t)v.x : (half_t)vd;
-                    hv[1] = i > k + 1 ? (half_t)v.y : (i == k + 1 ? (half_t)vd : (half_t)0.f);
-                    hv[2] = i > k + 2 ? (half_t)v.z : (i == k + 2 ? (half_t)vd : (half_t)0.f);
-                    hv[3] = i > k + 3 ? (half_t)v.w : (i == k + 3 ? (half_t)vd : (half_t)0.f);
+#pragma unroll
+                    for (int q = 0; q < 4; q++) hv[q] = i > k + q ? (half_t)t4[q] : (i == k + q ? (half_t)vd : (half_t)0.f);
                     *(half4v*)&a.Vh[(long)(a.c0 + i) * a.ldvh + a.c0 + k] = hv;
                 }
             }
@@ -640,7 +663,8 @@ __global__ __launch_bounds__(GH_SOLVE_THREADS) void gh_solve_kernel(LeafArgs a, 
         for (int e = tid; e < GW * GW; e += GH_SOLVE_THREADS) {
             const int i = e >> 7, k = e & 127;                 // k fastest: rows of A and Vh
             if (i < w && k < w) {
-                const float v = Ts[k * TPS + i];
+                const float t = Ts[k * TPS + i];
+                const float v = (i <= k) ? -sgn[i] * t : t;
                 a.A[(long)(a.c0 + i) * a.lda + a.c0 + k] = v;
                 if (i > k) a.Vh[(long)(a.c0 + i) * a.ldvh + a.c0 + k] = (half_t)v;
             }
@@ -663,23 +687,12 @@ __global__ __launch_bounds__(GH_SOLVE_THREADS) void gh_solve_kernel(LeafArgs a, 
     __syncthreads();
     for (int e = tid; e < TP * TPS; e += GH_SOLVE_THREADS) Ts[e] = 0.f;
     __syncthreads();
-    TSTAMP();
-    // C = (D^-1 + W)^-1, columns of skipped reflectors zeroed
+    // C = (D^-1 + W)^-1, columns of flagged reflectors zeroed
     tri_inverse_128(Ws, tdiag, Ts, (w + 31) / 32, tid);
-    TSTAMP();
     for (int e = tid; e < GW * GW; e += GH_SOLVE_THREADS) {          // window coordinates (leaf index + off), zero elsewhere
         const int i = (e >> 7) - off, k = (e & 127) - off;
         Cv[e] = (i >= 0 && i <= k && k < w && cmask[k]) ? Ts[i * TPS + k] : 0.f;
     }
-#ifdef MPQR_SOLVE_TRACE
-    if (trace && threadIdx.x == TRACE_TID) {
-        tq[nt++] = clock64();
-        printf("gh_solve tid %d:", TRACE_TID);
-        for (int q = 1; q < nt; q++) printf(" %ld", tq[q] - tq[q - 1]);
-        printf("\n");
-    }
-#endif
-#undef TSTAMP
 }
 
 typedef half_t half8p __attribute__((ext_vector_type(8)));

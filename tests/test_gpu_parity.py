@@ -30,6 +30,25 @@ def relF(X, Y):
     return np.linalg.norm(X.astype(np.float64) - Y) / max(np.linalg.norm(Y), 1e-30)
 
 
+def align_pivot_signs(V, V0, R, R0, n, tol=2e-3):
+    """The reference's sign rule alpha = sgn(u0) ||u|| is discontinuous at u0 = 0: when the pivot u0 is tiny relative
+    to ||u|| its sign is decided by rounding noise (here: of the fp16 trailing updates), and both choices are equally
+    valid Householder steps with R row / Q column k negated.  After such a column the two runs hold different (equally
+    valid) reflector representations of the same factorisation, so later signs may differ as well.
+    Returns (D, first): D = +-1 per column aligning our R rows / Q columns with the oracle's, after CHECKING that the
+    FIRST flipped column really has a tiny pivot in both runs (|v_kk| = (|u0| + nu) / ||u|| within `tol` of 1/sqrt(2),
+    i.e. |u0| < ~3e-3 nu); `first` = that column (reflectors are compared element-wise only before it)."""
+    d, d0 = np.diag(R)[:n], np.diag(R0)[:n]
+    D = np.where(np.sign(d) == np.sign(d0), 1.0, -1.0).astype(np.float32)
+    flipped = np.where(D < 0)[0]
+    if len(flipped):
+        k = int(flipped[0])
+        assert abs(abs(V[k, k]) - np.sqrt(0.5)) <= tol and abs(abs(V0[k, k]) - np.sqrt(0.5)) <= tol, \
+            ("sign differs at a pivot that is not small", k, V[k, k], V0[k, k])
+        assert len(flipped) <= n // 4, flipped
+    return D, (int(flipped[0]) if len(flipped) else n)
+
+
 def run_gpu(mp, h, A, r):
     m, n = A.shape
     Ao = np.zeros((m + 1, n), np.float32); Ao[:m] = A
@@ -170,9 +189,14 @@ def test_oracle_sized_block_compare_1536x768(mp, h, po):
     A = po.generate(m, n, seed=1234)
     Ao, Q, R = run_gpu(mp, h, A, r)
     A0, Q0, R0 = po.block_qr(A, r, "compact32", omp=True)
-    assert relF(R, R0) <= 2e-3 and relF(Q, Q0) <= 3e-3
     V = po.extract_V(Ao, m, n, 0, n); V0 = po.extract_V(A0, m, n, 0, n)
-    assert relF(V, V0) <= 3e-3
+    D, first = align_pivot_signs(V, V0, R, R0, n)
+    Dm = np.ones(m, np.float32); Dm[:n] = D
+    # thin Q (the first n columns) is unique up to these signs; the complement basis is not once a sign has flipped
+    assert relF(R * Dm[:, None], R0) <= 2e-3 and relF(Q[:, :n] * D[None, :], Q0[:, :n]) <= 3e-3
+    if first == n:
+        assert relF(Q, Q0) <= 3e-3
+    assert relF(V[:, :first], V0[:, :first]) <= 3e-3
     mt = mp.qr_metrics(A, R, Q, handle=h)
     assert mt["backward_error"] <= 1e-3 and mt["q_error_fro"] <= 2e-3 * np.sqrt(m)
 
@@ -185,9 +209,13 @@ def test_ragged_tall_leaves_match_oracle(mp, h, po, m, n, r):
     Ao, Q, R = run_gpu(mp, h, A, r)
     A0, Q0, R0 = po.block_qr(A, r, "compact32", omp=True)
     assert np.isfinite(Ao).all() and np.isfinite(Q).all()
-    assert relF(R, R0) <= 3e-3 and relF(Q, Q0) <= 5e-3, (relF(R, R0), relF(Q, Q0))
     V = po.extract_V(Ao, m, n, 0, n); V0 = po.extract_V(A0, m, n, 0, n)
-    assert relF(V, V0) <= 5e-3, relF(V, V0)
+    D, first = align_pivot_signs(V, V0, R, R0, n)
+    Dm = np.ones(m, np.float32); Dm[:n] = D
+    assert relF(R * Dm[:, None], R0) <= 3e-3 and relF(Q[:, :n] * D[None, :], Q0[:, :n]) <= 5e-3, (relF(R, R0), relF(Q, Q0))
+    if first == n:
+        assert relF(Q, Q0) <= 5e-3
+    assert relF(V[:, :first], V0[:, :first]) <= 5e-3, relF(V, V0)
     mt = mp.qr_metrics(A, R, Q, handle=h)
     assert mt["backward_error"] <= 1e-3 and mt["q_error_fro"] <= 2e-3 * np.sqrt(m), mt
     assert np.all(R[np.tril_indices(n, -1)[0], np.tril_indices(n, -1)[1]] == 0)
