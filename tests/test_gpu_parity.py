@@ -253,6 +253,31 @@ def test_config2_2048_properties(mp, h):
     assert t["ms_total"] > 0 and t["n_far_launches"] >= 1
 
 
+@pytest.mark.parametrize("m,n,r", [(16384, 16384, 128), (65536, 8192, 256)])
+def test_full_size_configs_properties(mp, m, n, r):
+    """BASELINE configs 4 and 5 at full size, device-resident (input generated on the GPU, metrics reduced on the GPU):
+    size-independent properties -- A = QR within the north-star tolerance, Q^T Q = I, R upper triangular,
+    bit-repeatable -- and the tall leaves stay on the fast (Gram-Householder) path for well-conditioned input."""
+    hh = mp.Handle(0)
+    try:
+        hh.plan(m, n, r)
+        hh.generate(1234); hh.factor(); hh.sync()
+        mt = hh.metrics()
+        assert mt["backward_error"] <= 1e-3, mt                    # north star: ||A - QR||_F / ||A||_F <= 1e-3
+        assert mt["q_error_fro"] <= 2e-3 * np.sqrt(m), mt
+        assert abs(mt["q_error_max_signed"]) <= 2e-3, mt
+        assert mt["lower_trapezoid"] == 0.0
+        t1 = hh.timings()
+        hh.factor(); hh.sync()
+        mt2 = hh.metrics()
+        # the factorisation is deterministic (no atomics on the path); the fp64 metric reductions may reassociate
+        assert abs(mt2["backward_error"] - mt["backward_error"]) <= 1e-12 * mt["backward_error"]
+        assert abs(mt2["q_error_fro"] - mt["q_error_fro"]) <= 1e-12 * mt["q_error_fro"]
+        assert t1["ms_total"] > 0 and t1["n_far_launches"] >= 1
+    finally:
+        hh.close()
+
+
 def test_cpp_main_path_fp64(mp, h, po, golden):
     """a-10: qr_factorization (C++/main.cpp:16-43) in fp64 on the GPU vs the real reference's outputs."""
     for name in golden["cppmain_names"]:
