@@ -317,32 +317,40 @@ __global__ __launch_bounds__(256) void gh_gram_kernel(LeafArgs a, double* __rest
         *(double2*)(d + 2) = make_double2((double)v.z, (double)v.w);
     }
     __syncthreads();
-    // thread -> 4 x 8 block: rows 64*hb + 4*(tid>>4) .. +3, columns 8*(tid&15) .. +7 of the 128 x 128 Gram
-    const int bi = tid >> 4, bj = tid & 15;
-    const int i0 = 64 * hb + 4 * bi;
-    double acc[4][8];
+    // G = T^T T on v_mfma_f64_16x16x4_f64 (A[i][k] from lane i + 16k, B[k][j] from lane j + 16k, D[i][j] in lane j + 16 (i%4),
+    // element i/4 -- probed, tools/probe_mfma_f64.hip).  G is symmetric: only the 36 upper 16 x 16 tiles are computed,
+    // tile t = hb + 2 wave + 8 s  (s < 5) by this wave; gh_reduce mirrors the sum.
+    const int lane = tid & 63, wave = tid >> 6, li = lane & 15, lk = lane >> 4;
+    int tti[5], ttj[5];
+    typedef double double4g __attribute__((ext_vector_type(4)));
+    double4g acc[5];
 #pragma unroll
-    for (int x = 0; x < 4; x++)
+    for (int s = 0; s < 5; s++) {
+        int t = hb + 2 * wave + 8 * s;                       // row-major index among the upper tiles of an 8 x 8 tile grid
+        int ti = 0;
+        if (t >= 36) { tti[s] = -1; ttj[s] = 0; }
+        else {
+            while (t >= 8 - ti) { t -= 8 - ti; ti++; }
+            tti[s] = ti; ttj[s] = ti + t;
+        }
+        acc[s] = double4g{0, 0, 0, 0};
+    }
+    for (int k0 = 0; k0 < GH_ROWS; k0 += 4) {
+        const double* tr = &tile[(k0 + lk) * GH_TD + li];
 #pragma unroll
-        for (int y = 0; y < 8; y++) acc[x][y] = 0.0;
-#pragma unroll 2
-    for (int r = 0; r < GH_ROWS; r++) {
-        const double* tr = &tile[r * GH_TD];
-        const double2 a0 = *(const double2*)(tr + i0), a1 = *(const double2*)(tr + i0 + 2);
-        const double2 b0 = *(const double2*)(tr + 8 * bj), b1 = *(const double2*)(tr + 8 * bj + 2);
-        const double2 b2 = *(const double2*)(tr + 8 * bj + 4), b3 = *(const double2*)(tr + 8 * bj + 6);
-        const double av[4] = {a0.x, a0.y, a1.x, a1.y};
-        const double bv[8] = {b0.x, b0.y, b1.x, b1.y, b2.x, b2.y, b3.x, b3.y};
-#pragma unroll
-        for (int x = 0; x < 4; x++)
-#pragma unroll
-            for (int y = 0; y < 8; y++) acc[x][y] = fma(av[x], bv[y], acc[x][y]);
+        for (int s = 0; s < 5; s++)
+            if (tti[s] >= 0) acc[s] = __builtin_amdgcn_mfma_f64_16x16x4f64(tr[16 * tti[s]], tr[16 * ttj[s]], acc[s], 0, 0, 0);
     }
     double* out = Gp + (long)(blockIdx.x >> 1) * (GW * GW);
 #pragma unroll
-    for (int x = 0; x < 4; x++)
+    for (int s = 0; s < 5; s++)
+        if (tti[s] >= 0) {
 #pragma unroll
-        for (int y = 0; y < 8; y++) out[(i0 + x) * GW + 8 * bj + y] = acc[x][y];
+            for (int v = 0; v < 4; v++) {
+                const int i = 16 * tti[s] + lk + 4 * v, j = 16 * ttj[s] + li;
+                out[i * GW + j] = acc[s][v];                 // upper tiles only: gh_reduce mirrors
+            }
+        }
 }
 
 // G = sum of the partials in slab order.  256 workgroups: workgroup b owns 64 consecutive entries, its 4 waves
@@ -351,11 +359,17 @@ __global__ __launch_bounds__(256) void gh_reduce_kernel(const double* __restrict
     __shared__ double part[4][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int e = blockIdx.x * 64 + lane;
+    const int i = e >> 7, j = e & 127;
+    const bool act = (i >> 4) <= (j >> 4);                // 16 x 16 tiles below the diagonal are not produced: mirrored below
     double s = 0;
-    for (int q = wave; q < nwg; q += 4) s += Gp[(long)q * (GW * GW) + e];
+    if (act) for (int q = wave; q < nwg; q += 4) s += Gp[(long)q * (GW * GW) + e];
     part[wave][lane] = s;
     __syncthreads();
-    if (wave == 0) G[e] = (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
+    if (wave == 0 && act) {
+        const double g = (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
+        G[e] = g;
+        if ((i >> 4) != (j >> 4)) G[j * GW + i] = g;       // mirror: G is symmetric
+    }
 }
 
 // 1/sqrt(x) in fp64 from an fp32 seed and two Newton steps (2^-23 -> 2^-46 -> 2^-92); x outside the fp32 range
