@@ -276,13 +276,16 @@ __global__ __launch_bounds__(1024) void leaf_wg_kernel(LeafArgs a) {
 // explicit values in the top w rows:  B_low = A_low M,  B_top explicit.  All inner products over the tall part
 // therefore follow from G = A_low^T A_low (w x w), and the Householder recursion (same u, alpha, v, w_j, sign
 // rule and zero-column skip as the kernels above) runs on w x w matrices:
-//   gh_gram    : per-workgroup partial G over 128 rows; fp32 data, products and sums in fp64
-//   gh_reduce  : G = sum of the partials (fixed order: deterministic)
-//   gh_solve   : one workgroup; N = Gram of all not-yet-final rows (fp64), B_top and M (fp32) in registers,
-//                4 x 4 entries per thread; emits R, V_top, C (V_low = A_low C) and rho_k = ||u_k||^2 / ||a_k||^2
-//   gh_apply   : V_low = A_low C on the exact-f32 MFMA, written over A_low, plus fp16 copies V and V^T
+//   gh_gram    : per-workgroup partial G over 128 rows; fp32 data, products and sums in fp64 (f64 MFMA, upper tiles)
+//   gh_reduce  : G = sum of the partials (fixed order: deterministic), mirrored to the full symmetric matrix
+//   gh_solve   : one workgroup; N = Gram of all not-yet-final rows (fp64) and B_top (fp32) in registers; a Cholesky
+//                chain on N and a Householder chain on B_top on separate waves (see the kernel); emits R, V_top,
+//                C (V_low = A_low C, one triangular inverse at the end) and checks rho_k = ||u_k||^2 / ||a_k||^2
+//   gh_apply   : V_low = A_low C on the exact-f32 MFMA, written over A_low, plus fp16 copies V and V^T and the
+//                partial Gram matrices of the fp16 V (for the leaf's T)
 // No pass over the tall data is sequential in k.  V differs from Householder's by O(2^-24 / sqrt(rho)); a leaf
-// with rho < GH_RHO_MIN raises a flag and the driver redoes the work on the column-by-column kernels above.
+// with rho < GH_RHO_MIN or a column that cannot be reflected raises a flag and the driver redoes the work on the
+// column-by-column kernels above.
 // optional in-kernel phase timing (make EXTRA=-DMPQR_KTRACE): thread 0 of block 0 stamps s_memtime at phase
 // boundaries and prints the deltas for the first few launches of each kernel
 #ifdef MPQR_KTRACE
