@@ -274,8 +274,8 @@ __global__ __launch_bounds__(1024) void leaf_wg_kernel(LeafArgs a) {
 // Leaf = up to 128 adjacent columns [c0,c1) inside one 128-aligned window [cb, cb+128), w = c1-c0.
 // After reflectors c0..k-1 every leaf column is (a combination of the ORIGINAL leaf columns) below row c1 plus
 // explicit values in the top w rows:  B_low = A_low M,  B_top explicit.  All inner products over the tall part
-// therefore follow from G = A_low^T A_low (w x w), and the Householder recursion (same u, alpha, v, w_j, sign
-// rule and zero-column skip as the kernels above) runs on w x w matrices:
+// therefore follow from G = A_low^T A_low (w x w), and the Householder recursion (same u, alpha, v, w_j and sign
+// rule as the kernels above; exactly-zero columns are handed to them through the flag) runs on w x w matrices:
 //   gh_gram    : per-workgroup partial G over 128 rows; fp32 data, products and sums in fp64 (f64 MFMA, upper tiles)
 //   gh_reduce  : G = sum of the partials (fixed order: deterministic), mirrored to the full symmetric matrix
 //   gh_solve   : one workgroup; N = Gram of all not-yet-final rows (fp64) and B_top (fp32) in registers; a Cholesky
