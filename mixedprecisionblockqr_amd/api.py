@@ -209,6 +209,29 @@ def write_euroc_jacobian(path, M):
         raise MpqrError(rc, f"cannot write {path}")
 
 
+def synthetic_jacobian(cams=40, points=580, views=2, seed=1234, outliers=8):
+    """Stand-in for a EuRoC bundle-adjustment Jacobian (BASELINE config 3; the reference's real files are an
+    absent LFS blob): one 2-row block per observation with a dense 2x6 camera block and a dense 2x3 point block,
+    everything else zero.  Values ~ N(0, 1) with a few large entries (1e3 .. 1e5) that would overflow fp16 without the
+    library's power-of-two scale.  Returns a dense row-major fp32 matrix (rows = 2 * observations >= columns)."""
+    rng = np.random.default_rng(seed)
+    n = 6 * cams + 3 * points
+    obs = [(pt, int(c)) for pt in range(points) for c in rng.choice(cams, size=views, replace=False)]
+    while 2 * len(obs) < n:                                   # keep the system at least square
+        obs.append((int(rng.integers(points)), int(rng.integers(cams))))
+    M = np.zeros((2 * len(obs), n), np.float32)
+    for k, (pt, c) in enumerate(obs):
+        M[2 * k:2 * k + 2, 6 * c:6 * c + 6] = rng.standard_normal((2, 6))
+        M[2 * k:2 * k + 2, 6 * cams + 3 * pt:6 * cams + 3 * pt + 3] = rng.standard_normal((2, 3))
+    nz = np.argwhere(M != 0)
+    for i, j in nz[rng.choice(len(nz), size=min(outliers, len(nz)), replace=False)]:
+        M[i, j] *= 10.0 ** rng.uniform(3, 5)
+    i, j = np.unravel_index(np.argmax(np.abs(M)), M.shape)
+    if abs(M[i, j]) <= 65504.0:                                # at least one entry beyond the fp16 range
+        M[i, j] = np.sign(M[i, j]) * 1.3e5
+    return M
+
+
 def h_write_results_to_log(height, width, time_ms, flops_per_second, backward_error, file_name="logFile", log_dir="log"):
     """Cuda/qr.cu:58-83."""
     rc = L.lib().mpqr_write_results_to_log(str(log_dir).encode(), file_name.encode(), height, width, time_ms,

@@ -278,6 +278,34 @@ def test_full_size_configs_properties(mp, m, n, r):
         hh.close()
 
 
+def test_config3_synthetic_jacobian_through_the_file_format(mp, h, po, tmp_path):
+    """BASELINE config 3 (EuRoC bundle-adjustment Jacobian, r = 64): the real files are an absent LFS blob, so a
+    block-sparse stand-in with the same structure goes through the reference's text format (a-9) and the factorisation,
+    and the CSV log row the reference's plotting scripts read (rows,cols,runtime,flops,error) is written."""
+    M = mp.synthetic_jacobian()
+    m, n = M.shape
+    assert m >= n and abs(M).max() > 65504.0                       # would overflow fp16 without the scale
+    f = tmp_path / "A_000000001.txt"
+    mp.write_euroc_jacobian(f, M)
+    A = mp.read_euroc_jacobian(f)
+    assert np.array_equal(A, M) and np.array_equal(A, po.read_euroc_jacobian(str(f)))
+    Ao, Q, R = run_gpu(mp, h, A, 64)
+    assert np.isfinite(Ao).all() and np.isfinite(Q).all()
+    mt = mp.qr_metrics(A, R, Q, handle=h)
+    assert mt["backward_error"] <= 1e-3 and mt["q_error_fro"] <= 2e-3 * np.sqrt(m), mt
+    assert mt["lower_trapezoid"] == 0.0
+    # same R as the fp32 oracle up to the sign ambiguity of near-zero pivots (sparse columns have many exact zeros below)
+    A0, Q0, R0 = po.block_qr(A, 64, "compact32", omp=True)
+    d, d0 = np.abs(np.diag(R)[:n]), np.abs(np.diag(R0)[:n])
+    assert np.linalg.norm(d - d0) <= 5e-3 * np.linalg.norm(d0)
+    logdir = tmp_path / "log"
+    mp.h_write_results_to_log(m, n, 1.0, mp.h_qr_flops_per_second(1.0, m, n), mt["backward_error"], "jacobian", str(logdir))
+    lines = (logdir / "jacobian.txt").read_text().strip().splitlines()
+    assert lines[0] == "rows,cols,runtime,flops,error"
+    row = lines[-1].split(",")
+    assert int(float(row[0])) == m and int(float(row[1])) == n and len(row) == 5
+
+
 def test_cpp_main_path_fp64(mp, h, po, golden):
     """a-10: qr_factorization (C++/main.cpp:16-43) in fp64 on the GPU vs the real reference's outputs."""
     for name in golden["cppmain_names"]:
