@@ -152,6 +152,20 @@ int mpqr_error_passes(double err, int m, int precision_bits);
  * Q (m x m) out.  Runs on the GPU in fp64. */
 int mpqr_qr_factorization_f64(mpqr_handle_t h, double* A, double* Q, int m, int n);
 
+/* ---------------- least squares on top of the factorisation ---------------- */
+/* B <- Q^T B for host B (m x nrhs, row-major, ld = nrhs), applied IMPLICITLY from the stored reflectors (V, T of every
+ * column block; Q is never formed): step 2 of Golub & Van Loan Alg. 5.3.2, the algorithm named by the reference's
+ * dev_QR_Solver stub (Cuda/QR/Solver/solver.cu:39-87).  Needs a factored handle (mpqr_factor / mpqr_block_qr_f32). */
+int mpqr_apply_qt_host(mpqr_handle_t h, float* B, int nrhs);
+/* X (n x nrhs, row-major, ld = nrhs) = argmin ||A X - B||_F = R^-1 (Q^T B)[0:n]  for host B (m x nrhs);
+ * replaces linear_least_square(A, y)  python/linear_least_sqare.py:5-22 (its pinv(Q) y is Q^T y, the back
+ * substitution is its loop :17-21).  Needs a factored handle; a zero R_ii gives x_i = 0. */
+int mpqr_solve_ls_host(mpqr_handle_t h, const float* B, int nrhs, float* X);
+/* replaces void dev_QR_Solver(float* A, float* b, float* x, int m, int n)  Cuda/QR/Solver/solver.cu:39-87 (a stub in
+ * the reference): factor A (m x n row-major host, r-column panels, Q not formed), x = argmin ||A x - b||. */
+int mpqr_qr_solver_f32(mpqr_handle_t h, const float* A, const float* b, float* x, int m, int n, int r);
+int mpqr_dev_qr_solver(const float* A, const float* b, float* x, int m, int n);    /* default handle, r = 128 */
+
 /* ---------------- host-side helpers of the path (no GPU needed) ---------------- */
 /* replaces read_euroc_jacobian(std::string, int*, int*, float**)  Cuda/qr.cu:696-776.
  * *matrix is malloc'd by the callee (as in the reference); free with mpqr_free_host. */

@@ -34,6 +34,11 @@ inline void dev_mixed_precision_block_qr(float* A, float* Q, int m, int n, int r
     mpqr_opts o; mpqr_default_opts(&o); o.precision = MPQR_PREC_FP16;
     mpqr_ref::check(mpqr_block_qr_f32(mpqr_ref::handle(), A, Q, m, n, r, &o), "dev_mixed_precision_block_qr");
 }
+// Cuda/QR/Solver/solver.cu:39  void dev_QR_Solver(float* A, float* b, float* x, int m, int n)   (a stub in the reference)
+inline void dev_QR_Solver(float* A, float* b, float* x, int m, int n) {
+    mpqr_ref::check(mpqr_qr_solver_f32(mpqr_ref::handle(), A, b, x, m, n, 128), "dev_QR_Solver");
+}
+
 // Cuda/qr.cuh:131  void dev_block_qr_wy(float* A, float* Q, int m, int n, int r)   (fp32 twin)
 inline void dev_block_qr_wy(float* A, float* Q, int m, int n, int r) {
     mpqr_opts o; mpqr_default_opts(&o); o.precision = MPQR_PREC_FP32;

@@ -73,6 +73,10 @@ SIGNATURES = {
     "mpqr_metrics_f32": (_i, [_H, _f32, _f32, _f32, _i, _i, C.POINTER(MpqrMetrics)]),
     "mpqr_error_passes": (_i, [_d, _i, _i]),
     "mpqr_qr_factorization_f64": (_i, [_H, _f64, _f64, _i, _i]),
+    "mpqr_apply_qt_host": (_i, [_H, _f32, _i]),
+    "mpqr_solve_ls_host": (_i, [_H, _f32, _i, _f32]),
+    "mpqr_qr_solver_f32": (_i, [_H, _f32, _f32, _f32, _i, _i, _i]),
+    "mpqr_dev_qr_solver": (_i, [_f32, _f32, _f32, _i, _i]),
     "mpqr_read_euroc_jacobian": (_i, [_s, C.POINTER(_i), C.POINTER(_i), C.POINTER(C.POINTER(_f))]),
     "mpqr_write_euroc_jacobian": (_i, [_s, _i, _i, _f32]),
     "mpqr_free_host": (None, [_p]),

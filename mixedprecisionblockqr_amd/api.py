@@ -190,6 +190,44 @@ def qr_factorization(A, handle=None):
     return Qc.T.copy(), Ac.T.copy()
 
 
+def apply_qt(B, handle=None):
+    """B <- Q^T B (m x nrhs), implicitly from the reflectors of the last factorisation (G&VL Alg. 5.3.2 step 2)."""
+    h = handle or default_handle()
+    B = np.ascontiguousarray(B, np.float32)
+    B2 = B.reshape(B.shape[0], -1).copy()
+    h._chk(L.lib().mpqr_apply_qt_host(h._h, B2, B2.shape[1]))
+    return B2.reshape(B.shape)
+
+
+def solve_ls(B, handle=None):
+    """argmin ||A X - B|| for the matrix last factored on `handle`: X = R^-1 (Q^T B)[0:n]."""
+    h = handle or default_handle()
+    B = np.ascontiguousarray(B, np.float32)
+    B2 = B.reshape(B.shape[0], -1)
+    X = np.empty((h.n, B2.shape[1]), np.float32)
+    h._chk(L.lib().mpqr_solve_ls_host(h._h, np.ascontiguousarray(B2), B2.shape[1], X))
+    return X[:, 0] if B.ndim == 1 else X
+
+
+def linear_least_square(A, y, r=128, handle=None):
+    """python/linear_least_sqare.py:5-22 / dev_QR_Solver (Cuda/QR/Solver/solver.cu:39-87): x = argmin ||A x - y||."""
+    h = handle or default_handle()
+    A = np.ascontiguousarray(A, np.float32)
+    y = np.ascontiguousarray(y, np.float32)
+    m, n = A.shape
+    x = np.empty(n, np.float32)
+    h._chk(L.lib().mpqr_qr_solver_f32(h._h, A, y, x, m, n, r))
+    h.m, h.n, h.r = m, n, r                                   # the call planned the handle for this shape
+    return x
+
+
+def dev_QR_Solver(A, b, x, m, n):
+    """void dev_QR_Solver(float* A, float* b, float* x, int m, int n)  Cuda/QR/Solver/solver.cu:39 (default handle)."""
+    rc = L.lib().mpqr_dev_qr_solver(np.ascontiguousarray(A, np.float32), np.ascontiguousarray(b, np.float32), x, m, n)
+    if rc != L.OK:
+        raise MpqrError(rc, "dev_QR_Solver failed")
+
+
 def read_euroc_jacobian(path):
     """Cuda/qr.cu:696.  Returns a dense float32 matrix."""
     rows, cols = C.c_int(), C.c_int()

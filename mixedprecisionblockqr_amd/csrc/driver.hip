@@ -1077,6 +1077,86 @@ int mpqr_q_backward_accumulation_f32(mpqr_handle_t h, const float* A, float* Q, 
 }
 
 // ---------------------------------------------------------------- C++/main.cpp path
+// ---------------------------------------------------------------------------- least squares
+namespace {
+// dB (m_pad x ldb, fp32, device) <- Q^T dB from the stored reflectors, block by block (the trailing-update operator)
+int apply_qt_device(mpqr_handle_t h, float* dB, long ldb, int nrhs) {
+    // power-of-two scale that keeps the fp16 operand in range, as for the matrix itself
+    launch_absmax(dB, ldb, h->m, nrhs, h->dscalar, h->s0);
+    float mx = 0.f;
+    HIPCHK(h, hipMemcpyAsync(&mx, h->dscalar, sizeof(float), hipMemcpyDeviceToHost, h->s0));
+    HIPCHK(h, hipStreamSynchronize(h->s0));
+    float sc = 1.f;
+    if (mx > 0.f && std::isfinite(mx)) { int e; frexpf(mx * sqrtf((float)h->m), &e); sc = ldexpf(1.f, 8 - e); }
+    for (size_t t = 0; t < h->tops.size(); t++) apply_node(h, h->nodes[h->tops[t]], dB, ldb, 0, nrhs, true, sc, false, 0);
+    return MPQR_OK;
+}
+// dB[0:n] <- R^-1 dB[0:n]: blocked back substitution from the last diagonal block up (R = upper part of the factor)
+int back_substitute_device(mpqr_handle_t h, float* dB, long ldb, int nrhs) {
+    const int n = h->n;
+    for (int k1 = n; k1 > 0;) {
+        const int k0 = ((k1 - 1) / 128) * 128, kb = k1 - k0;
+        launch_trsm_diag(h->dA, h->lda, k0, kb, dB, ldb, nrhs, h->s0);
+        if (k0 > 0) {                                         // Y[0:k0] -= R[0:k0, k0:k1] X[k0:k1], exact-f32 MFMA
+            SgemmArgs u{};
+            u.A = h->dA + k0; u.lda = h->lda; u.transA = 0; u.nslab_a = 1;
+            u.B = dB + (long)k0 * ldb; u.ldb = ldb; u.transB = 0;
+            u.C = dB; u.ldc = ldb; u.M = k0; u.N = nrhs; u.K = kb; u.alpha = -1.f; u.beta = 1.f;
+            launch_sgemm(u, h->s0);
+        }
+        k1 = k0;
+    }
+    HIPCHK(h, hipGetLastError());
+    return MPQR_OK;
+}
+int ls_core(mpqr_handle_t h, const float* B, int nrhs, float* out, bool solve) {
+    int rc = need_plan(h); if (rc) return rc;
+    if (!h->factored) return fail(h, MPQR_ERR_STATE, "factor first");
+    if (h->world != 1) return fail(h, MPQR_ERR_INVALID, "single-GPU handles only");
+    if (h->opts.precision == MPQR_PREC_FP32) return fail(h, MPQR_ERR_INVALID, "MPQR_PREC_FP16 handles only");
+    if (!B || !out || nrhs < 1) return fail(h, MPQR_ERR_INVALID, "bad arguments");
+    const long ldb = ((long)nrhs + 31) / 32 * 32;
+    float* dB = nullptr;
+    if ((rc = dalloc(h, &dB, (size_t)(h->m_pad + 256) * ldb))) return rc;
+    hipError_t e0 = hipMemsetAsync(dB, 0, (size_t)(h->m_pad + 256) * ldb * sizeof(float), h->s0);
+    hipError_t e1 = hipMemcpy2DAsync(dB, ldb * sizeof(float), B, (size_t)nrhs * sizeof(float), (size_t)nrhs * sizeof(float),
+                                     h->m, hipMemcpyHostToDevice, h->s0);
+    if (e0 != hipSuccess || e1 != hipSuccess) { (void)hipFree(dB); return fail(h, MPQR_ERR_HIP, "copy-in failed"); }
+    rc = apply_qt_device(h, dB, ldb, nrhs);
+    if (!rc && solve) rc = back_substitute_device(h, dB, ldb, nrhs);
+    if (!rc) {
+        const int rows = solve ? h->n : h->m;
+        hipError_t e2 = hipMemcpy2DAsync(out, (size_t)nrhs * sizeof(float), dB, ldb * sizeof(float), (size_t)nrhs * sizeof(float),
+                                         rows, hipMemcpyDeviceToHost, h->s0);
+        hipError_t e3 = hipStreamSynchronize(h->s0);
+        if (e2 != hipSuccess || e3 != hipSuccess) rc = fail(h, MPQR_ERR_HIP, "copy-out failed");
+    }
+    (void)hipStreamSynchronize(h->s0);
+    (void)hipFree(dB);
+    return rc;
+}
+}  // namespace
+
+int mpqr_apply_qt_host(mpqr_handle_t h, float* B, int nrhs) { return ls_core(h, B, nrhs, B, false); }
+int mpqr_solve_ls_host(mpqr_handle_t h, const float* B, int nrhs, float* X) { return ls_core(h, B, nrhs, X, true); }
+
+int mpqr_qr_solver_f32(mpqr_handle_t h, const float* A, const float* b, float* x, int m, int n, int r) {
+    int rc = check_shape(h, m, n, r); if (rc) return rc;
+    if (!A || !b || !x) return fail(h, MPQR_ERR_INVALID, "null buffer");
+    mpqr_opts o; mpqr_default_opts(&o);
+    o.form_q = 0;                                             // Q is applied implicitly
+    if ((rc = mpqr_plan(h, m, n, r, &o))) return rc;
+    if ((rc = mpqr_set_matrix_host(h, A, n))) return rc;
+    if ((rc = mpqr_factor(h))) return rc;
+    return mpqr_solve_ls_host(h, b, 1, x);
+}
+
+int mpqr_dev_qr_solver(const float* A, const float* b, float* x, int m, int n) {
+    std::lock_guard<std::mutex> lk(g_default_mu);
+    if (!g_default) { int rc = mpqr_create(&g_default, 0); if (rc) return rc; }
+    return mpqr_qr_solver_f32(g_default, A, b, x, m, n, 128);
+}
+
 int mpqr_qr_factorization_f64(mpqr_handle_t h, double* A, double* Q, int m, int n) {
     int rc = check_shape(h, m, n, 1); if (rc) return rc;
     if (!A || !Q) return fail(h, MPQR_ERR_INVALID, "NULL argument");

@@ -990,6 +990,49 @@ void launch_t_merge(const float* S, int ldl, int ldr, const float* TL, const flo
     hipLaunchKernelGGL(t_merge_kernel, dim3(1), dim3(1024), 2 * TP * TPS * 4, s, S, ldl, ldr, TL, TR, TLR);
 }
 
+// Back substitution, one diagonal block: X[k0:k0+kb] = R[k0:k0+kb, k0:k0+kb]^-1 Y[k0:k0+kb]  (kb <= 128, R upper
+// triangular fp32 in the working matrix, Y in place, nrhs columns).  The block is inverted with tri_inverse_128
+// (a zero diagonal entry gives a zero row / column: x_i = 0) and applied as a small product out of LDS.
+__global__ __launch_bounds__(1024) void trsm_diag_kernel(const float* __restrict__ R, long ldr, int k0, int kb,
+                                                         float* __restrict__ Y, long ldy, int nrhs) {
+    float* Ss = (float*)gh_smem;             // [TP][TPS]
+    float* Ts = Ss + TP * TPS;               // [TP][TPS]
+    __shared__ float tdiag[TP];
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int q = 0; q < TP * TP / 1024; q++) {
+        const int e = tid + 1024 * q, i = e >> 7, j = e & 127;
+        float v = 0.f;
+        if (i < kb && j < kb && j >= i) v = R[(long)(k0 + i) * ldr + k0 + j];
+        if (i == j) { tdiag[i] = (i < kb) ? (v != 0.f ? 1.0f / v : 0.f) : 1.f; v = 0.f; }
+        Ss[i * TPS + j] = v;
+        Ts[i * TPS + j] = 0.f;
+    }
+    __syncthreads();
+    tri_inverse_128(Ss, tdiag, Ts, (kb + 31) / 32, tid);
+    // stage Y_k (kb x nrhs) in Ss (dead now), then X = Ts * Y
+    for (int c0 = 0; c0 < nrhs; c0 += 128) {
+        const int nc = min(128, nrhs - c0);
+        for (int e = tid; e < kb * nc; e += 1024) { const int i = e / nc, c = e % nc; Ss[i * TPS + c] = Y[(long)(k0 + i) * ldy + c0 + c]; }
+        __syncthreads();
+        for (int e = tid; e < kb * nc; e += 1024) {
+            const int i = e / nc, c = e % nc;
+            float x = 0.f;
+            for (int j = i; j < kb; j++) x = fmaf(Ts[i * TPS + j], Ss[j * TPS + c], x);
+            Y[(long)(k0 + i) * ldy + c0 + c] = x;
+        }
+        __syncthreads();
+    }
+}
+void launch_trsm_diag(const float* R, long ldr, int k0, int kb, float* Y, long ldy, int nrhs, hipStream_t s) {
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute((const void*)trsm_diag_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * TP * TPS * 4);
+        attr = true;
+    }
+    hipLaunchKernelGGL(trsm_diag_kernel, dim3(1), dim3(1024), 2 * TP * TPS * 4, s, R, ldr, k0, kb, Y, ldy, nrhs);
+}
+
 void launch_t_leaf(const float* S, int nslab, long slab_stride, int lds_, int a0, int c0, int c1, float* T, half_t* Th,
                    half_t* Tth, int ldt, hipStream_t s) {
     static bool attr = false;

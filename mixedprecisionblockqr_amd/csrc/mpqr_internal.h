@@ -77,6 +77,8 @@ void launch_leaf_gram_householder(const LeafArgs& a, double* Gp /* nwg x 16384 *
 void launch_t_leaf(const float* S, int nslab, long slab_stride, int lds_, int a0, int c0, int c1,
                    float* T, half_t* Th, half_t* Tth, int ldt, hipStream_t s);
 // assemble a parent T from its children and T_LR
+// one diagonal block of the back substitution R X = Y (in place in Y), kb <= 128
+void launch_trsm_diag(const float* R, long ldr, int k0, int kb, float* Y, long ldy, int nrhs, hipStream_t s);
 // T_LR = -T_L (S T_R), children of <= 128 reflectors: one workgroup, exact-f32 MFMA out of LDS
 void launch_t_merge(const float* S, int ldl, int ldr, const float* TL, const float* TR, float* TLR, hipStream_t s);
 void launch_t_assemble(float* T, half_t* Th, half_t* Tth, int ldt, int A0,

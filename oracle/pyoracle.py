@@ -121,6 +121,20 @@ def householder_qr(A):
     return Ao, Q, strip_R(Ao, m, n)
 
 
+def linear_least_square(A, y):
+    """python/linear_least_sqare.py:5-22 on top of the oracle's Householder QR: b = Q^T y (the reference's pinv(Q) y for
+    an orthogonal Q), then its back-substitution loop x_i = (b_i - sum_{k>i} R_ik x_k) / R_ii, here in fp64 on the fp32
+    factors.  The solution does not depend on the sign convention of R."""
+    m, n = A.shape
+    _, Q, R = householder_qr(A)
+    b = Q.astype(np.float64).T @ np.asarray(y, np.float64)
+    Rd = R[:n].astype(np.float64)
+    x = np.zeros(n)
+    for i in reversed(range(n)):
+        x[i] = (b[i] - Rd[i, i + 1:] @ x[i + 1:]) / Rd[i, i]
+    return x
+
+
 def block_qr(A, r, variant="dense", omp=False):
     """variant: 'dense' (h_block_qr), 'mixed' (fp16 Q accumulation emulation),
     'compact32' / 'compact16' (compact-WY restatement, fp32 / fp16-operand)."""

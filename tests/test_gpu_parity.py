@@ -306,6 +306,34 @@ def test_config3_synthetic_jacobian_through_the_file_format(mp, h, po, tmp_path)
     assert int(float(row[0])) == m and int(float(row[1])) == n and len(row) == 5
 
 
+@pytest.mark.parametrize("m,n,r", [(6, 4, 2), (60, 40, 16), (300, 200, 64), (1500, 700, 128), (2100, 2100, 128)])
+def test_least_squares_matches_oracle_and_lstsq(mp, h, po, m, n, r):
+    """f-3: x = R^-1 Q^T b with Q applied implicitly from V, T (dev_QR_Solver stub, linear_least_sqare.py:5-22)."""
+    rng = np.random.default_rng(5)
+    A = po.generate(m, n, seed=77)
+    A[np.arange(n), np.arange(n)] += 2.0                          # well conditioned: forward errors stay O(u)
+    y = rng.standard_normal(m).astype(np.float32)
+    x = mp.linear_least_square(A, y, r=r, handle=h)
+    Ad64, y64 = A.astype(np.float64), y.astype(np.float64)
+    x_ref = np.linalg.lstsq(Ad64, y64, rcond=None)[0]
+    # backward-stable solve at the factorisation's accuracy (1e-3): the residual is as small as the optimum allows
+    assert np.linalg.norm(Ad64 @ x - y64) <= np.linalg.norm(Ad64 @ x_ref - y64) + 2e-3 * (np.linalg.norm(Ad64, 2) * np.linalg.norm(x) + np.linalg.norm(y64))
+    if m >= 3 * n // 2:                                           # tall = well conditioned: the forward error stays O(1e-3) too
+        assert np.linalg.norm(x - x_ref) <= 5e-3 * np.linalg.norm(x_ref), np.linalg.norm(x - x_ref) / np.linalg.norm(x_ref)
+    if m <= 300:
+        x_or = po.linear_least_square(A, y)
+        assert np.linalg.norm(x - x_or) <= 5e-3 * np.linalg.norm(x_or)
+    # the residual is orthogonal to range(A) (normal equations), several right-hand sides at once, Q^T b on its own
+    Y = rng.standard_normal((m, 3)).astype(np.float32)
+    X = mp.solve_ls(Y, handle=h)
+    Ad = A.astype(np.float64)
+    res = Ad @ X - Y
+    assert np.linalg.norm(Ad.T @ res) <= 5e-3 * np.linalg.norm(Ad) * np.linalg.norm(Y)
+    QtY = mp.apply_qt(Y, handle=h)
+    assert abs(np.linalg.norm(QtY) - np.linalg.norm(Y)) <= 2e-3 * np.linalg.norm(Y)          # Q^T is orthogonal
+    assert np.linalg.norm(QtY[n:] ) <= np.linalg.norm(res) * (1 + 5e-2) + 1e-3 * np.linalg.norm(Y)
+
+
 def test_cpp_main_path_fp64(mp, h, po, golden):
     """a-10: qr_factorization (C++/main.cpp:16-43) in fp64 on the GPU vs the real reference's outputs."""
     for name in golden["cppmain_names"]:
