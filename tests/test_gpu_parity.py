@@ -334,6 +334,28 @@ def test_least_squares_matches_oracle_and_lstsq(mp, h, po, m, n, r):
     assert np.linalg.norm(QtY[n:] ) <= np.linalg.norm(res) * (1 + 5e-2) + 1e-3 * np.linalg.norm(Y)
 
 
+@pytest.mark.parametrize("n,cond", [(10, 1e3), (100, 1e5), (100, 1e7), (500, 1e7)])
+def test_precision_study_points(mp, h, n, cond):
+    """f-4: the reference's error-vs-condition experiment (python/performance_test_result/error.md) on three paths; its
+    fp16 column is NaN from condition 1e6 on, the mixed path here must stay at fp16 operand accuracy for every condition."""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location("precision_study", os.path.join(os.path.dirname(__file__), "..", "tools", "precision_study.py"))
+    ps = importlib.util.module_from_spec(spec); spec.loader.exec_module(ps)
+    A = ps.spd_with_condition(n, cond, np.random.default_rng(11))
+    assert 0.3 * cond <= np.linalg.cond(A) <= 3.0 * cond
+    A32 = A.astype(np.float32)
+    r = min(32, n)
+    for fn, tol in ((mp.dev_mixed_precision_block_qr, 1e-3), (mp.dev_block_qr_wy, 1e-5)):
+        Ao = np.zeros((n + 1, n), np.float32); Ao[:n] = A32
+        Q = np.zeros((n, n), np.float32)
+        fn(Ao, Q, n, n, r, handle=h)
+        e = ps.backward_error(A32, Q, mp.h_strip_R_from_A(Ao, n, n))
+        assert np.isfinite(e) and e <= tol, (fn.__name__, e)
+    Q64, R64 = mp.qr_factorization(A, handle=h)
+    assert ps.backward_error(A, Q64, R64) <= 1e-12
+
+
 def test_cpp_main_path_fp64(mp, h, po, golden):
     """a-10: qr_factorization (C++/main.cpp:16-43) in fp64 on the GPU vs the real reference's outputs."""
     for name in golden["cppmain_names"]:
