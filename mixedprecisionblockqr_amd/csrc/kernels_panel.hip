@@ -473,9 +473,6 @@ __device__ __forceinline__ void tri_inverse_128(float* Ss, const float* tdiag, f
 // The coefficient matrix (V_low = A_low C) needs no update in the loop: with M the running column map,
 // C[:,k] = M[:,k] inv_k and M[:,j] = e_j - sum_{k<j} C[:,k] w^(k)_j, i.e. C (D^-1 + W) = I with W[k][j] = w^(k)_j
 // strictly upper and D = diag(inv): one triangular inverse after the loop (MFMA merges, tri_inverse_128).
-#ifndef TRACE_TID
-#define TRACE_TID 0
-#endif
 constexpr int SR = 8, SC = 4;
 constexpr int GH_UPD_THREADS = 512, GH_SOLVE_THREADS = 768;
 struct GhVecA { double c[GW], c1[GW], c2[GW]; };                    // Cholesky row: natural, by-column-block, by-row-block order
@@ -485,8 +482,7 @@ struct GhPreB { float B[GW], C[GW]; };                              // a row and
 __device__ __forceinline__ int gh_p1(int i) { return (i & 31) * 4 + (i >> 5); }   // thread tj reads entries tj + 32y contiguously
 __device__ __forceinline__ int gh_p2(int i) { return (i & 15) * 8 + (i >> 4); }   // thread ti reads entries ti + 16x contiguously
 __global__ __launch_bounds__(GH_SOLVE_THREADS) void gh_solve_kernel(LeafArgs a, const double* __restrict__ G,
-                                                                    float* __restrict__ Cv, int* __restrict__ flag, int trace) {
-    (void)trace;
+                                                                    float* __restrict__ Cv, int* __restrict__ flag) {
     float* Ws = (float*)gh_smem;                          // [TP][TPS]: row k = w^(k)
     float* Ts = Ws + TP * TPS;                            // [TP][TPS]: final columns of the top block, then the inverse
     __shared__ double col0[GW], nuv[GW];
@@ -850,9 +846,7 @@ void launch_leaf_gram_householder(const LeafArgs& a, double* Gp, double* G, floa
     const int nwg = (a.mrows - a.c0 + GH_ROWS - 1) / GH_ROWS;
     hipLaunchKernelGGL(gh_gram_kernel, dim3(2 * nwg), dim3(256), GH_ROWS * GH_TD * 8, s, a, Gp);
     hipLaunchKernelGGL(gh_reduce_kernel, dim3(256), dim3(256), 0, s, Gp, nwg, G);
-    static int trace_left = []() { const char* e = getenv("MPQR_TRACE"); return e ? atoi(e) : 0; }();
-    const int trace = trace_left > 0 ? (trace_left--, 1) : 0;
-    hipLaunchKernelGGL(gh_solve_kernel, dim3(1), dim3(GH_SOLVE_THREADS), 2 * TP * TPS * 4, s, a, G, Cv, flag, trace);
+    hipLaunchKernelGGL(gh_solve_kernel, dim3(1), dim3(GH_SOLVE_THREADS), 2 * TP * TPS * 4, s, a, G, Cv, flag);
     const int nlow = (a.mrows - a.c1 + 63) / 64;
     const int ntop = Sp ? (a.c1 - a.c0 + 63) / 64 : 0;      // extra workgroups: Gram contribution of the top block
     if (nlow + ntop == 0) return;
