@@ -27,9 +27,35 @@ PEAK_FP16_TFLOPS = 2500.0   # MI355X dense fp16 MFMA (MI355X_MICROARCH.md, chip-
 PEAK_HBM_GBPS = 8000.0      # HBM3E, same table
 
 
-def cpu_baseline(budget_s=20.0):
-    """The CPU oracle's compact-WY block loop (oracle/oracle_qr.c, OpenMP over trailing columns) timed on this
-    box's host cores on a bounded sample of the same workload family: 2048 x 2048, r = 64."""
+def cpu_baseline():
+    """The reference's CPU path timed on this box's host cores in the same run (north star / BASELINE.md section 4):
+    the REAL C++/main.cpp:16-43 qr_factorization (oracle/_ref/libref_cppmain.so, built from the reference tree with its
+    vendored Eigen; explicit m x m H per column, O(n^4), fp64, one thread) on a bounded sample of the same workload
+    family -- 256 x 256 (BASELINE config 1) and 384 x 384, U[0,1) seed 1234.  If that library did not travel to this
+    box the builder's own port is the only line (kind "port")."""
+    import numpy as np
+    from oracle import pyoracle as po
+    import mixedprecisionblockqr_amd as mp
+    port = cpu_baseline_port()
+    if po.ref_lib() is None:
+        return port, None
+    times = {}
+    for nn in (256, 384):
+        A = po.generate(nn, nn, seed=1234).astype(np.float64)
+        t0 = time.perf_counter()
+        Q, R = po.ref_qr_factorization(A)
+        times[nn] = time.perf_counter() - t0
+        err = float(np.linalg.norm(A - Q @ R) / np.linalg.norm(A))
+    nn = 384
+    ref = {"value": mp.flops(nn, nn, 32)["geqrf"] / times[nn] / 1e9, "unit": "GFLOP/s", "cores": 1, "kind": "reference",
+           "sample": f"C++/main.cpp qr_factorization (explicit H, fp64, Eigen 3.4.0, 1 thread): 256x256 in {times[256]:.2f} s, "
+                     f"384x384 in {times[384]:.2f} s (value quoted on 384x384, GEQRF-equivalent flops; ||A-QR||/||A|| = {err:.1e})"}
+    return ref, port
+
+
+def cpu_baseline_port():
+    """Second CPU line: the oracle's compact-WY block loop (oracle/oracle_qr.c, OpenMP over trailing columns), all host
+    cores of this job's share, 2048 x 2048, r = 64 (BASELINE config 2)."""
     import numpy as np
     from oracle import pyoracle as po
     import mixedprecisionblockqr_amd as mp
@@ -148,14 +174,16 @@ def main():
                    "outer_block": args.outer_block or 1024, "parallelism": "1 gpu"},
         "error": {"backward_error": mt["backward_error"], "q_error_fro": mt["q_error_fro"],
                   "q_error_max_signed": mt["q_error_max_signed"]},
-        "breakdown_ms": {k: tm[k] for k in ("ms_total", "ms_factor", "ms_form_q", "ms_trailing", "ms_panel",
-                                            "ms_far_tn", "ms_far_nn")},
+        "breakdown_ms": {k: tm[k] for k in ("ms_total", "ms_factor", "ms_form_q", "ms_trailing", "ms_panel", "ms_chain_wait",
+                                            "ms_far_tn", "ms_far_nn", "n_passes", "n_robust_leaves")},
         "gflops_with_q_flops": (fl["geqrf"] + fl["form_q"]) / dt / 1e9,
         "gflops_reference_formula": (4.0 * m * m * n - m * n * n + n ** 3 / 3.0) / dt / 1e9,
         "roofline": roof,
     }
     if not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline()
+        out["cpu_baseline"], port = cpu_baseline()
+        if port is not None:
+            out["cpu_baseline_port"] = port
     print(json.dumps(out))
 
 

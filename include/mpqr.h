@@ -71,13 +71,17 @@ typedef struct mpqr_timings {
     float ms_factor;      /* panels + trailing updates                                              */
     float ms_form_q;      /* backward accumulation of Q                                             */
     float ms_trailing;    /* sum over the far trailing updates (3 GEMM launches each)               */
-    float ms_panel;       /* ms_factor - ms_trailing: leaves, in-block updates, T merges            */
+    float ms_panel;       /* the panel chain timed on its own stream: leaves, in-block updates, T merges
+                             (with look-ahead the far updates overlap it on the second stream)       */
     float ms_far_tn;      /* sum over the far  X = A2^T V       launches (K = rows)                 */
     float ms_far_nn;      /* sum over the far  A2 -= V Y^T      launches (K = outer_block)          */
     int   n_far_launches; /* number of far updates (each = one tn + one small + one nn launch)      */
     double flops_far_tn;  /* flops executed by the tn launches (2 M N K each)                       */
     double flops_far_nn;  /* flops executed by the nn launches                                      */
-    int   reserved[8];
+    float ms_chain_wait;  /* ms_factor - ms_panel: the chain stream waiting for far updates of its columns      */
+    int   n_passes;       /* block-loop passes of the last mpqr_factor (> 1: flagged leaves were redone)          */
+    int   n_robust_leaves;/* tall leaves factored on the column-by-column (robust) kernels in the last pass       */
+    int   reserved[5];
 } mpqr_timings;
 
 typedef struct mpqr_handle_s* mpqr_handle_t;
@@ -127,7 +131,8 @@ int mpqr_metrics_device(mpqr_handle_t h, mpqr_metrics* out);
 /* ---------------- stage-level entry points (parity tests) ---------------- */
 /* replaces h_householder_qr(float* A,int m,int n,int global_offset,int panel_width)  Cuda/qr.cu:198-293
  * A: host (m+1) x n, factored in place on the GPU (columns [go, go+pw) only) */
-int mpqr_householder_qr_f32(mpqr_handle_t h, float* A, int m, int n, int global_offset, int panel_width);
+int mpqr_householder_qr_f32(mpqr_handle_t h, float* A, int m, int n, int global_offset, int panel_width,
+                            int precision /* MPQR_PREC_FP32 = the reference's arithmetic; FP16: in-panel updates on the fp16 MFMA path */);
 /* replaces h_wy_transform / dev_wy_transform  Cuda/qr.cu:337-426, :535-600.
  * Compact form: T (pw x pw, row-major, upper) of Q_panel = I - V T V^T built from the reflectors
  * stored in A.  If Qpanel != NULL also returns the dense (m-go)^2 matrix the reference materialises. */
@@ -135,7 +140,7 @@ int mpqr_wy_transform_f32(mpqr_handle_t h, const float* A, int m, int n, int glo
                           float* T, float* Qpanel);
 /* replaces h_q_backward_accumulation(float* h_A, float** h_Q, int m, int n)  Cuda/qr.cu:296-335
  * (Q is caller-allocated, m x m) */
-int mpqr_q_backward_accumulation_f32(mpqr_handle_t h, const float* A, float* Q, int m, int n);
+int mpqr_q_backward_accumulation_f32(mpqr_handle_t h, const float* A, float* Q, int m, int n, int precision);
 /* replaces the trailing update  A[l:,tau:] <- Q_panel^T A[l:,tau:]
  *   shared_mem_mmult_in_place_transpose_a + dev_cpy_strided_array  Cuda/mmult.cu:236-288, qr.cu:1098-1106
  * with the compact-WY MFMA apply, reflectors of columns [go, go+pw) taken from A itself */
@@ -143,6 +148,8 @@ int mpqr_apply_panel_to_trailing_f32(mpqr_handle_t h, float* A, int m, int n, in
                                      int precision);
 /* replaces h_backward_error / h_q_error / h_lower_trapezoid_error  Cuda/qr.cu:115-196 (host buffers) */
 int mpqr_metrics_f32(mpqr_handle_t h, const float* A, const float* R, const float* Q, int m, int n, mpqr_metrics* out);
+/* replaces h_q_error(float* Q, int m, ...)  Cuda/qr.cu:137-171 alone: fills q_error_max_signed and q_error_fro */
+int mpqr_q_error_f32(mpqr_handle_t h, const float* Q, int m, mpqr_metrics* out);
 /* pass criterion of the reference's testers: err <= 2^-precision_bits * m  (qr.cu:120,127) */
 int mpqr_error_passes(double err, int m, int precision_bits);
 

@@ -7,6 +7,9 @@
 //   * dev_wy_transform returned a device pointer to the dense (m-l)^2 Q_panel; the compact-WY T is what the
 //     build keeps, so the dense form is only available through h_wy_transform (host buffer, as in the reference).
 #pragma once
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <stdexcept>
 #include <string>
 
@@ -49,12 +52,13 @@ inline void dev_block_qr(float* A, float* Q, int m, int n, int r) { dev_block_qr
 
 // Cuda/qr.cuh:85   void h_householder_qr(float* A, int m, int n, int global_offset, int panel_width)
 inline void h_householder_qr(float* A, int m, int n, int global_offset, int panel_width) {
-    mpqr_ref::check(mpqr_householder_qr_f32(mpqr_ref::handle(), A, m, n, global_offset, panel_width), "h_householder_qr");
+    // the reference function is pure fp32 (qr.cu:198-293): MPQR_PREC_FP32 keeps every in-panel product on the exact-f32 MFMA
+    mpqr_ref::check(mpqr_householder_qr_f32(mpqr_ref::handle(), A, m, n, global_offset, panel_width, MPQR_PREC_FP32), "h_householder_qr");
 }
 // Cuda/qr.cuh:88   void h_q_backward_accumulation(float* h_A, float** h_Q, int m, int n)   (callee mallocs *h_Q)
 inline void h_q_backward_accumulation(float* h_A, float** h_Q, int m, int n) {
     *h_Q = (float*)malloc((size_t)m * m * sizeof(float));
-    mpqr_ref::check(mpqr_q_backward_accumulation_f32(mpqr_ref::handle(), h_A, *h_Q, m, n), "h_q_backward_accumulation");
+    mpqr_ref::check(mpqr_q_backward_accumulation_f32(mpqr_ref::handle(), h_A, *h_Q, m, n, MPQR_PREC_FP32), "h_q_backward_accumulation");
 }
 // Cuda/qr.cuh:90   void h_wy_transform(float* h_A, float** h_Q, int m, int n, int global_offset, int panel_width)
 inline void h_wy_transform(float* h_A, float** h_Q, int m, int n, int global_offset, int panel_width) {
@@ -78,9 +82,8 @@ inline float h_backward_error(float* A, float* R, float* Q, int m, int n, int pr
     return (float)mt.backward_error;
 }
 inline float h_q_error(float* Q, int m, int precision_bits) {
-    // reference computes max signed entry of Q^T Q - I (qr.cu:137-171); the metric kernel needs A and R too, so
-    // pass Q as both (A = R = Q is only used for the unrelated backward-error slot)
-    mpqr_metrics mt; mpqr_ref::check(mpqr_metrics_f32(mpqr_ref::handle(), Q, Q, Q, m, m, &mt), "h_q_error");
+    // max signed entry of Q^T Q - I (qr.cu:137-171)
+    mpqr_metrics mt; mpqr_ref::check(mpqr_q_error_f32(mpqr_ref::handle(), Q, m, &mt), "h_q_error");
     printf("||QT @ Q - Im|| = %E Error Criteria: %s\n", mt.q_error_max_signed,
            mpqr_error_passes(mt.q_error_max_signed, m, precision_bits) ? "True" : "False: should be less than ");
     return (float)mt.q_error_max_signed;

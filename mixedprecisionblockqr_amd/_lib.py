@@ -30,7 +30,8 @@ class MpqrTimings(C.Structure):
     _fields_ = [("ms_total", C.c_float), ("ms_factor", C.c_float), ("ms_form_q", C.c_float),
                 ("ms_trailing", C.c_float), ("ms_panel", C.c_float), ("ms_far_tn", C.c_float),
                 ("ms_far_nn", C.c_float), ("n_far_launches", C.c_int), ("flops_far_tn", C.c_double),
-                ("flops_far_nn", C.c_double), ("reserved", C.c_int * 8)]
+                ("flops_far_nn", C.c_double), ("ms_chain_wait", C.c_float), ("n_passes", C.c_int),
+                ("n_robust_leaves", C.c_int), ("reserved", C.c_int * 5)]
 
 
 def build(force=False):
@@ -66,11 +67,12 @@ SIGNATURES = {
     "mpqr_get_q_host": (_i, [_H, _f32]),
     "mpqr_get_r_host": (_i, [_H, _f32]),
     "mpqr_metrics_device": (_i, [_H, C.POINTER(MpqrMetrics)]),
-    "mpqr_householder_qr_f32": (_i, [_H, _f32, _i, _i, _i, _i]),
+    "mpqr_householder_qr_f32": (_i, [_H, _f32, _i, _i, _i, _i, _i]),
     "mpqr_wy_transform_f32": (_i, [_H, _f32, _i, _i, _i, _i, _p, _p]),
-    "mpqr_q_backward_accumulation_f32": (_i, [_H, _f32, _f32, _i, _i]),
+    "mpqr_q_backward_accumulation_f32": (_i, [_H, _f32, _f32, _i, _i, _i]),
     "mpqr_apply_panel_to_trailing_f32": (_i, [_H, _f32, _i, _i, _i, _i, _i]),
     "mpqr_metrics_f32": (_i, [_H, _f32, _f32, _f32, _i, _i, C.POINTER(MpqrMetrics)]),
+    "mpqr_q_error_f32": (_i, [_H, _f32, _i, C.POINTER(MpqrMetrics)]),
     "mpqr_error_passes": (_i, [_d, _i, _i]),
     "mpqr_qr_factorization_f64": (_i, [_H, _f64, _f64, _i, _i]),
     "mpqr_apply_qt_host": (_i, [_H, _f32, _i]),

@@ -128,12 +128,14 @@ def _block_qr(A, Q, m, n, r, precision, handle, **kw):
         assert Q.dtype == np.float32 and Q.shape == (m, m) and Q.flags.c_contiguous
         qp = Q.ctypes.data_as(C.c_void_p)
     h._chk(L.lib().mpqr_block_qr_f32(h._h, A, qp, m, n, r, C.byref(o)))
+    h.m, h.n, h.r = m, n, r                                   # the call planned the handle for this shape
 
 
-def h_householder_qr(A, m, n, global_offset, panel_width, handle=None):
-    """Cuda/qr.cu:198 semantics, executed on the GPU.  A: (m+1) x n, in place."""
+def h_householder_qr(A, m, n, global_offset, panel_width, handle=None, precision=L.PREC_FP32):
+    """Cuda/qr.cu:198 semantics, executed on the GPU.  A: (m+1) x n, in place.  The reference function is pure fp32,
+    so is the default here (PREC_FP16 runs the in-panel updates of panels wider than one leaf on the fp16 MFMA path)."""
     h = handle or default_handle()
-    h._chk(L.lib().mpqr_householder_qr_f32(h._h, A, m, n, global_offset, panel_width))
+    h._chk(L.lib().mpqr_householder_qr_f32(h._h, A, m, n, global_offset, panel_width, int(precision)))
 
 
 def wy_transform(A, m, n, global_offset, panel_width, dense=False, handle=None):
@@ -147,12 +149,21 @@ def wy_transform(A, m, n, global_offset, panel_width, dense=False, handle=None):
     return (T, Qp) if dense else T
 
 
-def h_q_backward_accumulation(A, m, n, handle=None):
-    """Cuda/qr.cu:296.  Returns Q (m x m) from the reflectors stored in A ((m+1) x n)."""
+def h_q_backward_accumulation(A, m, n, handle=None, precision=L.PREC_FP32):
+    """Cuda/qr.cu:296 (pure fp32 in the reference, the default here).  Returns Q (m x m) from the reflectors stored in A ((m+1) x n)."""
     h = handle or default_handle()
     Q = np.empty((m, m), np.float32)
-    h._chk(L.lib().mpqr_q_backward_accumulation_f32(h._h, np.ascontiguousarray(A, np.float32), Q, m, n))
+    h._chk(L.lib().mpqr_q_backward_accumulation_f32(h._h, np.ascontiguousarray(A, np.float32), Q, m, n, int(precision)))
     return Q
+
+
+def h_q_error(Q, handle=None):
+    """Cuda/qr.cu:137-171: max signed entry of Q^T Q - I (and its Frobenius norm)."""
+    h = handle or default_handle()
+    Q = np.ascontiguousarray(Q, np.float32)
+    mt = L.MpqrMetrics()
+    h._chk(L.lib().mpqr_q_error_f32(h._h, Q, Q.shape[0], C.byref(mt)))
+    return {"q_error_max_signed": mt.q_error_max_signed, "q_error_fro": mt.q_error_fro}
 
 
 def apply_panel_to_trailing(A, m, n, global_offset, panel_width, precision=L.PREC_FP16, handle=None):
@@ -247,7 +258,7 @@ def write_euroc_jacobian(path, M):
         raise MpqrError(rc, f"cannot write {path}")
 
 
-def synthetic_jacobian(cams=40, points=580, views=2, seed=1234, outliers=8):
+def synthetic_jacobian(cams=40, points=580, views=2, seed=1234, outliers=8, rank_deficiency=0):
     """Stand-in for a EuRoC bundle-adjustment Jacobian (BASELINE config 3; the reference's real files are an
     absent LFS blob): one 2-row block per observation with a dense 2x6 camera block and a dense 2x3 point block,
     everything else zero.  Values ~ N(0, 1) with a few large entries (1e3 .. 1e5) that would overflow fp16 without the
@@ -267,6 +278,15 @@ def synthetic_jacobian(cams=40, points=580, views=2, seed=1234, outliers=8):
     i, j = np.unravel_index(np.argmax(np.abs(M)), M.shape)
     if abs(M[i, j]) <= 65504.0:                                # at least one entry beyond the fp16 range
         M[i, j] = np.sign(M[i, j]) * 1.3e5
+    if rank_deficiency:
+        # gauge freedom of a real bundle-adjustment Jacobian (7 for a free similarity transform) as exactly dependent
+        # columns: camera column 12q+7 becomes a combination of camera columns 12q+2 and 12q+9, so rank = n - rank_deficiency.
+        # All of them lie in the first 128-column leaf: a dependency INSIDE a tall leaf is what the Gram-Householder
+        # leaf cannot resolve (cond^2 in its Gram matrix) and must hand to the column-by-column kernels; a dependency
+        # across leaves is reduced by the trailing updates first and arrives as a small, harmless column.
+        assert rank_deficiency <= 10 and 6 * cams >= 128
+        for q in range(rank_deficiency):
+            M[:, 12 * q + 7] = 0.5 * M[:, 12 * q + 2] - 0.25 * M[:, 12 * q + 9]
     return M
 
 

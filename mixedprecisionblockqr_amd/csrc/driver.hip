@@ -24,6 +24,8 @@
 #include <algorithm>
 #include <mutex>
 
+#include <rocprofiler-sdk-roctx/roctx.h>
+
 #include "mpqr_internal.h"
 
 using namespace mpqr;
@@ -36,6 +38,13 @@ struct Node {
     int ldt;           // a1 - a0
     int left, right;   // children or -1
     size_t toff;       // offset into the T arenas (elements)
+};
+
+// roctx range over the host-side enqueue of one phase (the reference brackets h_householder_qr, h_wy_transform,
+// dev_wy_transform and the WMMA GEMM launcher with NVTX ranges: Cuda/qr.cu:207,292,339,425,536,599, mmult.cuh:324,383)
+struct Range {
+    explicit Range(const char* name) { roctxRangePushA(name); }
+    ~Range() { roctxRangePop(); }
 };
 
 inline int rdown(int x, int a) { return (x / a) * a; }
@@ -72,7 +81,11 @@ struct mpqr_handle_s {
     float* P = nullptr;    int maxwg = 0;
     double* Gp = nullptr; double* Gs = nullptr; float* Cv = nullptr; int* dflag = nullptr;   // Gram-Householder leaf workspace
     float* Sp = nullptr;          // per-workgroup partial Grams of the fp16 reflectors (fused into gh_apply)
-    bool robust = false;          // true: tall leaves are factored column by column instead of by Gram-Householder
+    bool robust = false;          // true: EVERY tall leaf is factored column by column instead of by Gram-Householder
+    std::vector<char> leaf_robust;   // per tree node: this tall leaf was flagged by gh_solve and takes the robust path
+    int nflag = 0;                // ints in dflag: one flag per tree node (gh_solve raises dflag[node id])
+    int n_passes = 0, n_robust_leaves = 0;   // of the last mpqr_factor
+    float* rbTf = nullptr; half_t* rbTh = nullptr; half_t* rbTth = nullptr; size_t rb_elems = 0;   // T arena of a robust leaf's sub-tree
     bool force32 = false;         // tree building: only 32-column leaves (sub-tree of a robustly factored tall leaf)
     int gh_min_rows = 128;        // leaves with more rows than this below their first column use Gram-Householder
     float* tmp1 = nullptr; float* tmp2 = nullptr; size_t tmp_elems = 0;
@@ -93,8 +106,11 @@ struct mpqr_handle_s {
 
     // timing
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
-    std::vector<hipEvent_t> far_ev;   // pairs around far op1 / op3 launches
+    std::vector<hipEvent_t> far_ev;   // pool, 4 per recorded far update: around op1 / op3
+    size_t far_used = 0;
     std::vector<double> far_flops;
+    std::vector<hipEvent_t> chain_ev; // pool, 2 per top-level block: around factor_node on the chain stream
+    size_t chain_used = 0;
     mpqr_timings last_t;
 };
 
@@ -132,13 +148,17 @@ int dalloc(mpqr_handle_t h, T** p, size_t elems) {
 
 void free_plan(mpqr_handle_t h) {
     void* ptrs[] = {h->dA, h->dA0, h->dQ, h->Vh, h->Vt, h->vdiag, h->Xt, h->Yt, h->S, h->P, h->tmp1, h->tmp2,
-                    h->Tf, h->Th, h->Tth, h->dstage, h->Gp, h->Gs, h->Cv, h->dflag, h->Vf, h->Yf, h->Xt1, h->Yt1, h->Sp};
+                    h->Tf, h->Th, h->Tth, h->dstage, h->Gp, h->Gs, h->Cv, h->dflag, h->Vf, h->Yf, h->Xt1, h->Yt1, h->Sp,
+                    h->rbTf, h->rbTh, h->rbTth};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     h->dA = h->dA0 = h->dQ = nullptr; h->Vh = h->Vt = nullptr; h->vdiag = nullptr; h->Xt = nullptr; h->Yt = nullptr;
     h->S = nullptr; h->P = nullptr; h->tmp1 = h->tmp2 = nullptr; h->Tf = nullptr; h->Th = h->Tth = nullptr;
     h->dstage = nullptr; h->stage_elems = 0;
     h->Gp = nullptr; h->Gs = nullptr; h->Cv = nullptr; h->dflag = nullptr; h->Vf = nullptr; h->Yf = nullptr;
     h->Xt1 = nullptr; h->Yt1 = nullptr; h->Sp = nullptr;
+    h->rbTf = nullptr; h->rbTh = h->rbTth = nullptr; h->rb_elems = 0; h->nflag = 0; h->leaf_robust.clear();
+    for (hipEvent_t e : h->chain_ev) (void)hipEventDestroy(e);
+    h->chain_ev.clear(); h->chain_used = 0; h->far_used = 0;
     for (hipEvent_t e : h->ev_node) (void)hipEventDestroy(e);
     for (hipEvent_t e : h->ev_cols) (void)hipEventDestroy(e);
     h->ev_node.clear(); h->ev_cols.clear();
@@ -282,8 +302,10 @@ void apply_node(mpqr_handle_t h, const Node& nd, float* C, long ldc, int clo, in
     const int M1 = chi - clo_al;
     const int Kr = nd.ldt;
     hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr, e3 = nullptr;
+    if (record && h->far_used + 4 > h->far_ev.size()) record = false;      // pool exhausted (sized in plan_common)
     if (record) {
-        (void)hipEventCreate(&e0); (void)hipEventCreate(&e1); (void)hipEventCreate(&e2); (void)hipEventCreate(&e3);
+        e0 = h->far_ev[h->far_used]; e1 = h->far_ev[h->far_used + 1]; e2 = h->far_ev[h->far_used + 2]; e3 = h->far_ev[h->far_used + 3];
+        h->far_used += 4;
     }
     // op1: Xt[M1 x Kr] = (in_scale * C2)^T V
     GemmArgs g1{};
@@ -318,16 +340,17 @@ void apply_node(mpqr_handle_t h, const Node& nd, float* C, long ldc, int clo, in
     gemm_dispatch(A_H16, E_SUB_F32, g3, st);
     if (record) {
         (void)hipEventRecord(e3, st);
-        h->far_ev.push_back(e0); h->far_ev.push_back(e1); h->far_ev.push_back(e2); h->far_ev.push_back(e3);
         h->far_flops.push_back(2.0 * M1 * (double)Kr * Kw);
     }
 }
 
-void factor_node(mpqr_handle_t h, int id, bool do_panel);
+int factor_node(mpqr_handle_t h, int id, bool do_panel);
 
 // Robust path for a tall (<=128-column) leaf: factor it through a temporary sub-tree of 32-column leaves
-// (column-by-column kernels + MFMA updates inside the leaf) and keep only the sub-tree's root T.
-void robust_tall_leaf(mpqr_handle_t h, const Node nd, bool do_panel) {
+// (column-by-column kernels + MFMA updates inside the leaf) and keep only the sub-tree's root T.  The sub-tree's T
+// arena is part of the plan (rbTf/rbTh/rbTth): no allocation, no host synchronisation here.
+int robust_tall_leaf(mpqr_handle_t h, const Node nd, bool do_panel) {
+    Range rg("mpqr:robust_leaf");
     std::vector<Node> saved_nodes = h->nodes; std::vector<int> saved_tops = h->tops;
     float* oTf = h->Tf; half_t* oTh = h->Th; half_t* oTth = h->Tth;
     h->nodes.clear(); h->tops.clear();
@@ -335,40 +358,40 @@ void robust_tall_leaf(mpqr_handle_t h, const Node nd, bool do_panel) {
     const int root = build_tree(h, nd.c0, nd.c1);
     size_t toff = 0;
     for (Node& x : h->nodes) { x.toff = toff; toff += (size_t)x.ldt * x.ldt; }
-    float* Tf = nullptr; half_t* Th = nullptr; half_t* Tth = nullptr;
-    const size_t pad = (size_t)256 * 128;
-    if (hipMalloc((void**)&Tf, (toff + pad) * sizeof(float)) == hipSuccess &&
-        hipMalloc((void**)&Th, (toff + pad) * sizeof(half_t)) == hipSuccess &&
-        hipMalloc((void**)&Tth, (toff + pad) * sizeof(half_t)) == hipSuccess) {
-        (void)hipMemsetAsync(Th, 0, (toff + pad) * sizeof(half_t), h->s0);
-        (void)hipMemsetAsync(Tth, 0, (toff + pad) * sizeof(half_t), h->s0);
-        h->Tf = Tf; h->Th = Th; h->Tth = Tth;
-        factor_node(h, root, do_panel);
+    int rc = MPQR_OK;
+    if (!h->rbTf || toff > h->rb_elems) rc = fail(h, MPQR_ERR_STATE, "robust-leaf T arena missing or too small");
+    else {
+        h->Tf = h->rbTf; h->Th = h->rbTh; h->Tth = h->rbTth;
+        rc = factor_node(h, root, do_panel);
         const Node rt = h->nodes[root];
         const size_t el = (size_t)rt.ldt * rt.ldt;      // same aligned range as nd
-        (void)hipMemcpyAsync(oTf + nd.toff, Tf + rt.toff, el * sizeof(float), hipMemcpyDeviceToDevice, h->s0);
-        (void)hipMemcpyAsync(oTh + nd.toff, Th + rt.toff, el * sizeof(half_t), hipMemcpyDeviceToDevice, h->s0);
-        (void)hipMemcpyAsync(oTth + nd.toff, Tth + rt.toff, el * sizeof(half_t), hipMemcpyDeviceToDevice, h->s0);
-        (void)hipStreamSynchronize(h->s0);
+        if (hipMemcpyAsync(oTf + nd.toff, h->rbTf + rt.toff, el * sizeof(float), hipMemcpyDeviceToDevice, h->s0) != hipSuccess ||
+            hipMemcpyAsync(oTh + nd.toff, h->rbTh + rt.toff, el * sizeof(half_t), hipMemcpyDeviceToDevice, h->s0) != hipSuccess ||
+            hipMemcpyAsync(oTth + nd.toff, h->rbTth + rt.toff, el * sizeof(half_t), hipMemcpyDeviceToDevice, h->s0) != hipSuccess)
+            rc = fail(h, MPQR_ERR_HIP, "robust leaf: copying the root T failed");
     }
-    if (Tf) (void)hipFree(Tf); if (Th) (void)hipFree(Th); if (Tth) (void)hipFree(Tth);
     h->force32 = false;
     h->Tf = oTf; h->Th = oTh; h->Tth = oTth;
     h->nodes = saved_nodes; h->tops = saved_tops;
+    return rc;
 }
 
-void factor_node(mpqr_handle_t h, int id, bool do_panel) {
+int factor_node(mpqr_handle_t h, int id, bool do_panel) {
     const Node nd = h->nodes[id];
+    int rc;
     if (nd.left < 0) {
-        if (do_panel && h->robust && !h->force32 && leaf_width(h, nd.c0) == 128) { robust_tall_leaf(h, nd, do_panel); return; }
+        const bool tall = leaf_width(h, nd.c0) == 128;
+        const bool robust_leaf = h->robust || (id < (int)h->leaf_robust.size() && h->leaf_robust[id]);
+        if (do_panel && robust_leaf && !h->force32 && tall) return robust_tall_leaf(h, nd, do_panel);
         if (do_panel) {
+            Range rg("mpqr:panel");
             LeafArgs a{};
-            const bool tall = leaf_width(h, nd.c0) == 128;
             a.A = h->Aeff; a.lda = h->lda; a.mrows = h->m; a.cb = rdown(nd.c0, tall ? 128 : 32); a.c0 = nd.c0; a.c1 = nd.c1;
             a.Vh = h->Vh; a.ldvh = h->ldvh; a.Vt = h->Vt; a.ldvt = h->ldvt; a.vdiag = h->vdiag;
             a.P = h->P; a.maxwg = h->maxwg;
             const bool fused = tall && !h->Vf;    // fp16 mode: the Gram of the rounded reflectors comes out of gh_apply
-            if (tall) launch_leaf_gram_householder(a, h->Gp, h->Gs, h->Cv, h->dflag, fused ? h->Sp : nullptr, h->S, h->s0);
+            int* flag = h->dflag + (id < h->nflag ? id : 0);
+            if (tall) launch_leaf_gram_householder(a, h->Gp, h->Gs, h->Cv, flag, fused ? h->Sp : nullptr, h->S, h->s0);
             else launch_leaf_factor(a, h->s0);
             if (h->Vf) launch_extract_vf(h->Aeff, h->lda, h->vdiag, h->Vf, h->n_pad, h->m, nd.c0, nd.c1, h->s0);
             if (fused) {
@@ -376,27 +399,32 @@ void factor_node(mpqr_handle_t h, int id, bool do_panel) {
                 const int sh = nd.a0 - a.cb;
                 launch_t_leaf(h->S + (long)sh * 128 + sh, 1, 0, 128, nd.a0, nd.c0, nd.c1, h->Tf + nd.toff, h->Th + nd.toff,
                               h->Tth + nd.toff, nd.ldt, h->s0);
-                return;
+                return MPQR_OK;
             }
         }
+        Range rg("mpqr:wy_T");
         int nslab; long slab;
         gram(h, nd, nd, &nslab, &slab);
         launch_t_leaf(h->S, nslab, slab, nd.ldt, nd.a0, nd.c0, nd.c1, h->Tf + nd.toff, h->Th + nd.toff, h->Tth + nd.toff,
                       nd.ldt, h->s0);
-        return;
+        return MPQR_OK;
     }
     const Node L = h->nodes[nd.left], R = h->nodes[nd.right];
-    factor_node(h, nd.left, do_panel);
-    if (do_panel) apply_node(h, L, h->Aeff, h->lda, R.c0, R.c1, true, h->a_scale, false);
-    factor_node(h, nd.right, do_panel);
+    if ((rc = factor_node(h, nd.left, do_panel))) return rc;
+    if (do_panel) {
+        Range rg("mpqr:in_block_update");
+        apply_node(h, L, h->Aeff, h->lda, R.c0, R.c1, true, h->a_scale, false);
+    }
+    if ((rc = factor_node(h, nd.right, do_panel))) return rc;
     // T_LR = -T_L (V_L^T V_R) T_R
+    Range rg("mpqr:wy_T_merge");
     int nslab; long slab;
     gram(h, L, R, &nslab, &slab);
     if (L.ldt <= 128 && R.ldt <= 128) {
         launch_t_merge(h->S, L.ldt, R.ldt, h->Tf + L.toff, h->Tf + R.toff, h->tmp2, h->s0);
         launch_t_assemble(h->Tf + nd.toff, h->Th + nd.toff, h->Tth + nd.toff, nd.ldt, nd.a0, h->Tf + L.toff, L.ldt, L.a0,
                           nd.c0, L.c1, h->Tf + R.toff, R.ldt, R.a0, nd.c1, h->tmp2, R.ldt, h->s0);
-        return;
+        return MPQR_OK;
     }
     SgemmArgs s1{};
     s1.A = h->S; s1.lda = R.ldt; s1.transA = 0; s1.nslab_a = nslab; s1.slab_a = slab;
@@ -412,6 +440,7 @@ void factor_node(mpqr_handle_t h, int id, bool do_panel) {
     launch_sgemm(s2, h->s0);
     launch_t_assemble(h->Tf + nd.toff, h->Th + nd.toff, h->Tth + nd.toff, nd.ldt, nd.a0, h->Tf + L.toff, L.ldt, L.a0,
                       nd.c0, L.c1, h->Tf + R.toff, R.ldt, R.a0, nd.c1, h->tmp2, R.ldt, h->s0);
+    return MPQR_OK;
 }
 
 int clear_reflectors(mpqr_handle_t h) {
@@ -440,6 +469,7 @@ int compute_scale(mpqr_handle_t h, const float* src) {
 }
 
 int form_q(mpqr_handle_t h) {
+    Range rg("mpqr:form_q");
     HIPCHK(h, hipMemsetAsync(h->dQ, 0, (size_t)h->m_pad * h->ldq * sizeof(float), h->s0));
     launch_set_identity(h->dQ, h->ldq, h->m, h->m, h->s0);
     for (int t = (int)h->tops.size() - 1; t >= 0; t--) {
@@ -610,7 +640,19 @@ static int plan_common(mpqr_handle_t h, int m, int n, int r, const mpqr_opts* op
     if ((rc = dalloc(h, &h->Gs, (size_t)16384))) return rc;
     if ((rc = dalloc(h, &h->Sp, (size_t)(h->m_pad / 64 + 4) * 16384))) return rc;
     if ((rc = dalloc(h, &h->Cv, (size_t)16384))) return rc;
-    if ((rc = dalloc(h, &h->dflag, (size_t)4))) return rc;
+    h->nflag = (int)h->nodes.size() + 1024;               // one flag per tree node (+ room for the stage calls' private trees)
+    if ((rc = dalloc(h, &h->dflag, (size_t)h->nflag))) return rc;
+    h->leaf_robust.assign(h->nodes.size(), 0);
+    // T arena of a robustly factored tall leaf (sub-tree of 32-column leaves over <= 128 columns: 7 nodes, ldt <= 192)
+    h->rb_elems = (size_t)8 * 192 * 192;
+    if ((rc = dalloc(h, &h->rbTf, h->rb_elems + (size_t)256 * 256))) return rc;
+    if ((rc = dalloc(h, &h->rbTh, h->rb_elems + (size_t)256 * 256))) return rc;
+    if ((rc = dalloc(h, &h->rbTth, h->rb_elems + (size_t)256 * 256))) return rc;
+    HIPCHK(h, hipMemsetAsync(h->rbTh, 0, (h->rb_elems + (size_t)256 * 256) * sizeof(half_t), h->s0));
+    HIPCHK(h, hipMemsetAsync(h->rbTth, 0, (h->rb_elems + (size_t)256 * 256) * sizeof(half_t), h->s0));
+    // event pools (nothing is created inside the timed region): 2 recorded far updates per block, 2 chain events per block
+    for (size_t i = 0; i < 8 * h->tops.size() + 8; i++) { hipEvent_t e; HIPCHK(h, hipEventCreate(&e)); h->far_ev.push_back(e); }
+    for (size_t i = 0; i < 2 * h->tops.size() + 2; i++) { hipEvent_t e; HIPCHK(h, hipEventCreate(&e)); h->chain_ev.push_back(e); }
     if ((rc = dalloc(h, &h->dA0, (size_t)h->m_pad * h->lda + 1024))) return rc;
     if ((rc = dalloc(h, &h->tmp1, h->tmp_elems))) return rc;
     if ((rc = dalloc(h, &h->tmp2, h->tmp_elems))) return rc;
@@ -620,7 +662,7 @@ static int plan_common(mpqr_handle_t h, int m, int n, int r, const mpqr_opts* op
     HIPCHK(h, hipMemsetAsync(h->Th, 0, (h->t_elems + (size_t)256 * max_ldt) * sizeof(half_t), h->s0));
     HIPCHK(h, hipMemsetAsync(h->Tth, 0, (h->t_elems + (size_t)256 * max_ldt) * sizeof(half_t), h->s0));
     HIPCHK(h, hipMemsetAsync(h->dA0, 0, (size_t)h->m_pad * h->lda * sizeof(float), h->s0));
-    HIPCHK(h, hipMemsetAsync(h->dflag, 0, 4 * sizeof(int), h->s0));
+    HIPCHK(h, hipMemsetAsync(h->dflag, 0, (size_t)h->nflag * sizeof(int), h->s0));
     HIPCHK(h, hipMemsetAsync(h->dA, 0, (size_t)h->m_pad * h->lda * sizeof(float), h->s0));
     HIPCHK(h, hipMemsetAsync(h->dQ, 0, (size_t)h->m_pad * h->ldq * sizeof(float), h->s0));
     if ((rc = clear_reflectors(h))) return rc;
@@ -650,6 +692,7 @@ int mpqr_set_matrix_host(mpqr_handle_t h, const float* A, long ld) {
                                hipMemcpyHostToDevice, h->s0));
     HIPCHK(h, hipStreamSynchronize(h->s0));
     h->factored = false; h->q_formed = false; h->have_input = true; h->robust = false;
+    std::fill(h->leaf_robust.begin(), h->leaf_robust.end(), 0);
     return MPQR_OK;
 }
 
@@ -659,6 +702,7 @@ int mpqr_set_matrix_device(mpqr_handle_t h, const float* dA, long ld) {
     HIPCHK(h, hipMemcpy2DAsync(h->dA0, h->lda * sizeof(float), dA, ld * sizeof(float), (size_t)h->n * sizeof(float), h->m,
                                hipMemcpyDeviceToDevice, h->s0));
     h->factored = false; h->q_formed = false; h->have_input = true; h->robust = false;
+    std::fill(h->leaf_robust.begin(), h->leaf_robust.end(), 0);
     return MPQR_OK;
 }
 
@@ -666,17 +710,17 @@ int mpqr_generate_matrix(mpqr_handle_t h, uint64_t seed) {
     int rc = need_plan(h); if (rc) return rc;
     launch_generate(h->dA0, h->lda, h->m, h->n, seed, h->n, 1, 1, 0, h->s0);
     h->factored = false; h->q_formed = false; h->have_input = true; h->robust = false;
+    std::fill(h->leaf_robust.begin(), h->leaf_robust.end(), 0);
     return MPQR_OK;
 }
 
-// enqueue copy-in + the whole block loop; returns the leaf flag (1 = a Gram-Householder leaf was too ill-conditioned)
-static int run_block_loop(mpqr_handle_t h, int* flagged) {
+// enqueue copy-in + the whole block loop; flags[id] != 0: the Gram-Householder leaf `id` was too ill-conditioned
+static int run_block_loop(mpqr_handle_t h, std::vector<int>& flags) {
     int rc;
-    for (hipEvent_t e : h->far_ev) (void)hipEventDestroy(e);
-    h->far_ev.clear(); h->far_flops.clear();
+    h->far_used = 0; h->far_flops.clear(); h->chain_used = 0;
     HIPCHK(h, hipEventRecord(h->ev[0], h->s0));
     HIPCHK(h, hipMemcpyAsync(h->dA, h->dA0, (size_t)h->m_pad * h->lda * sizeof(float), hipMemcpyDeviceToDevice, h->s0));
-    HIPCHK(h, hipMemsetAsync(h->dflag, 0, sizeof(int), h->s0));
+    HIPCHK(h, hipMemsetAsync(h->dflag, 0, (size_t)h->nflag * sizeof(int), h->s0));
     if ((rc = clear_reflectors(h))) return rc;
     const bool la = h->Xt1 != nullptr;                    // look-ahead: far updates on s1, panel chain on s0
     if (la) {
@@ -686,13 +730,16 @@ static int run_block_loop(mpqr_handle_t h, int* flagged) {
     }
     for (size_t t = 0; t < h->tops.size(); t++) {
         const Node nd = h->nodes[h->tops[t]];
+        if (la && t > 0) HIPCHK(h, hipStreamWaitEvent(h->s0, h->ev_cols[t], 0));     // my columns carry all earlier updates
+        const bool timed = h->chain_used + 2 <= h->chain_ev.size();
+        if (timed) HIPCHK(h, hipEventRecord(h->chain_ev[h->chain_used], h->s0));
+        if ((rc = factor_node(h, h->tops[t], true))) return rc;
+        if (timed) { HIPCHK(h, hipEventRecord(h->chain_ev[h->chain_used + 1], h->s0)); h->chain_used += 2; }
+        Range rg("mpqr:far_update");
         if (!la) {
-            factor_node(h, h->tops[t], true);
             apply_node(h, nd, h->dA, h->lda, nd.c1, h->n, true, h->a_scale, true);
             continue;
         }
-        if (t > 0) HIPCHK(h, hipStreamWaitEvent(h->s0, h->ev_cols[t], 0));     // my columns carry all earlier updates
-        factor_node(h, h->tops[t], true);
         HIPCHK(h, hipEventRecord(h->ev_node[t], h->s0));
         HIPCHK(h, hipStreamWaitEvent(h->s1, h->ev_node[t], 0));
         if (t + 1 < h->tops.size()) {
@@ -707,11 +754,10 @@ static int run_block_loop(mpqr_handle_t h, int* flagged) {
         HIPCHK(h, hipStreamWaitEvent(h->s0, h->ev[3], 0));
     }
     HIPCHK(h, hipEventRecord(h->ev[1], h->s0));
-    int f = 0;
-    HIPCHK(h, hipMemcpyAsync(&f, h->dflag, sizeof(int), hipMemcpyDeviceToHost, h->s0));
+    flags.assign(h->nodes.size(), 0);
+    HIPCHK(h, hipMemcpyAsync(flags.data(), h->dflag, flags.size() * sizeof(int), hipMemcpyDeviceToHost, h->s0));
     HIPCHK(h, hipStreamSynchronize(h->s0));
     HIPCHK(h, hipGetLastError());
-    *flagged = f;
     return MPQR_OK;
 }
 
@@ -719,12 +765,22 @@ int mpqr_factor(mpqr_handle_t h) {
     int rc = need_plan(h); if (rc) return rc;
     if (!h->have_input) return fail(h, MPQR_ERR_STATE, "no input matrix has been set");
     if ((rc = compute_scale(h, h->dA0))) return rc;
-    int flagged = 0;
-    if ((rc = run_block_loop(h, &flagged))) return rc;
-    if (flagged && !h->robust) {          // ill-conditioned tall leaf: redo on the column-by-column panel kernels
-        h->robust = true;
-        if ((rc = run_block_loop(h, &flagged))) return rc;
+    // Gram-Householder leaves that gh_solve flags (a column that cannot be reflected, or rho < 1e-8) are redone on the
+    // column-by-column kernels: the pass is repeated with THOSE leaves on the robust path (results downstream of a flagged
+    // leaf are not trusted, so a pass can reveal further leaves); after three passes every tall leaf goes robust.
+    std::vector<int> flags;
+    h->n_passes = 0;
+    for (int pass = 0; pass < 5; pass++) {
+        h->n_passes++;
+        if ((rc = run_block_loop(h, flags))) return rc;
+        int fresh = 0;
+        for (size_t id = 0; id < flags.size(); id++)
+            if (flags[id] && !h->leaf_robust[id]) { h->leaf_robust[id] = 1; fresh++; }
+        if (!fresh || h->robust) break;
+        if (pass >= 2) h->robust = true;
     }
+    h->n_robust_leaves = 0;
+    for (char c : h->leaf_robust) h->n_robust_leaves += c ? 1 : 0;
     h->factored = true;
     if (h->opts.form_q) { if ((rc = form_q(h))) return rc; }
     HIPCHK(h, hipEventRecord(h->ev[2], h->s0));
@@ -750,27 +806,45 @@ int mpqr_get_timings(mpqr_handle_t h, mpqr_timings* t) {
     HIPCHK(h, hipEventElapsedTime(&t->ms_form_q, h->ev[1], h->ev[2]));
     t->ms_total = t->ms_factor + t->ms_form_q;
     double f = 0;
-    for (size_t i = 0; i + 3 < h->far_ev.size(); i += 4) {
-        float a = 0, b = 0;
+    float tr = 0;
+    for (size_t i = 0; i + 3 < h->far_used; i += 4) {
+        float a = 0, b = 0, x = 0;
         HIPCHK(h, hipEventElapsedTime(&a, h->far_ev[i], h->far_ev[i + 1]));
         HIPCHK(h, hipEventElapsedTime(&b, h->far_ev[i + 2], h->far_ev[i + 3]));
-        t->ms_far_tn += a; t->ms_far_nn += b;
+        HIPCHK(h, hipEventElapsedTime(&x, h->far_ev[i], h->far_ev[i + 3]));     // whole far update (op1..op3)
+        t->ms_far_tn += a; t->ms_far_nn += b; tr += x;
         f += h->far_flops[i / 4];
     }
-    t->n_far_launches = (int)(h->far_ev.size() / 4);
+    t->n_far_launches = (int)(h->far_used / 4);
     t->flops_far_tn = f; t->flops_far_nn = f;
-    float tr = 0;
-    if (!h->far_ev.empty()) {
-        // whole far updates (op1..op3) measured first event to last event of each update
-        for (size_t i = 0; i + 3 < h->far_ev.size(); i += 4) {
-            float x = 0;
-            HIPCHK(h, hipEventElapsedTime(&x, h->far_ev[i], h->far_ev[i + 3]));
-            tr += x;
-        }
-    }
     t->ms_trailing = tr;
-    t->ms_panel = t->ms_factor - tr;
+    // the panel chain timed on its own stream: leaves, in-block updates, T merges of every top-level block (with
+    // look-ahead the far updates run beside it on the second stream, so ms_panel + ms_trailing may exceed ms_factor)
+    float ch = 0;
+    for (size_t i = 0; i + 1 < h->chain_used; i += 2) {
+        float x = 0;
+        HIPCHK(h, hipEventElapsedTime(&x, h->chain_ev[i], h->chain_ev[i + 1]));
+        ch += x;
+    }
+    t->ms_panel = ch;
+    t->ms_chain_wait = t->ms_factor - ch;
+    t->n_passes = h->n_passes;
+    t->n_robust_leaves = h->n_robust_leaves;
     h->last_t = *t;
+    return MPQR_OK;
+}
+
+// any Gram-Householder flag raised since the last clear?  (synchronises the chain stream)
+static int any_leaf_flag(mpqr_handle_t h, int* out) {
+    std::vector<int> f((size_t)h->nflag, 0);
+    HIPCHK(h, hipMemcpyAsync(f.data(), h->dflag, f.size() * sizeof(int), hipMemcpyDeviceToHost, h->s0));
+    HIPCHK(h, hipStreamSynchronize(h->s0));
+    *out = 0;
+    for (int v : f) if (v) { *out = 1; break; }
+    return MPQR_OK;
+}
+static int clear_leaf_flags(mpqr_handle_t h) {
+    HIPCHK(h, hipMemsetAsync(h->dflag, 0, (size_t)h->nflag * sizeof(int), h->s0));
     return MPQR_OK;
 }
 
@@ -823,13 +897,15 @@ int mpqr_get_q_host(mpqr_handle_t h, float* Q) {
 static int metrics_core(mpqr_handle_t h, const float* A0, long lda0, const float* R, long ldr, const float* Q, long ldq,
                         int m, int n, float* work /* m*max(m,n) */, mpqr_metrics* out) {
     HIPCHK(h, hipMemsetAsync(h->dmetric, 0, 8 * sizeof(double), h->s0));
-    SgemmArgs g{};
-    g.A = Q; g.lda = ldq; g.transA = 0; g.nslab_a = 1;
-    g.B = R; g.ldb = ldr; g.transB = 0;
-    g.C = work; g.ldc = n; g.M = m; g.N = n; g.K = m; g.alpha = 1.f; g.beta = 0.f;
-    launch_sgemm(g, h->s0);
-    launch_diff_norms(A0, lda0, work, n, m, n, h->dmetric, h->s0);
-    launch_lower_norm(R, ldr, m, n, h->dmetric + 4, h->s0);
+    if (A0 && R) {                                        // A0 == NULL: only the Q metrics (h_q_error, qr.cu:137-171)
+        SgemmArgs g{};
+        g.A = Q; g.lda = ldq; g.transA = 0; g.nslab_a = 1;
+        g.B = R; g.ldb = ldr; g.transB = 0;
+        g.C = work; g.ldc = n; g.M = m; g.N = n; g.K = m; g.alpha = 1.f; g.beta = 0.f;
+        launch_sgemm(g, h->s0);
+        launch_diff_norms(A0, lda0, work, n, m, n, h->dmetric, h->s0);
+        launch_lower_norm(R, ldr, m, n, h->dmetric + 4, h->s0);
+    }
     SgemmArgs q{};
     q.A = Q; q.lda = ldq; q.transA = 1; q.nslab_a = 1;
     q.B = Q; q.ldb = ldq; q.transB = 0;
@@ -878,6 +954,18 @@ int mpqr_metrics_f32(mpqr_handle_t h, const float* A, const float* R, const floa
     if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess) rc = fail(h, MPQR_ERR_HIP, "H2D copy failed");
     else rc = metrics_core(h, dA, n, dR, n, dQ, m, m, n, work, out);
     (void)hipFree(dA); (void)hipFree(dR); (void)hipFree(dQ); (void)hipFree(work);
+    return rc;
+}
+
+int mpqr_q_error_f32(mpqr_handle_t h, const float* Q, int m, mpqr_metrics* out) {
+    if (!h || !Q || !out || m < 1) return MPQR_ERR_INVALID;
+    HIPCHK(h, hipSetDevice(h->device));
+    float *dQ = nullptr, *work = nullptr;
+    int rc;
+    if ((rc = dalloc(h, &dQ, (size_t)m * m)) || (rc = dalloc(h, &work, (size_t)m * m))) { if (dQ) (void)hipFree(dQ); return rc; }
+    if (hipMemcpyAsync(dQ, Q, (size_t)m * m * 4, hipMemcpyHostToDevice, h->s0) != hipSuccess) rc = fail(h, MPQR_ERR_HIP, "H2D copy failed");
+    else rc = metrics_core(h, nullptr, 0, nullptr, 0, dQ, m, m, m, work, out);
+    (void)hipFree(dQ); (void)hipFree(work);
     return rc;
 }
 
@@ -939,15 +1027,15 @@ static int stage_load(mpqr_handle_t h, const float* A, int m, int n, int r, int 
 // a private tree over [c0,c1) appended to the plan's node list (T storage taken from the arena tail is not
 // available, so stage calls build their own small arena)
 struct StageTree {
-    std::vector<Node> saved_nodes; std::vector<int> saved_tops;
+    std::vector<Node> saved_nodes; std::vector<int> saved_tops; std::vector<char> saved_robust;
     float* Tf = nullptr; half_t* Th = nullptr; half_t* Tth = nullptr;
     float *oTf = nullptr; half_t *oTh = nullptr, *oTth = nullptr;
     int root = -1;
 };
 static int stage_tree_begin(mpqr_handle_t h, StageTree& st, int c0, int c1, int r) {
-    st.saved_nodes = h->nodes; st.saved_tops = h->tops;
+    st.saved_nodes = h->nodes; st.saved_tops = h->tops; st.saved_robust = h->leaf_robust;
     st.oTf = h->Tf; st.oTh = h->Th; st.oTth = h->Tth;
-    h->nodes.clear(); h->tops.clear();
+    h->nodes.clear(); h->tops.clear(); h->leaf_robust.clear();
     const int saved_r = h->r; h->r = r;
     st.root = build_tree(h, c0, c1);
     h->r = saved_r;
@@ -956,8 +1044,13 @@ static int stage_tree_begin(mpqr_handle_t h, StageTree& st, int c0, int c1, int 
     if ((size_t)max_ldt * max_ldt > h->tmp_elems || (size_t)64 * max_ldt * max_ldt > h->s_elems ||
         (size_t)std::max(h->m_pad, h->n_pad) * max_ldt > h->yt_elems)
         return fail(h, MPQR_ERR_INVALID, "panel too wide for the planned workspace");
+    if ((int)h->nodes.size() > h->nflag) return fail(h, MPQR_ERR_INVALID, "panel tree larger than the planned flag array");
+    // + 256 rows of slack, zeroed: the 256-wide GEMM tiles load Bt (= T, T^T) unmasked up to the next multiple of 256 rows
+    const size_t tel = toff + (size_t)256 * max_ldt;
     int rc;
-    if ((rc = dalloc(h, &st.Tf, toff)) || (rc = dalloc(h, &st.Th, toff)) || (rc = dalloc(h, &st.Tth, toff))) return rc;
+    if ((rc = dalloc(h, &st.Tf, tel)) || (rc = dalloc(h, &st.Th, tel)) || (rc = dalloc(h, &st.Tth, tel))) return rc;
+    HIPCHK(h, hipMemsetAsync(st.Th, 0, tel * sizeof(half_t), h->s0));
+    HIPCHK(h, hipMemsetAsync(st.Tth, 0, tel * sizeof(half_t), h->s0));
     h->Tf = st.Tf; h->Th = st.Th; h->Tth = st.Tth;
     return MPQR_OK;
 }
@@ -965,25 +1058,27 @@ static void stage_tree_end(mpqr_handle_t h, StageTree& st) {
     (void)hipStreamSynchronize(h->s0);
     if (st.Tf) (void)hipFree(st.Tf); if (st.Th) (void)hipFree(st.Th); if (st.Tth) (void)hipFree(st.Tth);
     h->Tf = st.oTf; h->Th = st.oTh; h->Tth = st.oTth;
-    h->nodes = st.saved_nodes; h->tops = st.saved_tops;
+    h->nodes = st.saved_nodes; h->tops = st.saved_tops; h->leaf_robust = st.saved_robust;
 }
 
-int mpqr_householder_qr_f32(mpqr_handle_t h, float* A, int m, int n, int go, int pw) {
+int mpqr_householder_qr_f32(mpqr_handle_t h, float* A, int m, int n, int go, int pw, int precision) {
     int rc = check_shape(h, m, n, 1); if (rc) return rc;
     if (!A || go < 0 || go >= n || pw < 1) return fail(h, MPQR_ERR_INVALID, "bad panel range");
+    if (precision != MPQR_PREC_FP16 && precision != MPQR_PREC_FP32) return fail(h, MPQR_ERR_INVALID, "unknown precision");
     const int c0 = go, c1 = std::min(n, go + pw);           // qr.cu:210: r = min(go+pw, n)
     h->robust = false;
     for (int attempt = 0; attempt < 2; attempt++) {
-        if ((rc = stage_load(h, A, m, n, std::max(1, c1 - c0), 0, 0))) return rc;
+        if ((rc = stage_load(h, A, m, n, std::max(1, c1 - c0), 0, 0, precision))) return rc;
         if ((rc = compute_scale(h, h->dA))) return rc;
-        HIPCHK(h, hipMemsetAsync(h->dflag, 0, sizeof(int), h->s0));
+        if ((rc = clear_leaf_flags(h))) return rc;
         StageTree st;
         if ((rc = stage_tree_begin(h, st, c0, c1, c1 - c0))) { stage_tree_end(h, st); return rc; }
-        factor_node(h, st.root, true);
+        rc = factor_node(h, st.root, true);
         int f = 0;
-        hipError_t fe = hipMemcpyAsync(&f, h->dflag, sizeof(int), hipMemcpyDeviceToHost, h->s0);
+        const int rcf = any_leaf_flag(h, &f);
         stage_tree_end(h, st);          // synchronises the stream
-        if (fe != hipSuccess) return fail(h, MPQR_ERR_HIP, "flag readback failed");
+        if (rc) return rc;
+        if (rcf) return rcf;
         if (!f || h->robust) break;
         h->robust = true;               // ill-conditioned tall leaf: redo on the column-by-column kernels
     }
@@ -1008,7 +1103,7 @@ int mpqr_wy_transform_f32(mpqr_handle_t h, const float* A, int m, int n, int go,
     if ((rc = stage_load(h, A, m, n, pw, c0, c1))) return rc;
     StageTree st;
     if ((rc = stage_tree_begin(h, st, c0, c1, pw))) { stage_tree_end(h, st); return rc; }
-    factor_node(h, st.root, false);
+    if ((rc = factor_node(h, st.root, false))) { stage_tree_end(h, st); return rc; }
     const Node root = h->nodes[st.root];
     std::vector<float> Tpad((size_t)root.ldt * root.ldt);
     hipError_t e = hipMemcpyAsync(Tpad.data(), h->Tf + root.toff, Tpad.size() * 4, hipMemcpyDeviceToHost, h->s0);
@@ -1053,7 +1148,7 @@ int mpqr_apply_panel_to_trailing_f32(mpqr_handle_t h, float* A, int m, int n, in
     if ((rc = compute_scale(h, h->dA))) return rc;
     StageTree st;
     if ((rc = stage_tree_begin(h, st, c0, c1, pw))) { stage_tree_end(h, st); return rc; }
-    factor_node(h, st.root, false);
+    if ((rc = factor_node(h, st.root, false))) { stage_tree_end(h, st); return rc; }
     apply_node(h, h->nodes[st.root], h->dA, h->lda, c1, n, true, h->a_scale, false);
     stage_tree_end(h, st);
     if (c1 < n) {
@@ -1064,14 +1159,13 @@ int mpqr_apply_panel_to_trailing_f32(mpqr_handle_t h, float* A, int m, int n, in
     return MPQR_OK;
 }
 
-int mpqr_q_backward_accumulation_f32(mpqr_handle_t h, const float* A, float* Q, int m, int n) {
+int mpqr_q_backward_accumulation_f32(mpqr_handle_t h, const float* A, float* Q, int m, int n, int precision) {
     int rc = check_shape(h, m, n, 1); if (rc) return rc;
     if (!A || !Q) return fail(h, MPQR_ERR_INVALID, "NULL argument");
+    if (precision != MPQR_PREC_FP16 && precision != MPQR_PREC_FP32) return fail(h, MPQR_ERR_INVALID, "unknown precision");
     const int r = std::min(n, 128);
-    mpqr_opts o; mpqr_default_opts(&o);
-    if ((rc = mpqr_plan(h, m, n, r, &o))) return rc;
-    if ((rc = stage_load(h, A, m, n, r, 0, n))) return rc;
-    for (size_t t = 0; t < h->tops.size(); t++) factor_node(h, h->tops[t], false);
+    if ((rc = stage_load(h, A, m, n, r, 0, n, precision))) return rc;
+    for (size_t t = 0; t < h->tops.size(); t++) if ((rc = factor_node(h, h->tops[t], false))) return rc;
     if ((rc = form_q(h))) return rc;
     return mpqr_get_q_host(h, Q);
 }
@@ -1115,6 +1209,8 @@ int ls_core(mpqr_handle_t h, const float* B, int nrhs, float* out, bool solve) {
     if (h->world != 1) return fail(h, MPQR_ERR_INVALID, "single-GPU handles only");
     if (h->opts.precision == MPQR_PREC_FP32) return fail(h, MPQR_ERR_INVALID, "MPQR_PREC_FP16 handles only");
     if (!B || !out || nrhs < 1) return fail(h, MPQR_ERR_INVALID, "bad arguments");
+    if (nrhs > std::max(h->m_pad, h->n_pad))      // Xt / Yt scratch holds max(m_pad, n_pad) right-hand sides
+        return fail(h, MPQR_ERR_INVALID, "too many right-hand sides for the planned workspace (nrhs <= max(m, n) rounded up to 256)");
     const long ldb = ((long)nrhs + 31) / 32 * 32;
     float* dB = nullptr;
     if ((rc = dalloc(h, &dB, (size_t)(h->m_pad + 256) * ldb))) return rc;
@@ -1246,7 +1342,7 @@ int mpqr_dist_begin(mpqr_handle_t h, float absmax) {
     h->a_scale = sc;
     HIPCHK(h, hipEventRecord(h->ev[0], h->s0));
     HIPCHK(h, hipMemcpyAsync(h->dA, h->dA0, (size_t)h->m_pad * h->lda * sizeof(float), hipMemcpyDeviceToDevice, h->s0));
-    HIPCHK(h, hipMemsetAsync(h->dflag, 0, sizeof(int), h->s0));
+    if ((rc = clear_leaf_flags(h))) return rc;
     if ((rc = clear_reflectors(h))) return rc;
     h->factored = false; h->q_formed = false;
     return MPQR_OK;
@@ -1267,14 +1363,13 @@ int mpqr_dist_factor_block(mpqr_handle_t h, int s) {
     h->Aeff = h->dA + (lc0 - nd.c0);
     bool saved_robust = h->robust;
     for (int attempt = 0; attempt < 2; attempt++) {
-        factor_node(h, h->tops[s], true);
+        if ((rc = factor_node(h, h->tops[s], true))) { h->robust = saved_robust; h->Aeff = h->dA; return rc; }
         int f = 0;
-        HIPCHK(h, hipMemcpyAsync(&f, h->dflag, sizeof(int), hipMemcpyDeviceToHost, h->s0));
-        HIPCHK(h, hipStreamSynchronize(h->s0));
+        if ((rc = any_leaf_flag(h, &f))) { h->robust = saved_robust; h->Aeff = h->dA; return rc; }
         if (!f || h->robust) break;
         // restore the block and redo it column by column
         h->robust = true;
-        HIPCHK(h, hipMemsetAsync(h->dflag, 0, sizeof(int), h->s0));
+        if ((rc = clear_leaf_flags(h))) return rc;
         HIPCHK(h, hipMemcpy2DAsync(h->dA + lc0, h->lda * sizeof(float), h->dstage, wbytes, wbytes, h->m_pad,
                                    hipMemcpyDeviceToDevice, h->s0));
         HIPCHK(h, hipMemset2DAsync(h->Vh + nd.c0, h->ldvh * sizeof(half_t), 0, (size_t)(nd.c1 - nd.c0) * sizeof(half_t),

@@ -155,7 +155,7 @@ def global_columns(ncols, block, world, rank):
     return np.array([l.mpqr_part_global_index(lc, block, world, rank) for lc in range(k)], dtype=np.int64)
 
 
-def residual_check(engine, comm, nvec=4, seed=7):
+def residual_check(engine, comm, nvec=4, seed=7, group=None):
     """Randomised size-independent check without gathering the matrices: for Gaussian x,
         ||A x - Q (R x)|| / (||A||_F ||x||)  and  ||Q_loc^T Q_loc - I||_F.
     A x, R x and Q y are sums over column shards (all-reduced m-vectors)."""
@@ -175,10 +175,10 @@ def residual_check(engine, comm, nvec=4, seed=7):
     a2 = torch.tensor([float((A * A).sum())], dtype=torch.float64)
     if comm.world > 1:
         for t in (Ax, y, a2):
-            dist.all_reduce(t)                      # default group (gloo/nccl); tensors are on the host
+            dist.all_reduce(t, group=group)         # host tensors: `group` must be a gloo group (default group in the CPU tests)
     Qy = Q @ y[qcols]
     if comm.world > 1:
-        dist.all_reduce(Qy)
+        dist.all_reduce(Qy, group=group)
     res = float(torch.linalg.norm(Ax - Qy) / (torch.sqrt(a2) * torch.linalg.norm(X)))
     # ||Q_loc^T Q_loc - I||_F: exactly for small shards, by Gaussian probing (E ||(Q^T Q - I) z||^2 = ||.||_F^2, 16 probes)
     # for large ones -- the exact product is 2 m q^2 flops in fp64 on the host, minutes at bench sizes
@@ -190,7 +190,7 @@ def residual_check(engine, comm, nvec=4, seed=7):
         qe2 = float(((Q.T @ (Q @ Z) - Z) ** 2).sum() / 16.0)
     qe = torch.tensor([qe2], dtype=torch.float64)
     if comm.world > 1:
-        dist.all_reduce(qe)
+        dist.all_reduce(qe, group=group)
     return {"randomized_residual": res, "q_shard_orth_fro": float(torch.sqrt(qe))}
 
 
@@ -222,10 +222,7 @@ def bench_main(args, m, n, r, world, rank, local_rank):
     chk = None
     try:
         g = dist.new_group(backend="gloo")
-        _default = dist.all_reduce
-        dist.all_reduce = lambda t, op=dist.ReduceOp.SUM: _default(t, op=op, group=g)
-        chk = residual_check(eng, comm)
-        dist.all_reduce = _default
+        chk = residual_check(eng, comm, group=g)
     except Exception as e:  # verification must never take the benchmark down
         chk = {"error": repr(e)}
     if rank == 0:

@@ -19,6 +19,12 @@ def golden():
 
 
 @pytest.fixture(scope="session")
+def golden_precision():
+    """Inputs made by the reference's generate_matrix (python/utils.py:13-24) + its own fp32 / fp64 errors on them."""
+    return np.load(os.path.join(ROOT, "tests", "golden", "pyref_precision.npz"))
+
+
+@pytest.fixture(scope="session")
 def po():
     from oracle import pyoracle
     return pyoracle

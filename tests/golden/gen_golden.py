@@ -83,6 +83,31 @@ def main():
                                             np.linalg.norm(np.tril(R, -1))])
     np.savez_compressed(os.path.join(HERE, "pyref_qr.npz"), **out)
     print("wrote", os.path.join(HERE, "pyref_qr.npz"), len(names), "cases")
+    precision_fixtures()
+
+
+def precision_fixtures():
+    """inputs of the reference's precision experiment (python/performance_test.py:22-33) made by ITS
+    generator python/utils.py:13-24 (generate_matrix, legacy global RNG seeded here), with the backward errors of ITS
+    householder_qr in float32 / float64 (python/qr.py:27-70) on exactly these matrices -> pyref_precision.npz.
+    The float16 column is not reproduced: explicit-H NumPy in fp16 takes minutes per matrix (duration.md)."""
+    import utils as refutils          # /root/reference/python/utils.py
+    out = {}
+    cases = [(10, 3), (10, 5), (10, 7), (100, 3), (100, 5), (100, 7), (500, 5)]
+    np.random.seed(20240)
+    for n, p in cases:
+        A = refutils.generate_matrix(n, 10.0 ** p)
+        key = "n%d_c%d" % (n, p)
+        out[key + "__A"] = A
+        errs = []
+        for dt in (np.float32, np.float64):
+            Q, R = refqr.householder_qr(A.copy(), dtype=dt)
+            errs.append(refutils.get_error(A, Q, R))
+        out[key + "__ref_err_f32_f64"] = np.array(errs)
+        print(key, "cond %.2e" % np.linalg.cond(A), "reference fp32 / fp64 error: %.2e %.2e" % tuple(errs))
+    out["cases"] = np.array(cases)
+    np.savez_compressed(os.path.join(HERE, "pyref_precision.npz"), **out)
+    print("wrote", os.path.join(HERE, "pyref_precision.npz"))
 
 
 if __name__ == "__main__":

@@ -1,0 +1,72 @@
+"""The C++ entry point (apps/mpqr_main = Cuda/main.cu's run list on include/mpqr_reference_api.hpp) exercised as a
+fresh child process on the GPU box, plus a CPU-side check that it builds and links against the C-ABI library."""
+import os
+import re
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EXE = os.path.join(ROOT, "apps", "mpqr_main")
+
+
+def _build():
+    subprocess.run(["make", "-C", os.path.join(ROOT, "mixedprecisionblockqr_amd", "csrc"), "-j4"], check=True, capture_output=True)
+    subprocess.run(["make", "-C", os.path.join(ROOT, "apps")], check=True, capture_output=True)
+
+
+def test_cpp_entry_point_builds_and_links():
+    """g++ compiles the reference-named shim header and links libmpqr.so; without a GPU the program must fail loudly
+    (no CPU fallback), with one: see the gpu tests below."""
+    _build()
+    assert os.access(EXE, os.X_OK)
+    out = subprocess.run(["ldd", EXE], capture_output=True, text=True).stdout
+    assert "libmpqr.so" in out and "not found" not in out.split("libmpqr.so")[1].splitlines()[0]
+    usage = subprocess.run([EXE, "--bogus"], capture_output=True, text=True)
+    assert usage.returncode == 2 and "usage" in usage.stderr
+
+
+CRIT = re.compile(r"(\|\|A - QR\|\|/\|\|A\|\||\|\|QT @ Q - Im\|\||\|\|L\|\|) = ([-+0-9.eE]+) Error Criteria: (True|False)")
+
+
+def _parse(stdout):
+    """-> list of (title, (m, n, r), {metric: (value, passed)})"""
+    cases = []
+    for chunk in stdout.split("\nTesting ")[1:]:
+        title = chunk.split("...")[0]
+        m, n, r = map(int, re.search(r"\(m, n, r\): \((\d+), (\d+), (\d+)\)", chunk).groups())
+        crit = {k: (float(v), ok == "True") for k, v, ok in CRIT.findall(chunk)}
+        cases.append((title, (m, n, r), crit))
+    return cases
+
+
+@pytest.mark.gpu
+def test_cpp_entry_point_single_case(tmp_path):
+    _build()
+    p = subprocess.run([EXE, "--m", "600", "--n", "400", "--r", "16"], cwd=tmp_path, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr
+    (title, shape, crit), = _parse(p.stdout)
+    assert shape == (600, 400, 16) and "mixed-precision" in title
+    assert len(crit) == 3 and all(ok for _, ok in crit.values()), crit        # p = 11 criteria (qr.cu:1889-1892)
+    assert crit["||A - QR||/||A||"][0] <= 1e-3
+    rows = (tmp_path / "log" / "gpu_block.txt").read_text().strip().splitlines()
+    assert rows[0] == "rows,cols,runtime,flops,error" and len(rows) == 2
+    f = rows[1].split(",")
+    assert int(float(f[0])) == 600 and int(float(f[1])) == 400 and float(f[2]) > 0 and float(f[3]) > 0
+
+
+@pytest.mark.gpu
+def test_cpp_entry_point_default_run_list(tmp_path):
+    """Cuda/main.cu:18-24: three algorithms x the 20 shapes of qr.cu:1762-1783; fp32 paths must meet the reference's
+    p = 23 criterion (qr.cu:1367,1836), the mixed path p = 11 (qr.cu:1889)."""
+    _build()
+    p = subprocess.run([EXE], cwd=tmp_path, capture_output=True, text=True, timeout=1100)
+    assert p.returncode == 0, p.stderr
+    cases = _parse(p.stdout)
+    assert len(cases) == 60
+    for title, shape, crit in cases:
+        assert len(crit) == 3, (title, shape, crit)
+        assert all(ok for _, ok in crit.values()), (title, shape, crit)
+    assert sum("householder" in t for t, _, _ in cases) == 20 and sum("mixed" in t for t, _, _ in cases) == 20
+    assert len((tmp_path / "log" / "cpu_householder.txt").read_text().strip().splitlines()) == 21
+    assert len((tmp_path / "log" / "gpu_block.txt").read_text().strip().splitlines()) == 41
