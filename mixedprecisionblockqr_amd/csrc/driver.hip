@@ -38,6 +38,7 @@ struct Node {
     int ldt;           // a1 - a0
     int left, right;   // children or -1
     size_t toff;       // offset into the T arenas (elements)
+    int id;            // index in the node list (per-node events / flags)
 };
 
 // roctx range over the host-side enqueue of one phase (the reference brackets h_householder_qr, h_wy_transform,
@@ -56,6 +57,12 @@ struct mpqr_handle_s {
     int device = 0;
     hipStream_t s0 = nullptr;   // panel chain (high priority)
     hipStream_t s1 = nullptr;   // far trailing updates / Q formation when opts.lookahead (low priority)
+    hipStream_t sT = nullptr;   // compact-WY T construction (leaf T, merges): runs beside the chain's next V-only GEMM
+    std::vector<hipEvent_t> ev_T;     // per node: T of that node is complete (recorded on sT)
+    hipEvent_t ev_v = nullptr, ev_join = nullptr;   // chain -> T stream (reflectors written), T stream -> chain (join)
+    hipEvent_t wait_after_first_leaf = nullptr;     // look-ahead: the rest of the block's columns become valid with this event
+    std::vector<hipEvent_t> ev_cols2;
+    bool tq_on = false;         // this plan builds its T's on sT (fp16 mode)
     std::string err;
 
     bool planned = false;
@@ -161,7 +168,8 @@ void free_plan(mpqr_handle_t h) {
     h->chain_ev.clear(); h->chain_used = 0; h->far_used = 0;
     for (hipEvent_t e : h->ev_node) (void)hipEventDestroy(e);
     for (hipEvent_t e : h->ev_cols) (void)hipEventDestroy(e);
-    h->ev_node.clear(); h->ev_cols.clear();
+    for (hipEvent_t e : h->ev_cols2) (void)hipEventDestroy(e);
+    h->ev_node.clear(); h->ev_cols.clear(); h->ev_cols2.clear();
     for (hipEvent_t e : h->far_ev) (void)hipEventDestroy(e);
     h->far_ev.clear();
     h->nodes.clear(); h->tops.clear();
@@ -197,6 +205,7 @@ int build_tree(mpqr_handle_t h, int c0, int c1) {
     nd.c0 = c0; nd.c1 = c1; nd.a0 = rdown(c0, 64); nd.a1 = rup(c1, 64); nd.ldt = nd.a1 - nd.a0;
     nd.left = nd.right = -1; nd.toff = 0;
     const int id = (int)h->nodes.size();
+    nd.id = id;
     h->nodes.push_back(nd);
     if (!is_leaf(h, c0, c1)) {
         const int cm = pick_split(h, c0, c1, h->r);
@@ -242,14 +251,14 @@ int choose_split(int M, int N, int K, size_t cap_elems, long slab) {
 }
 
 // S (slabs, KrL x KrR, ld = KrR) = V_L^T V_R over rows >= 64-aligned start of R
-int gram(mpqr_handle_t h, const Node& L, const Node& R, int* nslab, long* slab) {
+int gram(mpqr_handle_t h, const Node& L, const Node& R, int* nslab, long* slab, hipStream_t st) {
     const int rlo = rdown(R.c0, 64);
     if (h->opts.precision == MPQR_PREC_FP32) {            // exact-f32 products of the fp32 reflectors
         SgemmArgs g{};
         g.A = h->Vf + (long)rlo * h->n_pad + L.a0; g.lda = h->n_pad; g.transA = 1;
         g.B = h->Vf + (long)rlo * h->n_pad + R.a0; g.ldb = h->n_pad; g.transB = 0;
         g.C = h->S; g.ldc = R.ldt; g.M = L.ldt; g.N = R.ldt; g.K = h->m_pad - rlo; g.alpha = 1.f; g.beta = 0.f; g.nslab_a = 1;
-        launch_sgemm(g, h->s0);
+        launch_sgemm(g, st);
         *nslab = 1; *slab = (long)L.ldt * R.ldt;
         return MPQR_OK;
     }
@@ -262,8 +271,8 @@ int gram(mpqr_handle_t h, const Node& L, const Node& R, int* nslab, long* slab) 
     *slab = (long)L.ldt * R.ldt;
     g.nsplit = choose_split(g.M, g.N, g.K, h->s_elems, *slab);
     g.slab_out_stride = *slab;
-    launch_gemm_f16(A_H16, E_STORE_F32, g, h->s0);
-    if (g.nsplit > 1) launch_slab_reduce(h->S, g.nsplit, *slab, *slab, h->S, h->s0);
+    launch_gemm_f16(A_H16, E_STORE_F32, g, st);
+    if (g.nsplit > 1) launch_slab_reduce(h->S, g.nsplit, *slab, *slab, h->S, st);
     *nslab = 1;
     return MPQR_OK;
 }
@@ -321,7 +330,8 @@ void apply_node(mpqr_handle_t h, const Node& nd, float* C, long ldc, int clo, in
     gemm_dispatch(A_F32T, E_STORE_F32, g1, st);
     if (g1.nsplit > 1) launch_slab_reduce(Xt, g1.nsplit, slab, slab, Xt, st);
     if (record) (void)hipEventRecord(e1, st);
-    // op2: Yt[M1 x Kr] = fp16( Xt * T' )
+    // op2: Yt[M1 x Kr] = fp16( Xt * T' ) -- the first use of T: it was built on the T stream beside op1
+    if (h->tq_on && nd.id >= 0 && nd.id < (int)h->ev_T.size()) (void)hipStreamWaitEvent(st, h->ev_T[nd.id], 0);
     GemmArgs g2{};
     g2.A = Xt; g2.lda = Kr; g2.nslab_in = 1; g2.slab_in_stride = slab;
     g2.Bt = (trans_t ? h->Tth : h->Th) + nd.toff; g2.ldb = Kr;
@@ -345,6 +355,7 @@ void apply_node(mpqr_handle_t h, const Node& nd, float* C, long ldc, int clo, in
 }
 
 int factor_node(mpqr_handle_t h, int id, bool do_panel);
+int factor_rec(mpqr_handle_t h, int id, bool do_panel);
 
 // Robust path for a tall (<=128-column) leaf: factor it through a temporary sub-tree of 32-column leaves
 // (column-by-column kernels + MFMA updates inside the leaf) and keep only the sub-tree's root T.  The sub-tree's T
@@ -376,71 +387,113 @@ int robust_tall_leaf(mpqr_handle_t h, const Node nd, bool do_panel) {
     return rc;
 }
 
-int factor_node(mpqr_handle_t h, int id, bool do_panel) {
+// chain stream -> T stream: everything enqueued on s0 so far (reflectors of the nodes below) is visible to sT
+static void t_stream_follows_chain(mpqr_handle_t h) {
+    (void)hipEventRecord(h->ev_v, h->s0);
+    (void)hipStreamWaitEvent(h->sT, h->ev_v, 0);
+}
+
+int factor_rec(mpqr_handle_t h, int id, bool do_panel) {
     const Node nd = h->nodes[id];
     int rc;
+    // compact-WY T's are built on their own stream (sT): nothing on the chain needs T before op2 of the next apply,
+    // so the leaf's T (Gram reduction + triangular inverse) and the merges T_LR = -T_L (V_L^T V_R) T_R run beside
+    // that apply's X = A2^T V.  fp32 twin: everything stays on the chain stream.
+    const bool tq = h->tq_on && id < (int)h->ev_T.size();
+    hipStream_t st = tq ? h->sT : h->s0;
     if (nd.left < 0) {
         const bool tall = leaf_width(h, nd.c0) == 128;
         const bool robust_leaf = h->robust || (id < (int)h->leaf_robust.size() && h->leaf_robust[id]);
-        if (do_panel && robust_leaf && !h->force32 && tall) return robust_tall_leaf(h, nd, do_panel);
+        if (do_panel && robust_leaf && !h->force32 && tall) {
+            rc = robust_tall_leaf(h, nd, do_panel);
+            if (tq) { t_stream_follows_chain(h); (void)hipEventRecord(h->ev_T[id], h->sT); }
+            return rc;
+        }
+        bool have_s = false;
+        LeafArgs a{};
         if (do_panel) {
             Range rg("mpqr:panel");
-            LeafArgs a{};
             a.A = h->Aeff; a.lda = h->lda; a.mrows = h->m; a.cb = rdown(nd.c0, tall ? 128 : 32); a.c0 = nd.c0; a.c1 = nd.c1;
             a.Vh = h->Vh; a.ldvh = h->ldvh; a.Vt = h->Vt; a.ldvt = h->ldvt; a.vdiag = h->vdiag;
             a.P = h->P; a.maxwg = h->maxwg;
             const bool fused = tall && !h->Vf;    // fp16 mode: the Gram of the rounded reflectors comes out of gh_apply
             int* flag = h->dflag + (id < h->nflag ? id : 0);
-            if (tall) launch_leaf_gram_householder(a, h->Gp, h->Gs, h->Cv, flag, fused ? h->Sp : nullptr, h->S, h->s0);
+            if (tall) launch_leaf_gram_householder(a, h->Gp, h->Gs, h->Cv, flag, fused ? h->Sp : nullptr, nullptr, h->s0);
             else launch_leaf_factor(a, h->s0);
             if (h->Vf) launch_extract_vf(h->Aeff, h->lda, h->vdiag, h->Vf, h->n_pad, h->m, nd.c0, nd.c1, h->s0);
-            if (fused) {
-                // S is in window coordinates (128 x 128 from a.cb); the node's aligned range starts at a0 >= cb
-                const int sh = nd.a0 - a.cb;
-                launch_t_leaf(h->S + (long)sh * 128 + sh, 1, 0, 128, nd.a0, nd.c0, nd.c1, h->Tf + nd.toff, h->Th + nd.toff,
-                              h->Tth + nd.toff, nd.ldt, h->s0);
-                return MPQR_OK;
+            have_s = fused;
+            if (h->wait_after_first_leaf) {          // look-ahead: the block's other columns arrive with this event
+                (void)hipStreamWaitEvent(h->s0, h->wait_after_first_leaf, 0);
+                h->wait_after_first_leaf = nullptr;
             }
         }
         Range rg("mpqr:wy_T");
-        int nslab; long slab;
-        gram(h, nd, nd, &nslab, &slab);
-        launch_t_leaf(h->S, nslab, slab, nd.ldt, nd.a0, nd.c0, nd.c1, h->Tf + nd.toff, h->Th + nd.toff, h->Tth + nd.toff,
-                      nd.ldt, h->s0);
+        if (tq) t_stream_follows_chain(h);
+        if (have_s) {
+            // S = sum of gh_apply's partial Grams, in window coordinates (128 x 128 from a.cb); the node's aligned
+            // range starts at a0 >= cb
+            launch_gh_reduce_f32(h->Sp, gh_num_partials(a), h->S, st);
+            const int sh = nd.a0 - a.cb;
+            launch_t_leaf(h->S + (long)sh * 128 + sh, 1, 0, 128, nd.a0, nd.c0, nd.c1, h->Tf + nd.toff, h->Th + nd.toff,
+                          h->Tth + nd.toff, nd.ldt, st);
+        } else {
+            int nslab; long slab;
+            gram(h, nd, nd, &nslab, &slab, st);
+            launch_t_leaf(h->S, nslab, slab, nd.ldt, nd.a0, nd.c0, nd.c1, h->Tf + nd.toff, h->Th + nd.toff, h->Tth + nd.toff,
+                          nd.ldt, st);
+        }
+        if (tq) (void)hipEventRecord(h->ev_T[id], h->sT);
         return MPQR_OK;
     }
     const Node L = h->nodes[nd.left], R = h->nodes[nd.right];
-    if ((rc = factor_node(h, nd.left, do_panel))) return rc;
+    if ((rc = factor_rec(h, nd.left, do_panel))) return rc;
     if (do_panel) {
         Range rg("mpqr:in_block_update");
         apply_node(h, L, h->Aeff, h->lda, R.c0, R.c1, true, h->a_scale, false);
     }
-    if ((rc = factor_node(h, nd.right, do_panel))) return rc;
+    if ((rc = factor_rec(h, nd.right, do_panel))) return rc;
     // T_LR = -T_L (V_L^T V_R) T_R
     Range rg("mpqr:wy_T_merge");
+    if (tq) t_stream_follows_chain(h);        // V_R is complete on the chain; T_L, T_R are earlier work of sT itself
     int nslab; long slab;
-    gram(h, L, R, &nslab, &slab);
+    gram(h, L, R, &nslab, &slab, st);
     if (L.ldt <= 128 && R.ldt <= 128) {
-        launch_t_merge(h->S, L.ldt, R.ldt, h->Tf + L.toff, h->Tf + R.toff, h->tmp2, h->s0);
-        launch_t_assemble(h->Tf + nd.toff, h->Th + nd.toff, h->Tth + nd.toff, nd.ldt, nd.a0, h->Tf + L.toff, L.ldt, L.a0,
-                          nd.c0, L.c1, h->Tf + R.toff, R.ldt, R.a0, nd.c1, h->tmp2, R.ldt, h->s0);
-        return MPQR_OK;
+        launch_t_merge(h->S, L.ldt, R.ldt, h->Tf + L.toff, h->Tf + R.toff, h->tmp2, st);
+    } else {
+        SgemmArgs s1{};
+        s1.A = h->S; s1.lda = R.ldt; s1.transA = 0; s1.nslab_a = nslab; s1.slab_a = slab;
+        s1.B = h->Tf + R.toff; s1.ldb = R.ldt; s1.transB = 0;
+        s1.C = h->tmp1; s1.ldc = R.ldt; s1.M = L.ldt; s1.N = R.ldt; s1.K = R.ldt; s1.alpha = 1.f; s1.beta = 0.f;
+        s1.upperB = 1;
+        launch_sgemm(s1, st);
+        SgemmArgs s2{};
+        s2.A = h->Tf + L.toff; s2.lda = L.ldt; s2.transA = 0; s2.nslab_a = 1;
+        s2.B = h->tmp1; s2.ldb = R.ldt; s2.transB = 0;
+        s2.C = h->tmp2; s2.ldc = R.ldt; s2.M = L.ldt; s2.N = R.ldt; s2.K = L.ldt; s2.alpha = -1.f; s2.beta = 0.f;
+        s2.upperA = 1;
+        launch_sgemm(s2, st);
     }
-    SgemmArgs s1{};
-    s1.A = h->S; s1.lda = R.ldt; s1.transA = 0; s1.nslab_a = nslab; s1.slab_a = slab;
-    s1.B = h->Tf + R.toff; s1.ldb = R.ldt; s1.transB = 0;
-    s1.C = h->tmp1; s1.ldc = R.ldt; s1.M = L.ldt; s1.N = R.ldt; s1.K = R.ldt; s1.alpha = 1.f; s1.beta = 0.f;
-    s1.upperB = 1;
-    launch_sgemm(s1, h->s0);
-    SgemmArgs s2{};
-    s2.A = h->Tf + L.toff; s2.lda = L.ldt; s2.transA = 0; s2.nslab_a = 1;
-    s2.B = h->tmp1; s2.ldb = R.ldt; s2.transB = 0;
-    s2.C = h->tmp2; s2.ldc = R.ldt; s2.M = L.ldt; s2.N = R.ldt; s2.K = L.ldt; s2.alpha = -1.f; s2.beta = 0.f;
-    s2.upperA = 1;
-    launch_sgemm(s2, h->s0);
     launch_t_assemble(h->Tf + nd.toff, h->Th + nd.toff, h->Tth + nd.toff, nd.ldt, nd.a0, h->Tf + L.toff, L.ldt, L.a0,
-                      nd.c0, L.c1, h->Tf + R.toff, R.ldt, R.a0, nd.c1, h->tmp2, R.ldt, h->s0);
+                      nd.c0, L.c1, h->Tf + R.toff, R.ldt, R.a0, nd.c1, h->tmp2, R.ldt, st);
+    if (tq) (void)hipEventRecord(h->ev_T[id], h->sT);
     return MPQR_OK;
+}
+
+// factor the sub-tree `id`; on return every T below it is ordered before whatever is enqueued on the chain stream next
+int factor_node(mpqr_handle_t h, int id, bool do_panel) {
+    if (h->tq_on) {
+        while (h->ev_T.size() < h->nodes.size()) {
+            hipEvent_t e;
+            if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return fail(h, MPQR_ERR_HIP, "hipEventCreate failed");
+            h->ev_T.push_back(e);
+        }
+    }
+    const int rc = factor_rec(h, id, do_panel);
+    if (h->tq_on) {
+        (void)hipEventRecord(h->ev_join, h->sT);
+        (void)hipStreamWaitEvent(h->s0, h->ev_join, 0);
+    }
+    return rc;
 }
 
 int clear_reflectors(mpqr_handle_t h) {
@@ -538,7 +591,10 @@ int mpqr_create(mpqr_handle_t* out, int device) {
     (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
     if (hipSetDevice(device) != hipSuccess ||
         hipStreamCreateWithPriority(&h->s0, hipStreamNonBlocking, prio_hi) != hipSuccess ||
-        create_update_stream(&h->s1, prio_lo) != hipSuccess) {
+        create_update_stream(&h->s1, prio_lo) != hipSuccess ||
+        hipStreamCreateWithPriority(&h->sT, hipStreamNonBlocking, prio_hi) != hipSuccess ||
+        hipEventCreateWithFlags(&h->ev_v, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming) != hipSuccess) {
         g_create_err = "hipSetDevice/hipStreamCreate failed";
         delete h;
         return MPQR_ERR_HIP;
@@ -559,12 +615,17 @@ int mpqr_destroy(mpqr_handle_t h) {
     (void)hipSetDevice(h->device);
     (void)hipStreamSynchronize(h->s0);
     if (h->s1) (void)hipStreamSynchronize(h->s1);
+    if (h->sT) (void)hipStreamSynchronize(h->sT);
     free_plan(h);
     if (h->dmetric) (void)hipFree(h->dmetric);
     if (h->dscalar) (void)hipFree(h->dscalar);
     for (int i = 0; i < 4; i++) if (h->ev[i]) (void)hipEventDestroy(h->ev[i]);
+    for (hipEvent_t e : h->ev_T) (void)hipEventDestroy(e);
+    if (h->ev_v) (void)hipEventDestroy(h->ev_v);
+    if (h->ev_join) (void)hipEventDestroy(h->ev_join);
     (void)hipStreamDestroy(h->s0);
     if (h->s1) (void)hipStreamDestroy(h->s1);
+    if (h->sT) (void)hipStreamDestroy(h->sT);
     delete h;
     return MPQR_OK;
 }
@@ -586,6 +647,12 @@ static int plan_common(mpqr_handle_t h, int m, int n, int r, const mpqr_opts* op
     HIPCHK(h, hipStreamSynchronize(h->s0));
     free_plan(h);
     h->m = m; h->n = n; h->r = r; h->opts = o; h->world = world; h->rank = rank;
+    {   // MPQR_TSTREAM=1 builds the compact-WY T's on a third stream beside the chain's next V-only GEMM.  Measured at
+        // 16384^2 (profiles/README.md): the serial T chain at the end of a sub-tree (leaf T -> merge -> merge, ~230 us)
+        // is longer than the GEMM it hides behind, so the chain then waits for T instead (60.9 vs 59.0 ms): off by default.
+        const char* e = getenv("MPQR_TSTREAM");
+        h->tq_on = h->sT != nullptr && o.precision == MPQR_PREC_FP16 && (e && atoi(e) == 1);
+    }
     if (const char* e = getenv("MPQR_GH_MIN_ROWS")) h->gh_min_rows = atoi(e);      // tuning hook
     h->m_pad = rup(m, 256); h->n_pad = rup(n, 256);
     int Ko = o.outer_block > 0 ? o.outer_block : 1024;
@@ -632,6 +699,9 @@ static int plan_common(mpqr_handle_t h, int m, int n, int r, const mpqr_opts* op
             HIPCHK(h, hipEventCreateWithFlags(&e1, hipEventDisableTiming));
             HIPCHK(h, hipEventCreateWithFlags(&e2, hipEventDisableTiming));
             h->ev_node.push_back(e1); h->ev_cols.push_back(e2);
+            hipEvent_t e3;
+            HIPCHK(h, hipEventCreateWithFlags(&e3, hipEventDisableTiming));
+            h->ev_cols2.push_back(e3);
         }
     }
     if ((rc = dalloc(h, &h->S, h->s_elems))) return rc;
@@ -730,10 +800,19 @@ static int run_block_loop(mpqr_handle_t h, std::vector<int>& flags) {
     }
     for (size_t t = 0; t < h->tops.size(); t++) {
         const Node nd = h->nodes[h->tops[t]];
-        if (la && t > 0) HIPCHK(h, hipStreamWaitEvent(h->s0, h->ev_cols[t], 0));     // my columns carry all earlier updates
+        if (la && t > 0) {
+            // the first leaf's columns carry all earlier updates; the rest of the block follows with ev_cols2 (waited
+            // for right after the first leaf's kernels are enqueued, factor_rec)
+            HIPCHK(h, hipStreamWaitEvent(h->s0, h->ev_cols[t], 0));
+            h->wait_after_first_leaf = h->ev_cols2[t];
+        }
         const bool timed = h->chain_used + 2 <= h->chain_ev.size();
         if (timed) HIPCHK(h, hipEventRecord(h->chain_ev[h->chain_used], h->s0));
         if ((rc = factor_node(h, h->tops[t], true))) return rc;
+        if (h->wait_after_first_leaf) {       // (no leaf launched: cannot happen, but never leave the wait pending)
+            HIPCHK(h, hipStreamWaitEvent(h->s0, h->wait_after_first_leaf, 0));
+            h->wait_after_first_leaf = nullptr;
+        }
         if (timed) { HIPCHK(h, hipEventRecord(h->chain_ev[h->chain_used + 1], h->s0)); h->chain_used += 2; }
         Range rg("mpqr:far_update");
         if (!la) {
@@ -744,8 +823,13 @@ static int run_block_loop(mpqr_handle_t h, std::vector<int>& flags) {
         HIPCHK(h, hipStreamWaitEvent(h->s1, h->ev_node[t], 0));
         if (t + 1 < h->tops.size()) {
             const Node nx = h->nodes[h->tops[t + 1]];
-            apply_node(h, nd, h->dA, h->lda, nx.c0, nx.c1, true, h->a_scale, true, 1);    // next block first ...
+            int fl = h->tops[t + 1];
+            while (h->nodes[fl].left >= 0) fl = h->nodes[fl].left;
+            const int c_first = h->nodes[fl].c1;                                           // end of the next block's first leaf
+            apply_node(h, nd, h->dA, h->lda, nx.c0, c_first, true, h->a_scale, false, 1);  // next block's first leaf first ...
             HIPCHK(h, hipEventRecord(h->ev_cols[t + 1], h->s1));
+            apply_node(h, nd, h->dA, h->lda, c_first, nx.c1, true, h->a_scale, true, 1);   // ... then the rest of that block ...
+            HIPCHK(h, hipEventRecord(h->ev_cols2[t + 1], h->s1));
             apply_node(h, nd, h->dA, h->lda, nx.c1, h->n, true, h->a_scale, true, 1);      // ... the rest overlaps its panels
         }
     }
@@ -793,6 +877,7 @@ int mpqr_sync(mpqr_handle_t h) {
     HIPCHK(h, hipSetDevice(h->device));
     HIPCHK(h, hipStreamSynchronize(h->s0));
     if (h->s1) HIPCHK(h, hipStreamSynchronize(h->s1));
+    if (h->sT) HIPCHK(h, hipStreamSynchronize(h->sT));
     return MPQR_OK;
 }
 

@@ -834,6 +834,12 @@ __global__ __launch_bounds__(256) void gh_reduce_f32_kernel(const float* __restr
     if (wave == 0) S[e] = (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
 }
 
+int gh_num_partials(const LeafArgs& a) {
+    return (a.mrows - a.c1 + 63) / 64 + (a.c1 - a.c0 + 63) / 64;
+}
+void launch_gh_reduce_f32(const float* Sp, int nslab, float* S, hipStream_t s) {
+    hipLaunchKernelGGL(gh_reduce_f32_kernel, dim3(256), dim3(256), 0, s, Sp, nslab, S);
+}
 void launch_leaf_gram_householder(const LeafArgs& a, double* Gp, double* G, float* Cv, int* flag, float* Sp, float* S,
                                   hipStream_t s) {
     static bool attr = false;
@@ -851,7 +857,7 @@ void launch_leaf_gram_householder(const LeafArgs& a, double* Gp, double* G, floa
     const int ntop = Sp ? (a.c1 - a.c0 + 63) / 64 : 0;      // extra workgroups: Gram contribution of the top block
     if (nlow + ntop == 0) return;
     hipLaunchKernelGGL(gh_apply_kernel, dim3(nlow + ntop), dim3(256), (8256 + GW * GH_TS) * 4, s, a, Cv, Sp, nlow);
-    if (Sp) hipLaunchKernelGGL(gh_reduce_f32_kernel, dim3(256), dim3(256), 0, s, Sp, nlow + ntop, S);
+    if (Sp && S) hipLaunchKernelGGL(gh_reduce_f32_kernel, dim3(256), dim3(256), 0, s, Sp, nlow + ntop, S);
 }
 
 void launch_leaf_factor(const LeafArgs& a, hipStream_t s) {

@@ -70,8 +70,11 @@ void launch_leaf_factor(const LeafArgs& a, hipStream_t s);   // robust path: one
 // when the leaf is too ill-conditioned for it
 // If Sp != nullptr the apply kernel also emits the Gram matrix of the fp16 reflectors (window coordinates,
 // 128 x 128 fp32, upper triangle only) into S, via per-workgroup partials Sp ((rows/64 + 2) x 16384).
+// S == nullptr: the partials Sp are left for launch_gh_reduce_f32 (gh_num_partials of them) on another stream.
 void launch_leaf_gram_householder(const LeafArgs& a, double* Gp /* nwg x 16384 */, double* G /* 16384 */,
                                   float* Cv /* 16384 */, int* flag, float* Sp, float* S, hipStream_t s);
+int gh_num_partials(const LeafArgs& a);
+void launch_gh_reduce_f32(const float* Sp, int nslab, float* S, hipStream_t s);
 
 // T of a leaf (<= 128 reflectors) from its Gram slabs S (row stride lds_, aligned range starting at a0)
 void launch_t_leaf(const float* S, int nslab, long slab_stride, int lds_, int a0, int c0, int c1,
