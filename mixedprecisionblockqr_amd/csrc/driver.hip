@@ -663,6 +663,14 @@ static int plan_common(mpqr_handle_t h, int m, int n, int r, const mpqr_opts* op
     h->qloc = (world == 1) ? m : mpqr_part_local_cols(m, Ko, world, rank);
     h->lda = rup(std::max(h->nloc, 1), 256); h->ldq = rup(std::max(h->qloc, 1), 256);
     h->ldvh = h->n_pad; h->ldvt = h->m_pad;
+    {   // Leading-dimension padding (elements; multiples of 64 keep every row 128-B aligned).  Row strides that are large
+        // powers of two (16384 floats = 64 KiB) put the 256 rows of a GEMM tile on few HBM channels.
+        static const int pad = []() { const char* e = getenv("MPQR_LD_PAD"); return e ? atoi(e) : 0; }();
+        if (pad > 0) {
+            const int p64 = rup(pad, 64);
+            h->lda += p64; h->ldq += p64; h->ldvh += p64; h->ldvt += p64;
+        }
+    }
     // tree over the GLOBAL columns (every rank builds the same one)
     for (int c = 0; c < n; c += Ko) h->tops.push_back(build_tree(h, c, std::min(n, c + Ko)));
     size_t toff = 0; int max_ldt = 64;

@@ -285,13 +285,76 @@ static void launch2(const GemmArgs& g, hipStream_t s) {
     hipLaunchKernelGGL((gemm2_f16_kernel<AM, EM, WM, WN, BK>), dim3(groups * 32, a.nsplit), dim3(NT), LDS, s, a, tilesM, tilesN);
 }
 
+// ------------------------------------------------------------------ read-modify-write epilogue through LDS-DMA
+// C[256 x 256 tile] -= alpha * acc for the 2 x 4 wave layout (wave tile 128 x 64 = 4 x 2 MFMA 32x32 tiles).
+// At K = 1024 the register-staged epilogue (gemm_epilogue.h) costs as much as the K loop: a lane has at most 16-32
+// four-byte loads of old C in flight, ~32 KiB per CU, so the tile's 256 KiB of old values arrive latency-bound.
+// Here the old values come in by LDS-DMA (global_load_lds_dwordx4: no VGPR destination, nothing for a wave to wait
+// on): the tile is cut into 8 chunks of 32 rows (16 from each wave row, so every wave has work in every chunk),
+// 4 chunks = 128 KiB are in flight at once in the LDS the K loop has just released, and each wave then reads its
+// 16 old values per chunk with conflict-free ds_read_b32 (lanes run along n), subtracts and stores.
+// Rows >= M are clamped on the load side (never stored); columns past N read the row's continuation (inside the
+// allocation: every matrix has 1024 floats of slack) and are never stored.
+// Only for tiles that lie completely inside [0,M) x [col_lo,N): every lane stores, so the number of outstanding
+// vector-memory operations at each wait is known at compile time.  Edge tiles take the register-staged epilogue.
+template <typename ACC>
+__device__ __forceinline__ void epilogue_sub_f32_dma(const ACC (&acc)[4][2], char* smem, float* __restrict__ C, long ldc,
+                                                     float alpha, int bm, int bn, int wave, int lane) {
+    const int r = lane & 31, h = lane >> 5;
+    const int wr = wave >> 2, wn = (wave & 3) * 64;
+    // chunk c: tile rows 16 c .. 16 c + 15 of BOTH wave rows -> 32 rows x 1 KiB; wave w moves rows 4 w .. 4 w + 3 of it
+    const float* src0 = C + (long)(bm + (wave >> 2) * 128 + (wave & 3) * 4) * ldc + bn + 4 * lane;
+    auto issue = [&](int c) {
+        char* base = smem + (c & 3) * 32768 + wave * 4096;
+        const float* src = src0 + (long)(16 * c) * ldc;
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (long)q * ldc),
+                                             (__attribute__((address_space(3))) void*)(base + q * 1024), 16, 0, 0);
+    };
+    issue(0); issue(1); issue(2); issue(3);
+    float* pbase = C + (long)(bm + wr * 128 + 4 * h) * ldc + bn + wn + r;
+#pragma unroll
+    for (int c = 0; c < 8; c++) {
+        // Vector-memory operations retire in issue order.  Issue order of this wave:
+        //   [0][1][2][3] st0 [4] st1 [5] st2 [6] st3 [7] st4 st5 st6 st7      ([k] = 4 DMAs of chunk k, st = 16 stores)
+        // chunk c has landed when only what was issued after [c] is still outstanding:
+        if (c == 0) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");          // [1][2][3]
+        else if (c == 1) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");     // [2][3] st0
+        else if (c == 2) asm volatile("s_waitcnt vmcnt(40)" ::: "memory");     // [3] st0 [4] st1
+        else if (c <= 5) asm volatile("s_waitcnt vmcnt(56)" ::: "memory");     // st [c+1] st [c+2] st
+        else if (c == 6) asm volatile("s_waitcnt vmcnt(52)" ::: "memory");     // st3 [7] st4 st5
+        else asm volatile("s_waitcnt vmcnt(48)" ::: "memory");                 // st4 st5 st6
+        __builtin_amdgcn_s_barrier();                  // chunk c landed for every wave; everybody is done reading chunk c-1
+        if (c >= 1 && c + 3 < 8) issue(c + 3);         // into the buffer chunk c-1 has just released
+        const int i = c >> 1, hf = c & 1;
+        const char* base = smem + (c & 3) * 32768 + (16 * wr + 4 * h) * 1024 + (wn + r) * 4;
+        float oldv[2][8];
+#pragma unroll
+        for (int j = 0; j < 2; j++)
+#pragma unroll
+            for (int ee = 0; ee < 8; ee++)
+                oldv[j][ee] = *(const float*)(base + ((ee & 3) + 8 * (ee >> 2)) * 1024 + j * 128);
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+            float* p = pbase + (long)(16 * c) * ldc + j * 32;
+#pragma unroll
+            for (int q = 0; q < 2; q++) {
+#pragma unroll
+                for (int e = 0; e < 4; e++) p[(long)e * ldc] = oldv[j][q * 4 + e] - alpha * acc[i][j][8 * hf + q * 4 + e];
+                p += 8 * ldc;
+            }
+        }
+    }
+}
+
 // ------------------------------------------------------------------ all-DMA 4-stage ring (both operands fp16)
 // C[M x N] (-)= A[M][K] * Bt[N][K]^T with A and Bt both fp16 and k contiguous: the far trailing update
 // A2 -= V Y^T and the Q-formation twin, the dominant kernels of the factorisation.  256 x 256 x 32 tiles,
 // 512 threads = 8 waves (2 x 4), a ring of 4 LDS stages (4 x 32 KiB); A and Bt both go HBM -> LDS with
 // global_load_lds_dwordx4 (4 per wave and K-tile), three K-tiles in flight behind a COUNTED s_waitcnt vmcnt and
 // a raw s_barrier (one per K-tile; __syncthreads() would drain the DMA queue).  Source-side XOR swizzle as above.
-template <int EM>
+template <int EM, int DMA_EPI = 0>
 __global__ __launch_bounds__(512) void gemm3_f16_kernel(GemmArgs g, int tilesM, int tilesN) {
     using namespace g2;
     constexpr int BM = 256, BN = 256, BK = 32, NS = 4;
@@ -372,8 +435,9 @@ __global__ __launch_bounds__(512) void gemm3_f16_kernel(GemmArgs g, int tilesM, 
     __builtin_amdgcn_s_barrier();
     const float alpha = g.alpha;
     if (EM == E_SUB_F32) {
-        // (an LDS-staged variant with 16-B accesses along full rows was measured: 527 vs 559 TFLOP/s -- not kept)
-        epilogue_sub_f32<4, 2>(acc, (float*)g.C, g.ldc, g.M, g.N, g.col_lo, alpha, bm + wm, bn + wn, r, h);
+        const bool full = DMA_EPI && bm + BM <= g.M && bn + BN <= g.N && bn >= g.col_lo;      // uniform over the workgroup
+        if (full) epilogue_sub_f32_dma(acc, g2_smem, (float*)g.C, g.ldc, alpha, bm, bn, wave, lane);
+        else epilogue_sub_f32<4, 2>(acc, (float*)g.C, g.ldc, g.M, g.N, g.col_lo, alpha, bm + wm, bn + wn, r, h);
         return;
     }
 #pragma unroll
@@ -387,6 +451,194 @@ __global__ __launch_bounds__(512) void gemm3_f16_kernel(GemmArgs g, int tilesM, 
                 if (m < g.M && n < g.N) ((float*)g.C)[(long)m * g.ldc + n] = alpha * acc[i][j][e];
             }
         }
+}
+
+// ------------------------------------------------------------------ gemm6: ping-pong wave groups, 256 x 256 x 64
+// Same contract as gemm3 (A, Bt fp16, k contiguous; E_SUB_F32 / E_STORE_F32), different main loop.  gemm3 syncs all
+// eight waves once per 32-deep K step and every wave then reads its fragments before anybody can issue an MFMA: the
+// matrix pipes idle while the LDS bursts (in steady state 44 % of the MFMA rate inside the K loop).  Here:
+//   * K tile 64, two LDS buffers of 64 KiB (A 256 x 128 B, B 256 x 128 B, XOR-swizzled 16-B chunks as in gemm2);
+//   * a wave's 128 x 64 output is cut into four 64 x 32 quadrants; one PHASE computes one quadrant over the K tile
+//     (8 MFMA 32x32x16) and needs only the fragments of one 64-row A sub-tile / one 32-column B sub-tile:
+//         p0: read A0, B0 -> q00     p1: read B1 -> q01     p2: read A1 -> q11     p3: (nothing) -> q10
+//   * the two wave rows (waves 0-3 / 4-7; one wave of each lives on every SIMD) run HALF A PHASE APART: while one
+//     group issues its 8 MFMAs the other reads fragments and issues LDS-DMA, then they swap (two s_barriers per
+//     phase, the second group enters the loop one barrier late);
+//   * staging unit = "half tile" = the sub-tile rows of BOTH wave rows / all four wave columns (128 rows x 128 B =
+//     16 KiB = 2 LDS-DMA per wave), one per phase, in the order they are needed: A-S0, B-S0, B-S1, A-S1.  An LDS
+//     region is dead as soon as its fragments are in registers, so element e = 4 tile + s is issued in phase e - 6:
+//     four half tiles (64 KiB) are always in flight behind a counted s_waitcnt vmcnt(8); the region a DMA overwrites
+//     was last read >= 2 phases earlier and the data a phase reads was waited for before the previous barrier.
+template <int EM, int DMA_EPI>
+__global__ __launch_bounds__(512) void gemm6_f16_kernel(GemmArgs g, int tilesM, int tilesN) {
+    using namespace g2;
+    constexpr int BM = 256, BN = 256, BK = 64;
+    constexpr int ROWB = 128, A_BYTES = BM * ROWB, BUF = 2 * A_BYTES;
+    auto swz = [](int r, int c) -> int { return r * ROWB + ((c ^ ((r >> 1) & 7)) << 4); };
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, h = lane >> 5;
+    const int nwg = gridDim.x, bid = blockIdx.x;
+    const int q = nwg / 8, rem = nwg % 8, xcd = bid % 8;
+    const int seq = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + bid / 8;
+    const int groupsN = (tilesN + 7) / 8;
+    const int grp = seq / 32, within = seq % 32;
+    const int tm = (grp / groupsN) * 4 + within / 8;
+    const int tn = (grp % groupsN) * 8 + within % 8;
+    if (tm >= tilesM || tn >= tilesN) return;
+    const int bm = tm * BM, bn = tn * BN;
+    const int ktiles = g.K / BK;
+    const half_t* const A = (const half_t*)g.A;
+    const int wr = wave >> 2, wc = wave & 3;
+    const int wm = wr * 128, wn = wc * 64;
+
+    // half tile s of K tile tau -> buffer tau & 1.  s: 0 = A-S0, 1 = B-S0, 2 = B-S1, 3 = A-S1.
+    // One wave-instruction = 8 rows x 128 B; lane l lands on row row0 + l/8, physical chunk l%8.
+    auto issue = [&](int tau, int sidx) {
+        const int k = min(tau, ktiles - 1) * BK;              // past the end: re-fetch the last tile into a dead region
+        char* buf = g2_smem + (tau & 1) * BUF;
+        const bool isA = (sidx == 0 || sidx == 3);
+        const int sub = (sidx == 0 || sidx == 1) ? 0 : 1;
+#pragma unroll
+        for (int i = 0; i < 2; i++) {
+            const int gidx = i * 8 + wave;                    // 16 row groups of 8 per half tile
+            int row0;
+            if (isA) row0 = (gidx >> 3) * 128 + sub * 64 + 8 * (gidx & 7);
+            else row0 = 64 * (gidx >> 2) + 32 * sub + 8 * (gidx & 3);
+            const int rr = row0 + (lane >> 3);
+            const int c = (lane & 7) ^ ((rr >> 1) & 7);
+            if (isA)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(A + (long)(bm + rr) * g.lda + k + c * 8),
+                                                 (__attribute__((address_space(3))) void*)(buf + row0 * ROWB), 16, 0, 0);
+            else
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g.Bt + (long)(bn + rr) * g.ldb + k + c * 8),
+                                                 (__attribute__((address_space(3))) void*)(buf + A_BYTES + row0 * ROWB), 16, 0, 0);
+        }
+    };
+
+    floatx16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++)
+#pragma unroll
+            for (int e = 0; e < 16; e++) acc[i][j][e] = 0.f;
+
+    half8 af[4][2], b0[4], b1[4];                             // A sub-tile fragments [k step][row tile], B-S0, B-S1
+    auto read_A = [&](const char* As, int sub) {
+#pragma unroll
+        for (int ks = 0; ks < 4; ks++)
+#pragma unroll
+            for (int i2 = 0; i2 < 2; i2++) af[ks][i2] = *(const half8*)(As + swz(wm + sub * 64 + i2 * 32 + r, ks * 2 + h));
+    };
+    auto read_B = [&](const char* Bs, int sub, half8 (&b)[4]) {
+#pragma unroll
+        for (int ks = 0; ks < 4; ks++) b[ks] = *(const half8*)(Bs + swz(wn + sub * 32 + r, ks * 2 + h));
+    };
+    auto mma = [&](int subA, int subB, const half8 (&b)[4]) {
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < 4; ks++)
+#pragma unroll
+            for (int i2 = 0; i2 < 2; i2++)
+                acc[subA * 2 + i2][subB] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[ks][i2], b[ks], acc[subA * 2 + i2][subB], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+    };
+
+#ifdef MPQR_KTRACE
+    const bool kt_on = (tid == 0) && (bid % 397 == 5) && EM == E_SUB_F32 && gridDim.x > 2000;
+    long kt0 = 0, kt1 = 0, kt2 = 0; unsigned long long rt0 = 0;
+    if (kt_on) { kt0 = clock64(); rt0 = __builtin_amdgcn_s_memrealtime(); }
+#endif
+    // prologue: elements 0..5 (tile 0 complete, B-S0 / A-S0 of tile 1), elements 0 and 1 landed
+    issue(0, 0); issue(0, 1); issue(0, 2); issue(0, 3); issue(1, 0); issue(1, 1);
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (wr == 1) __builtin_amdgcn_s_barrier();               // second group: half a phase behind
+    for (int t = 0; t < ktiles; t++) {
+        const char* As = g2_smem + (t & 1) * BUF;
+        const char* Bs = As + A_BYTES;
+        // ---- p0
+        read_A(As, 0); read_B(Bs, 0, b0);
+        issue(t + 1, 2);
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        mma(0, 0, b0);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        // ---- p1
+        read_B(Bs, 1, b1);
+        issue(t + 1, 3);
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        mma(0, 1, b1);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        // ---- p2
+        read_A(As, 1);
+        issue(t + 2, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        mma(1, 1, b1);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        // ---- p3 (no fragment reads: A1 and B0 are in registers)
+        issue(t + 2, 1);
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        mma(1, 0, b0);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+    }
+    if (wr == 0) __builtin_amdgcn_s_barrier();               // first group waits for the second one's last half phase
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // the trailing (redundant) half tiles
+    __builtin_amdgcn_s_barrier();
+#ifdef MPQR_KTRACE
+    if (kt_on) kt1 = clock64();
+#endif
+    const float alpha = g.alpha;
+    if (EM == E_SUB_F32) {
+        const bool full = DMA_EPI && bm + BM <= g.M && bn + BN <= g.N && bn >= g.col_lo;      // uniform over the workgroup
+        if (full) epilogue_sub_f32_dma(acc, g2_smem, (float*)g.C, g.ldc, alpha, bm, bn, wave, lane);
+        else epilogue_sub_f32<4, 2>(acc, (float*)g.C, g.ldc, g.M, g.N, g.col_lo, alpha, bm + wm, bn + wn, r, h);
+#ifdef MPQR_KTRACE
+        if (kt_on) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            kt2 = clock64();
+            const unsigned long long rt1 = __builtin_amdgcn_s_memrealtime();
+            printf("ktrace gemm6 bid %d K %d full %d: loop %ld epi %ld cycles, total %.2f us\n", bid, g.K, (int)full, kt1 - kt0, kt2 - kt1,
+                   (double)(rt1 - rt0) / 100.0);
+        }
+#endif
+        return;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+            const int n = bn + wn + j * 32 + r;
+#pragma unroll
+            for (int e = 0; e < 16; e++) {
+                const int m = bm + wm + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+                if (m < g.M && n < g.N) ((float*)g.C)[(long)m * g.ldc + n] = alpha * acc[i][j][e];
+            }
+        }
+}
+
+template <int EM, int DMA_EPI>
+static void launch6(const GemmArgs& g, hipStream_t s) {
+    constexpr int LDS = 2 * 2 * 256 * 128;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)gemm6_f16_kernel<EM, DMA_EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        attr_set = true;
+    }
+    const int tilesM = (g.M + 255) / 256, tilesN = (g.N + 255) / 256;
+    const int groups = ((tilesM + 3) / 4) * ((tilesN + 7) / 8);
+    hipLaunchKernelGGL((gemm6_f16_kernel<EM, DMA_EPI>), dim3(groups * 32), dim3(512), LDS, s, g, tilesM, tilesN);
 }
 
 // gemm4: the same all-DMA pipeline with a 256 x 128 x 32 tile, 256 threads (2 x 2 waves of 128 x 64) and a ring of
@@ -514,17 +766,17 @@ static void launch4(const GemmArgs& g, hipStream_t s) {
     hipLaunchKernelGGL((gemm4_f16_kernel<EM>), dim3(groups * 64), dim3(256), LDS, s, g, tilesM, tilesN);
 }
 
-template <int EM>
+template <int EM, int DMA_EPI = 0>
 static void launch3(const GemmArgs& g, hipStream_t s) {
     constexpr int LDS = 4 * 2 * 256 * 64;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)gemm3_f16_kernel<EM>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        (void)hipFuncSetAttribute((const void*)gemm3_f16_kernel<EM, DMA_EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         attr_set = true;
     }
     const int tilesM = (g.M + 255) / 256, tilesN = (g.N + 255) / 256;
     const int groups = ((tilesM + 3) / 4) * ((tilesN + 7) / 8);
-    hipLaunchKernelGGL((gemm3_f16_kernel<EM>), dim3(groups * 32), dim3(512), LDS, s, g, tilesM, tilesN);
+    hipLaunchKernelGGL((gemm3_f16_kernel<EM, DMA_EPI>), dim3(groups * 32), dim3(512), LDS, s, g, tilesM, tilesN);
 }
 
 // Large-shape path.  Preconditions (checked by the caller, driver.hip): no split-K, K % 64 == 0, and the
@@ -534,6 +786,13 @@ bool launch_gemm2_f16(AMode am, EMode em, const GemmArgs& g, hipStream_t s, int 
     if (am == A_H16 && config != 2 && config != 1) {          // config 2 keeps the register-staged kernel (A/B comparison)
         static const int use4 = []() { const char* e = getenv("MPQR_GEMM4"); return e ? atoi(e) : 0; }();
         if (em == E_SUB_F32 && use4) { launch4<E_SUB_F32>(g, s); return true; }
+        static const int dma_epi = []() { const char* e = getenv("MPQR_DMA_EPILOGUE"); return e ? atoi(e) : 1; }();
+        static const int use6 = []() { const char* e = getenv("MPQR_GEMM6"); return e ? atoi(e) : 1; }();
+        if (use6 && (g.K % 64) == 0) {
+            if (em == E_SUB_F32) { if (dma_epi) launch6<E_SUB_F32, 1>(g, s); else launch6<E_SUB_F32, 0>(g, s); return true; }
+            if (em == E_STORE_F32) { launch6<E_STORE_F32, 0>(g, s); return true; }
+        }
+        if (em == E_SUB_F32 && dma_epi) { launch3<E_SUB_F32, 1>(g, s); return true; }
         if (em == E_SUB_F32) { launch3<E_SUB_F32>(g, s); return true; }
         if (em == E_STORE_F32) { launch3<E_STORE_F32>(g, s); return true; }
     }
