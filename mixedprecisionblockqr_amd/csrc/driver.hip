@@ -39,6 +39,7 @@ struct Node {
     int left, right;   // children or -1
     size_t toff;       // offset into the T arenas (elements)
     int id;            // index in the node list (per-node events / flags)
+    int tld;           // leading dimension of this node's T (ldt: own contiguous T; larger: diagonal block of a block-level T)
 };
 
 // roctx range over the host-side enqueue of one phase (the reference brackets h_householder_qr, h_wy_transform,
@@ -63,6 +64,8 @@ struct mpqr_handle_s {
     hipEvent_t wait_after_first_leaf = nullptr;     // look-ahead: the rest of the block's columns become valid with this event
     std::vector<hipEvent_t> ev_cols2;
     bool tq_on = false;         // this plan builds its T's on sT (fp16 mode)
+    hipStream_t op1_stream = nullptr;   // set by factor_block_flat: X = C2^T V (+ its slab sum) of the next apply runs there
+    hipEvent_t ev_x = nullptr;          // ... and this event orders it before the apply's second GEMM
     std::string err;
 
     bool planned = false;
@@ -85,6 +88,7 @@ struct mpqr_handle_s {
     float* Xt1 = nullptr;  half_t* Yt1 = nullptr;      // scratch of the far-update stream (look-ahead)
     std::vector<hipEvent_t> ev_node, ev_cols;          // per top-level node: reflectors ready / columns up to date
     float* S = nullptr;    size_t s_elems = 0;
+    float* Sleaf = nullptr;       // 128 x 128 Gram of a leaf's fp16 reflectors (chain stream; S itself is used by the T stream)
     float* P = nullptr;    int maxwg = 0;
     double* Gp = nullptr; double* Gs = nullptr; float* Cv = nullptr; int* dflag = nullptr;   // Gram-Householder leaf workspace
     float* Sp = nullptr;          // per-workgroup partial Grams of the fp16 reflectors (fused into gh_apply)
@@ -156,14 +160,14 @@ int dalloc(mpqr_handle_t h, T** p, size_t elems) {
 void free_plan(mpqr_handle_t h) {
     void* ptrs[] = {h->dA, h->dA0, h->dQ, h->Vh, h->Vt, h->vdiag, h->Xt, h->Yt, h->S, h->P, h->tmp1, h->tmp2,
                     h->Tf, h->Th, h->Tth, h->dstage, h->Gp, h->Gs, h->Cv, h->dflag, h->Vf, h->Yf, h->Xt1, h->Yt1, h->Sp,
-                    h->rbTf, h->rbTh, h->rbTth};
+                    h->rbTf, h->rbTh, h->rbTth, h->Sleaf};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     h->dA = h->dA0 = h->dQ = nullptr; h->Vh = h->Vt = nullptr; h->vdiag = nullptr; h->Xt = nullptr; h->Yt = nullptr;
     h->S = nullptr; h->P = nullptr; h->tmp1 = h->tmp2 = nullptr; h->Tf = nullptr; h->Th = h->Tth = nullptr;
     h->dstage = nullptr; h->stage_elems = 0;
     h->Gp = nullptr; h->Gs = nullptr; h->Cv = nullptr; h->dflag = nullptr; h->Vf = nullptr; h->Yf = nullptr;
     h->Xt1 = nullptr; h->Yt1 = nullptr; h->Sp = nullptr;
-    h->rbTf = nullptr; h->rbTh = h->rbTth = nullptr; h->rb_elems = 0; h->nflag = 0; h->leaf_robust.clear();
+    h->rbTf = nullptr; h->rbTh = h->rbTth = nullptr; h->rb_elems = 0; h->nflag = 0; h->leaf_robust.clear(); h->Sleaf = nullptr;
     for (hipEvent_t e : h->chain_ev) (void)hipEventDestroy(e);
     h->chain_ev.clear(); h->chain_used = 0; h->far_used = 0;
     for (hipEvent_t e : h->ev_node) (void)hipEventDestroy(e);
@@ -203,7 +207,7 @@ int pick_split(mpqr_handle_t h, int c0, int c1, int r) {
 int build_tree(mpqr_handle_t h, int c0, int c1) {
     Node nd;
     nd.c0 = c0; nd.c1 = c1; nd.a0 = rdown(c0, 64); nd.a1 = rup(c1, 64); nd.ldt = nd.a1 - nd.a0;
-    nd.left = nd.right = -1; nd.toff = 0;
+    nd.left = nd.right = -1; nd.toff = 0; nd.tld = nd.ldt;
     const int id = (int)h->nodes.size();
     nd.id = id;
     h->nodes.push_back(nd);
@@ -327,14 +331,16 @@ void apply_node(mpqr_handle_t h, const Node& nd, float* C, long ldc, int clo, in
     g1.nsplit = choose_split(M1, Kr, Kw, h->xt_elems, slab);
     g1.slab_out_stride = slab;
     if (record) (void)hipEventRecord(e0, st);
-    gemm_dispatch(A_F32T, E_STORE_F32, g1, st);
-    if (g1.nsplit > 1) launch_slab_reduce(Xt, g1.nsplit, slab, slab, Xt, st);
+    hipStream_t st1 = (h->op1_stream && lane == 0) ? h->op1_stream : st;     // flat schedule: X on the side stream, T on the chain
+    gemm_dispatch(A_F32T, E_STORE_F32, g1, st1);
+    if (g1.nsplit > 1) launch_slab_reduce(Xt, g1.nsplit, slab, slab, Xt, st1);
+    if (st1 != st) { (void)hipEventRecord(h->ev_x, st1); (void)hipStreamWaitEvent(st, h->ev_x, 0); }
     if (record) (void)hipEventRecord(e1, st);
     // op2: Yt[M1 x Kr] = fp16( Xt * T' ) -- the first use of T: it was built on the T stream beside op1
-    if (h->tq_on && nd.id >= 0 && nd.id < (int)h->ev_T.size()) (void)hipStreamWaitEvent(st, h->ev_T[nd.id], 0);
+    if (st1 == st && h->tq_on && nd.id >= 0 && nd.id < (int)h->ev_T.size()) (void)hipStreamWaitEvent(st, h->ev_T[nd.id], 0);
     GemmArgs g2{};
     g2.A = Xt; g2.lda = Kr; g2.nslab_in = 1; g2.slab_in_stride = slab;
-    g2.Bt = (trans_t ? h->Tth : h->Th) + nd.toff; g2.ldb = Kr;
+    g2.Bt = (trans_t ? h->Tth : h->Th) + nd.toff; g2.ldb = nd.tld;
     g2.C = Yt; g2.ldc = Kr;
     g2.M = M1; g2.N = Kr; g2.K = Kr;
     g2.in_scale = 1.f; g2.alpha = 1.f; g2.nsplit = 1;
@@ -356,6 +362,7 @@ void apply_node(mpqr_handle_t h, const Node& nd, float* C, long ldc, int clo, in
 
 int factor_node(mpqr_handle_t h, int id, bool do_panel);
 int factor_rec(mpqr_handle_t h, int id, bool do_panel);
+int robust_tall_leaf(mpqr_handle_t h, const Node nd, bool do_panel);
 
 // Robust path for a tall (<=128-column) leaf: factor it through a temporary sub-tree of 32-column leaves
 // (column-by-column kernels + MFMA updates inside the leaf) and keep only the sub-tree's root T.  The sub-tree's T
@@ -479,6 +486,121 @@ int factor_rec(mpqr_handle_t h, int id, bool do_panel) {
     return MPQR_OK;
 }
 
+// ---- right-looking factorisation of one top-level block with a block-level T ("flat" mode)
+// Inside a top-level block the tree schedule above puts merged T's on the critical path: after the last leaf of a
+// sub-tree the chain waits for leaf T -> merge -> merge (-> merge) before the next apply can run its second GEMM (kernel
+// trace: 100-350 us per sub-tree end, ~15 of the 37 ms the chain takes at 16384^2).  Here every leaf j is applied to the
+// block's remaining columns on its own (K = 128, needs only the leaf's T_j, which is built beside the apply's first
+// GEMM), and the block's T is completed in the background, one column block per leaf (LAPACK larft order):
+//     T[0:o, o:o+w] = -T[0:o, 0:o] (V_P^T V_j) T_j,    P = the block's earlier reflectors,  o = their count,
+// which only the far update and Q formation need.  Same flops as the tree (every column still receives every
+// reflector of the block once), K = 128 instead of 128 / 256 / 512 for the in-block updates.
+static void collect_leaves(mpqr_handle_t h, int id, std::vector<int>& out) {
+    const Node& nd = h->nodes[id];
+    if (nd.left < 0) { out.push_back(id); return; }
+    collect_leaves(h, nd.left, out); collect_leaves(h, nd.right, out);
+}
+static bool flat_block_ok(mpqr_handle_t h, int top, std::vector<int>& leaves) {
+    static const int on = []() { const char* e = getenv("MPQR_FLAT"); return e ? atoi(e) : 1; }();
+    if (!on || h->Vf || h->force32) return false;
+    leaves.clear();
+    collect_leaves(h, top, leaves);
+    if (leaves.size() < 2) return false;
+    const Node& tp = h->nodes[top];
+    if (tp.a0 != tp.c0) return false;
+    for (int id : leaves) {
+        const Node& lf = h->nodes[id];
+        if (leaf_width(h, lf.c0) != 128 || lf.a0 != lf.c0 || (lf.c0 % 64) != 0) return false;
+    }
+    return true;
+}
+int factor_block_flat(mpqr_handle_t h, int top, const std::vector<int>& leaves) {
+    const Node tp = h->nodes[top];
+    const int ld = tp.ldt;
+    const bool tq = h->tq_on && top < (int)h->ev_T.size();
+    hipStream_t st = tq ? h->sT : h->s0;
+    int rc;
+    // column block of the block's T for leaf `lf` (o = reflectors of the block before it): on the side stream
+    auto t_column_block = [&](const Node& lf, int o) {
+        if (o <= 0) return;
+        Range rg("mpqr:wy_T_merge");
+        Node P = tp; P.c1 = lf.c0; P.a1 = lf.c0; P.ldt = o;                     // the earlier reflectors of the block
+        int nslab; long slab;
+        gram(h, P, lf, &nslab, &slab, st);                                         // S = V_P^T V_j  (o x ldt_j, ld = ldt_j)
+        SgemmArgs s1{};                                                            // tmp1 = S T_j
+        s1.A = h->S; s1.lda = lf.ldt; s1.transA = 0; s1.nslab_a = nslab; s1.slab_a = slab;
+        s1.B = h->Tf + lf.toff; s1.ldb = ld; s1.transB = 0;
+        s1.C = h->tmp1; s1.ldc = lf.ldt; s1.M = o; s1.N = lf.ldt; s1.K = lf.ldt; s1.alpha = 1.f; s1.beta = 0.f; s1.upperB = 1;
+        launch_sgemm(s1, st);
+        SgemmArgs s2{};                                                            // T[0:o, o:o+w] = -T_P tmp1
+        s2.A = h->Tf + tp.toff; s2.lda = ld; s2.transA = 0; s2.nslab_a = 1;
+        s2.B = h->tmp1; s2.ldb = lf.ldt; s2.transB = 0;
+        s2.C = h->Tf + tp.toff + o; s2.ldc = ld; s2.M = o; s2.N = lf.ldt; s2.K = o; s2.alpha = -1.f; s2.beta = 0.f; s2.upperA = 1;
+        launch_sgemm(s2, st);
+        launch_t_colblock_h16(h->Tf + tp.toff, h->Th + tp.toff, h->Tth + tp.toff, ld, o, o, lf.ldt, st);
+    };
+    Node prev{}; int prev_o = -1;                         // leaf whose column block of T is still to be built
+    for (size_t j = 0; j < leaves.size(); j++) {
+        const int id = leaves[j];
+        Node lf = h->nodes[id];
+        const int o = lf.c0 - tp.c0;                       // reflectors of the block before this leaf
+        lf.toff = tp.toff + (size_t)o * (ld + 1);          // the leaf's T = diagonal block of the block's T
+        lf.tld = ld;
+        const bool robust_leaf = h->robust || (id < (int)h->leaf_robust.size() && h->leaf_robust[id]);
+        if (robust_leaf) {
+            // column-by-column kernels through a private sub-tree; its root T (contiguous, ldt^2) goes into the diagonal block
+            const size_t keep = h->nodes[id].toff;
+            if ((rc = robust_tall_leaf(h, h->nodes[id], true))) return rc;
+            (void)hipMemcpy2DAsync(h->Tf + lf.toff, (size_t)ld * 4, h->Tf + keep, (size_t)lf.ldt * 4, (size_t)lf.ldt * 4, lf.ldt, hipMemcpyDeviceToDevice, h->s0);
+            (void)hipMemcpy2DAsync(h->Th + lf.toff, (size_t)ld * 2, h->Th + keep, (size_t)lf.ldt * 2, (size_t)lf.ldt * 2, lf.ldt, hipMemcpyDeviceToDevice, h->s0);
+            (void)hipMemcpy2DAsync(h->Tth + lf.toff, (size_t)ld * 2, h->Tth + keep, (size_t)lf.ldt * 2, (size_t)lf.ldt * 2, lf.ldt, hipMemcpyDeviceToDevice, h->s0);
+            if (tq) t_stream_follows_chain(h);
+        } else {
+            Range rg("mpqr:panel");
+            LeafArgs a{};
+            a.A = h->Aeff; a.lda = h->lda; a.mrows = h->m; a.cb = rdown(lf.c0, 128); a.c0 = lf.c0; a.c1 = lf.c1;
+            a.Vh = h->Vh; a.ldvh = h->ldvh; a.Vt = h->Vt; a.ldvt = h->ldvt; a.vdiag = h->vdiag;
+            a.P = h->P; a.maxwg = h->maxwg;
+            launch_leaf_gram_householder(a, h->Gp, h->Gs, h->Cv, h->dflag + (id < h->nflag ? id : 0), h->Sp, nullptr, h->s0);
+            if (h->wait_after_first_leaf) {              // look-ahead: the block's other columns arrive with this event
+                (void)hipStreamWaitEvent(h->s0, h->wait_after_first_leaf, 0);
+                h->wait_after_first_leaf = nullptr;
+            }
+            Range rt("mpqr:wy_T");
+            // ONE chain -> side-stream hand-off per leaf (each event operation costs the chain stream ~7 us): it publishes
+            // the leaf's reflectors (for the apply's first GEMM and for this leaf's column block of T) and, being later in
+            // the chain stream than the previous leaf's T, that T as well (for the previous leaf's column block).
+            if (tq) t_stream_follows_chain(h);
+            // T_j (Gram reduction + triangular inverse, ~46 us) is the longer of the two things the apply's second GEMM
+            // needs, so it stays on the chain stream and the apply's X = C2^T V (+ slab sum, ~35 us) goes to the side stream
+            launch_gh_reduce_f32(h->Sp, gh_num_partials(a), h->Sleaf, h->s0);
+            const int sh = lf.a0 - a.cb;
+            launch_t_leaf(h->Sleaf + (long)sh * 128 + sh, 1, 0, 128, lf.a0, lf.c0, lf.c1, h->Tf + lf.toff, h->Th + lf.toff,
+                          h->Tth + lf.toff, lf.ldt, h->s0, ld);
+        }
+        // the chain: this leaf alone onto the rest of the block
+        if (lf.c1 < tp.c1) {
+            Range rg("mpqr:in_block_update");
+            h->op1_stream = tq ? h->sT : nullptr;
+            apply_node(h, lf, h->Aeff, h->lda, lf.c1, tp.c1, true, h->a_scale, false);
+            h->op1_stream = nullptr;
+        }
+        // background, behind this leaf's X GEMM in the side stream's queue: the PREVIOUS leaf's column block of T
+        if (prev_o >= 0) t_column_block(prev, prev_o);
+        prev = lf; prev_o = o;
+        if (!tq) { t_column_block(prev, prev_o); prev_o = -1; }          // single stream: nothing to defer
+    }
+    if (prev_o >= 0) {                                     // the last leaf's column block needs its T (chain stream)
+        if (tq) t_stream_follows_chain(h);
+        t_column_block(prev, prev_o);
+    }
+    if (tq) {
+        for (int id : leaves) (void)hipEventRecord(h->ev_T[id], h->sT);
+        (void)hipEventRecord(h->ev_T[top], h->sT);
+    }
+    return MPQR_OK;
+}
+
 // factor the sub-tree `id`; on return every T below it is ordered before whatever is enqueued on the chain stream next
 int factor_node(mpqr_handle_t h, int id, bool do_panel) {
     if (h->tq_on) {
@@ -488,7 +610,9 @@ int factor_node(mpqr_handle_t h, int id, bool do_panel) {
             h->ev_T.push_back(e);
         }
     }
-    const int rc = factor_rec(h, id, do_panel);
+    std::vector<int> leaves;
+    const bool is_top = std::find(h->tops.begin(), h->tops.end(), id) != h->tops.end();
+    const int rc = (do_panel && is_top && flat_block_ok(h, id, leaves)) ? factor_block_flat(h, id, leaves) : factor_rec(h, id, do_panel);
     if (h->tq_on) {
         (void)hipEventRecord(h->ev_join, h->sT);
         (void)hipStreamWaitEvent(h->s0, h->ev_join, 0);
@@ -536,14 +660,17 @@ int form_q(mpqr_handle_t h) {
 // The far-update stream may use only 3 of every 4 CUs: its GEMM workgroups hold a CU's LDS for ~100 us each, and
 // the latency-bound panel kernels on s0 would otherwise queue behind them (MPQR_UPDATE_CU_MASK=0 disables this).
 hipError_t create_update_stream(hipStream_t* st, int prio) {
+    // MPQR_UPDATE_CU_MASK=0x........ restricts the far-update stream to a CU pattern (32-bit, repeated 8 times); measured
+    // at 16384^2: no effect on the step time for 1/2 .. 7/8 of the CUs, so the default is an unmasked low-priority stream.
     const char* e = getenv("MPQR_UPDATE_CU_MASK");
-    if (e && atoi(e) == 0) return hipStreamCreateWithPriority(st, hipStreamNonBlocking, prio);
+    if (!(e && strlen(e) > 2 && e[0] == '0' && (e[1] == 'x' || e[1] == 'X')))
+        return hipStreamCreateWithPriority(st, hipStreamNonBlocking, prio);
     uint32_t mask[8];
-    uint32_t pat = 0xEEEEEEEEu;                              // CU i enabled unless i % 4 == 0
-    if (e && strlen(e) > 2 && e[0] == '0' && (e[1] == 'x' || e[1] == 'X')) pat = (uint32_t)strtoul(e, nullptr, 16);
+    const uint32_t pat = (uint32_t)strtoul(e, nullptr, 16);
     for (int i = 0; i < 8; i++) mask[i] = pat;
     hipError_t rc = hipExtStreamCreateWithCUMask(st, 8, mask);
-    if (rc != hipSuccess) rc = hipStreamCreateWithPriority(st, hipStreamNonBlocking, prio);
+    if (rc != hipSuccess) return hipStreamCreateWithPriority(st, hipStreamNonBlocking, prio);
+    gemm_register_stream_cus(*st, 8 * __builtin_popcount(pat));
     return rc;
 }
 
@@ -594,7 +721,8 @@ int mpqr_create(mpqr_handle_t* out, int device) {
         create_update_stream(&h->s1, prio_lo) != hipSuccess ||
         hipStreamCreateWithPriority(&h->sT, hipStreamNonBlocking, prio_hi) != hipSuccess ||
         hipEventCreateWithFlags(&h->ev_v, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming) != hipSuccess) {
+        hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&h->ev_x, hipEventDisableTiming) != hipSuccess) {
         g_create_err = "hipSetDevice/hipStreamCreate failed";
         delete h;
         return MPQR_ERR_HIP;
@@ -623,6 +751,7 @@ int mpqr_destroy(mpqr_handle_t h) {
     for (hipEvent_t e : h->ev_T) (void)hipEventDestroy(e);
     if (h->ev_v) (void)hipEventDestroy(h->ev_v);
     if (h->ev_join) (void)hipEventDestroy(h->ev_join);
+    if (h->ev_x) (void)hipEventDestroy(h->ev_x);
     (void)hipStreamDestroy(h->s0);
     if (h->s1) (void)hipStreamDestroy(h->s1);
     if (h->sT) (void)hipStreamDestroy(h->sT);
@@ -647,11 +776,12 @@ static int plan_common(mpqr_handle_t h, int m, int n, int r, const mpqr_opts* op
     HIPCHK(h, hipStreamSynchronize(h->s0));
     free_plan(h);
     h->m = m; h->n = n; h->r = r; h->opts = o; h->world = world; h->rank = rank;
-    {   // MPQR_TSTREAM=1 builds the compact-WY T's on a third stream beside the chain's next V-only GEMM.  Measured at
-        // 16384^2 (profiles/README.md): the serial T chain at the end of a sub-tree (leaf T -> merge -> merge, ~230 us)
-        // is longer than the GEMM it hides behind, so the chain then waits for T instead (60.9 vs 59.0 ms): off by default.
+    {   // The compact-WY T's are built on a third stream beside the chain's next V-only GEMM (MPQR_TSTREAM=0: on the chain
+        // stream).  With the tree schedule alone this did not pay (the serial leaf T -> merge -> merge chain at the end of a
+        // sub-tree is longer than the GEMM it hides behind: 60.9 vs 59.0 ms at 16384^2); the flat block schedule
+        // (factor_block_flat) needs only the leaf's own T on the chain and is what the T stream is for (53.0 ms).
         const char* e = getenv("MPQR_TSTREAM");
-        h->tq_on = h->sT != nullptr && o.precision == MPQR_PREC_FP16 && (e && atoi(e) == 1);
+        h->tq_on = h->sT != nullptr && o.precision == MPQR_PREC_FP16 && !(e && atoi(e) == 0);
     }
     if (const char* e = getenv("MPQR_GH_MIN_ROWS")) h->gh_min_rows = atoi(e);      // tuning hook
     h->m_pad = rup(m, 256); h->n_pad = rup(n, 256);
@@ -713,6 +843,7 @@ static int plan_common(mpqr_handle_t h, int m, int n, int r, const mpqr_opts* op
         }
     }
     if ((rc = dalloc(h, &h->S, h->s_elems))) return rc;
+    if ((rc = dalloc(h, &h->Sleaf, (size_t)128 * 128))) return rc;
     if ((rc = dalloc(h, &h->P, (size_t)2 * h->maxwg * 32))) return rc;
     if ((rc = dalloc(h, &h->Gp, (size_t)(h->m_pad / 128 + 2) * 16384))) return rc;
     if ((rc = dalloc(h, &h->Gs, (size_t)16384))) return rc;
@@ -735,6 +866,7 @@ static int plan_common(mpqr_handle_t h, int m, int n, int r, const mpqr_opts* op
     if ((rc = dalloc(h, &h->tmp1, h->tmp_elems))) return rc;
     if ((rc = dalloc(h, &h->tmp2, h->tmp_elems))) return rc;
     if ((rc = dalloc(h, &h->Tf, h->t_elems))) return rc;
+    HIPCHK(h, hipMemsetAsync(h->Tf, 0, h->t_elems * sizeof(float), h->s0));
     if ((rc = dalloc(h, &h->Th, h->t_elems + (size_t)256 * max_ldt))) return rc;
     if ((rc = dalloc(h, &h->Tth, h->t_elems + (size_t)256 * max_ldt))) return rc;
     HIPCHK(h, hipMemsetAsync(h->Th, 0, (h->t_elems + (size_t)256 * max_ldt) * sizeof(half_t), h->s0));

@@ -827,8 +827,18 @@ __global__ __launch_bounds__(256) void gh_reduce_f32_kernel(const float* __restr
     __shared__ float part[4][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int e = blockIdx.x * 64 + lane;
+    const bool act = ((e >> 7) >> 5) <= ((e & 127) >> 5);   // the partials hold the 10 upper 32 x 32 tiles only; T reads j >= i
     float s = 0.f;
-    for (int q = wave; q < nslab; q += 4) s += Sp[(long)q * (GW * GW) + e];
+    if (act) {
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;       // four independent chains: more loads in flight per lane
+        int q = wave;
+        for (; q + 12 < nslab; q += 16) {
+            s0 += Sp[(long)q * (GW * GW) + e]; s1 += Sp[(long)(q + 4) * (GW * GW) + e];
+            s2 += Sp[(long)(q + 8) * (GW * GW) + e]; s3 += Sp[(long)(q + 12) * (GW * GW) + e];
+        }
+        for (; q < nslab; q += 4) s0 += Sp[(long)q * (GW * GW) + e];
+        s = (s0 + s1) + (s2 + s3);
+    }
     part[wave][lane] = s;
     __syncthreads();
     if (wave == 0) S[e] = (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
@@ -895,7 +905,7 @@ void launch_leaf_factor(const LeafArgs& a, hipStream_t s) {
 // Replaces the reference's dev_wy_transform loop (Cuda/qr.cu:535-600: r rounds of three kernels, dense (m-l)^2).
 __global__ __launch_bounds__(1024) void t_panel_kernel(const float* __restrict__ S, int nslab, long slab_stride, int lds_,
                                                        int a0, int c0, int c1, float* __restrict__ T,
-                                                       half_t* __restrict__ Th, half_t* __restrict__ Tth, int ldt) {
+                                                       half_t* __restrict__ Th, half_t* __restrict__ Tth, int ldt, int ld) {
     float* Ss = (float*)gh_smem;             // [TP][TPS]
     float* Ts = Ss + TP * TPS;               // [TP][TPS]
     __shared__ float tdiag[TP];
@@ -920,20 +930,22 @@ __global__ __launch_bounds__(1024) void t_panel_kernel(const float* __restrict__
     KT();
     tri_inverse_128(Ss, tdiag, Ts, nblk, tid);
     KT();
+    // the ldt x ldt aligned range is written (zeros outside the leaf) into a matrix of leading dimension ld (>= ldt:
+    // the node's own T, or its diagonal block inside the T of the enclosing top-level block)
     for (int e = tid; e < ldt * ldt; e += 1024) {
         const int i = e / ldt, j = e % ldt;
         const int li = i - off, lj = j - off;
         float v = 0.f;
         if (li >= 0 && li < w && lj >= li && lj < w) v = Ts[li * TPS + lj];
-        T[(long)i * ldt + j] = v;
-        Th[(long)i * ldt + j] = (half_t)v;
+        T[(long)i * ld + j] = v;
+        Th[(long)i * ld + j] = (half_t)v;
     }
     for (int e = tid; e < ldt * ldt; e += 1024) {          // T^T: consecutive lanes walk a column of T (odd LDS stride)
         const int j = e / ldt, i = e % ldt;
         const int li = i - off, lj = j - off;
         float v = 0.f;
         if (li >= 0 && li < w && lj >= li && lj < w) v = Ts[li * TPS + lj];
-        Tth[(long)j * ldt + i] = (half_t)v;
+        Tth[(long)j * ld + i] = (half_t)v;
     }
     KT(); KT_DUMP(1, "t_panel load|inverse|store");
 }
@@ -1034,14 +1046,40 @@ void launch_trsm_diag(const float* R, long ldr, int k0, int kb, float* Y, long l
 }
 
 void launch_t_leaf(const float* S, int nslab, long slab_stride, int lds_, int a0, int c0, int c1, float* T, half_t* Th,
-                   half_t* Tth, int ldt, hipStream_t s) {
+                   half_t* Tth, int ldt, hipStream_t s, int ld) {
+    if (ld <= 0) ld = ldt;
     static bool attr = false;
     if (!attr) {
         (void)hipFuncSetAttribute((const void*)t_panel_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * TP * TPS * 4);
         attr = true;
     }
     hipLaunchKernelGGL(t_panel_kernel, dim3(1), dim3(1024), 2 * TP * TPS * 4, s, S, nslab, slab_stride, lds_, a0, c0, c1, T, Th,
-                       Tth, ldt);
+                       Tth, ldt, ld);
+}
+
+// fp16 copies of one column block of a block-level T: Th[0:rows, c:c+w] = T[0:rows, c:c+w], Tth[c:c+w, 0:rows] = its transpose
+__global__ __launch_bounds__(256) void t_colblock_h16_kernel(const float* __restrict__ T, half_t* __restrict__ Th,
+                                                             half_t* __restrict__ Tth, int ld, int rows, int c, int w) {
+    __shared__ float tile[32][33];
+    const int i0 = blockIdx.y * 32, j0 = blockIdx.x * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;          // 32 x 8
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const int i = i0 + ty + 8 * q, j = j0 + tx;
+        float v = 0.f;
+        if (i < rows && j < w) { v = T[(long)i * ld + c + j]; Th[(long)i * ld + c + j] = (half_t)v; }
+        tile[ty + 8 * q][tx] = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const int j = j0 + ty + 8 * q, i = i0 + tx;
+        if (i < rows && j < w) Tth[(long)(c + j) * ld + i] = (half_t)tile[tx][ty + 8 * q];
+    }
+}
+void launch_t_colblock_h16(const float* T, half_t* Th, half_t* Tth, int ld, int rows, int c, int w, hipStream_t s) {
+    if (rows <= 0 || w <= 0) return;
+    hipLaunchKernelGGL(t_colblock_h16_kernel, dim3((w + 31) / 32, (rows + 31) / 32), dim3(256), 0, s, T, Th, Tth, ld, rows, c, w);
 }
 
 // parent T = [[T_L, T_LR], [0, T_R]] placed inside the parent's 64-aligned reflector range

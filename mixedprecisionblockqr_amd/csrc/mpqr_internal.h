@@ -38,6 +38,8 @@ struct GemmArgs {
 void launch_gemm_f16(AMode am, EMode em, const GemmArgs& g, hipStream_t s);
 // 256 x 256 x 64 variant for large shapes (no split-K; operands readable up to the next multiple of 256 rows)
 bool launch_gemm2_f16(AMode am, EMode em, const GemmArgs& g, hipStream_t s, int config = 0);
+// number of CUs a stream may use (CU-masked streams): persistent GEMM grids are sized to it
+void gemm_register_stream_cus(hipStream_t s, int cus);
 
 // ------------------------------------------------------------------ fp32 helper GEMM (T merges, metrics)
 // C[M x N] (ldc) = alpha * opA(A) * opB(B) + beta*C, plain fp32 FMA, any sizes.
@@ -77,8 +79,11 @@ int gh_num_partials(const LeafArgs& a);
 void launch_gh_reduce_f32(const float* Sp, int nslab, float* S, hipStream_t s);
 
 // T of a leaf (<= 128 reflectors) from its Gram slabs S (row stride lds_, aligned range starting at a0)
+// ld: leading dimension of T / Th / Tth (0: ldt, the node's own contiguous T)
 void launch_t_leaf(const float* S, int nslab, long slab_stride, int lds_, int a0, int c0, int c1,
-                   float* T, half_t* Th, half_t* Tth, int ldt, hipStream_t s);
+                   float* T, half_t* Th, half_t* Tth, int ldt, hipStream_t s, int ld = 0);
+// fp16 copies (plain and transposed) of column block [c, c+w) x rows [0, rows) of a T with leading dimension ld
+void launch_t_colblock_h16(const float* T, half_t* Th, half_t* Tth, int ld, int rows, int c, int w, hipStream_t s);
 // assemble a parent T from its children and T_LR
 // one diagonal block of the back substitution R X = Y (in place in Y), kb <= 128
 void launch_trsm_diag(const float* R, long ldr, int k0, int kb, float* Y, long ldy, int nrhs, hipStream_t s);

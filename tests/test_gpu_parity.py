@@ -384,7 +384,12 @@ def test_least_squares_matches_oracle_and_lstsq(mp, h, po, m, n, r):
     X = mp.solve_ls(Y, handle=h)
     Ad = A.astype(np.float64)
     res = Ad @ X - Y
-    assert np.linalg.norm(Ad.T @ res) <= 5e-3 * np.linalg.norm(Ad) * np.linalg.norm(Y)
+    # normal equations of a backward-stable solve, (A+E)^T ((A+E) X - Y) = 0 with ||E|| <= eps ||A||, eps = the north-star
+    # backward error 1e-3:  ||A^T res|| <= eps ||A|| (||res|| + ||A|| ||X||); for tall (well-conditioned) systems the cruder
+    # 5e-3 ||A|| ||Y|| holds as well
+    assert np.linalg.norm(Ad.T @ res) <= 1e-3 * np.linalg.norm(Ad) * (np.linalg.norm(res) + np.linalg.norm(Ad, 2) * np.linalg.norm(X))
+    if m >= 3 * n // 2:
+        assert np.linalg.norm(Ad.T @ res) <= 5e-3 * np.linalg.norm(Ad) * np.linalg.norm(Y)
     QtY = mp.apply_qt(Y, handle=h)
     assert abs(np.linalg.norm(QtY) - np.linalg.norm(Y)) <= 2e-3 * np.linalg.norm(Y)          # Q^T is orthogonal
     assert np.linalg.norm(QtY[n:] ) <= np.linalg.norm(res) * (1 + 5e-2) + 1e-3 * np.linalg.norm(Y)
