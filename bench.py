@@ -24,6 +24,7 @@ CONFIGS = {  # name: (m, n, r)
     "c3": (2320, 1980, 64),     # synthetic bundle-adjustment Jacobian through the reference's text format (api.synthetic_jacobian)
 }
 PEAK_FP16_TFLOPS = 2500.0   # MI355X dense fp16 MFMA (MI355X_MICROARCH.md, chip-level parameters)
+PEAK_FP8_TFLOPS = 5000.0    # MI355X dense fp8 (block-scaled MFMA), same table
 PEAK_HBM_GBPS = 8000.0      # HBM3E, same table
 
 
@@ -95,6 +96,8 @@ def main():
     ap.add_argument("--outer-block", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-lookahead", action="store_true")
+    ap.add_argument("--precision", default=None, choices=["fp16", "fp8", "fp32"],
+                    help="operand precision of the trailing-update GEMMs (default: fp8 for c5 = BASELINE config 5, fp16 otherwise)")
     args = ap.parse_args()
 
     import torch
@@ -104,6 +107,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     m, n, r = CONFIGS[args.config]
+    prec_name = args.precision or ("fp8" if args.config == "c5" else "fp16")
     if world > 1 or os.environ.get("MPQR_FORCE_DIST") == "1":     # the env switch lets a 1-GPU box exercise the RCCL leg
         from mixedprecisionblockqr_amd import dist as mpdist
         return mpdist.bench_main(args, m, n, r, world, rank, local_rank)
@@ -122,7 +126,8 @@ def main():
         h.set_matrix(J)
         data = "synthetic block-sparse Jacobian (40 cameras, 580 points) read from the reference's text format"
     else:
-        h.plan(m, n, r, outer_block=args.outer_block, lookahead=not args.no_lookahead)
+        h.plan(m, n, r, outer_block=args.outer_block, lookahead=not args.no_lookahead,
+               precision={"fp16": mp.PREC_FP16, "fp8": mp.PREC_FP8, "fp32": mp.PREC_FP32}[prec_name])
         h.generate(1234)
     h.sync()
 
@@ -147,8 +152,12 @@ def main():
     roof = None
     if tm["n_far_launches"] > 0 and nn_t > 0:
         ach = tm["flops_far_nn"] / nn_t / 1e12
-        roof = {"bound": "mfma", "kernel": "gemm3_f16_kernel<E_SUB_F32> (far A2 -= V*Y^T, fp16 x fp16 -> fp32, K = outer block)",
-                "achieved": ach, "peak": PEAK_FP16_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_FP16_TFLOPS,
+        peak = PEAK_FP8_TFLOPS if prec_name == "fp8" else PEAK_FP16_TFLOPS
+        kname = ("gemm8_fp8_kernel<E_SUB_F32> (far A2 -= V*Y^T, e4m3 x e4m3 -> fp32 on v_mfma_scale_f32_32x32x64_f8f6f4, K = outer block)"
+                 if prec_name == "fp8" else
+                 "gemm6_f16_kernel<E_SUB_F32> (far A2 -= V*Y^T, fp16 x fp16 -> fp32, K = outer block)")
+        roof = {"bound": "mfma", "kernel": kname,
+                "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
                 "traffic": _pmc_traffic(), "launches": tm["n_far_launches"],
                 "avg_launch_ms": tm["ms_far_nn"] / tm["n_far_launches"],
                 "tn_achieved": (tm["flops_far_tn"] / (tm["ms_far_tn"] * 1e-3) / 1e12) if tm["ms_far_tn"] > 0 else None}
@@ -164,11 +173,13 @@ def main():
                     alg += 8.0 * W * N + 2.0 * K * (W + N)
         roof["hbm_view"] = {"algorithmic_bytes": alg, "achieved": alg / nn_t / 1e9, "peak": PEAK_HBM_GBPS, "unit": "GB/s",
                             "frac": alg / nn_t / 1e9 / PEAK_HBM_GBPS, "flop_per_byte": tm["flops_far_nn"] / alg,
-                            "ridge_flop_per_byte": PEAK_FP16_TFLOPS * 1e3 / PEAK_HBM_GBPS}
+                            "ridge_flop_per_byte": peak * 1e3 / PEAK_HBM_GBPS}
     out = {
-        "metric": "GFLOP/s block QR (fp16 MFMA trailing)", "value": fl["geqrf"] / dt / 1e9, "unit": "GFLOP/s",
+        "metric": "GFLOP/s block QR (%s MFMA trailing)" % prec_name, "value": fl["geqrf"] / dt / 1e9, "unit": "GFLOP/s",
         "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt * 1e3,
-        "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f16xf16->f32 (fp32 panel)",
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+        "dtype": {"fp16": "f16xf16->f32 (fp32 panel)", "fp32": "f32 (exact-f32 MFMA)",
+                  "fp8": "e4m3xe4m3->f32 far trailing update (fp32 panel; fp16 in-block updates and Q formation)"}[prec_name],
         "data": data,
         "config": {"workload": f"{m}x{n} {'sparse Jacobian' if args.config == 'c3' else 'random dense'}, block={r}, full Q formed", "m": m, "n": n, "block": r,
                    "outer_block": args.outer_block or 1024, "parallelism": "1 gpu"},

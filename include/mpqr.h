@@ -47,7 +47,11 @@ enum {
 /* operand precision of the trailing-update / Q GEMMs */
 enum {
     MPQR_PREC_FP16 = 0,       /* fp16 operands, fp32 accumulate on MFMA (default; Cuda/qr.cu:1049 twin) */
-    MPQR_PREC_FP32 = 1        /* fp32 operands, exact-f32 MFMA (Cuda/qr.cu:958 dev_block_qr_wy twin) */
+    MPQR_PREC_FP32 = 1,       /* fp32 operands, exact-f32 MFMA (Cuda/qr.cu:958 dev_block_qr_wy twin) */
+    MPQR_PREC_FP8 = 2         /* as FP16, but the far trailing updates (K = outer block) take fp8 e4m3 operands on the
+                                 block-scaled MFMA v_mfma_scale_f32_32x32x64_f8f6f4, fp32 accumulate (BASELINE config 5;
+                                 the dtype-templated WMMA GEMM of Cuda/mmult.cuh:252-300).  Panel fp32, in-block updates
+                                 and Q formation fp16.  4 significant bits per operand: see DESIGN.md for the measured error */
 };
 
 typedef struct mpqr_opts {

@@ -8,4 +8,4 @@ from . import _lib
 from .api import *  # noqa: F401,F403
 from .api import Handle, MpqrError
 
-PREC_FP16, PREC_FP32 = _lib.PREC_FP16, _lib.PREC_FP32
+PREC_FP16, PREC_FP32, PREC_FP8 = _lib.PREC_FP16, _lib.PREC_FP32, _lib.PREC_FP8

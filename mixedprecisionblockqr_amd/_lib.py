@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmpqr.so")
 
 OK, ERR_INVALID, ERR_NO_DEVICE, ERR_HIP, ERR_ALLOC, ERR_IO, ERR_STATE = range(7)
-PREC_FP16, PREC_FP32 = 0, 1
+PREC_FP16, PREC_FP32, PREC_FP8 = 0, 1, 2
 
 
 class MpqrOpts(C.Structure):

@@ -80,6 +80,12 @@ struct mpqr_handle_s {
     float* dQ = nullptr;
     half_t* Vh = nullptr;
     half_t* Vt = nullptr;
+    // MPQR_PREC_FP8 only: e4m3 operands of the far trailing update (kernels_fp8.hip)
+    uint8_t* V8n = nullptr;   // [row][reflector of the block]  (2^8 V), ld = ld8k
+    uint8_t* V8t = nullptr;   // [reflector of the block][row]  (2^8 V), ld = m_pad
+    uint8_t* A8t = nullptr;   // [column][row]  (s A2)^T of the columns being updated, ld = m_pad
+    uint8_t* Y8 = nullptr;    // [column][reflector]  (2^-2 Y), ld = ld8k
+    long ld8k = 0; int v8_node = -1;          // node whose reflectors V8n / V8t currently hold
     float* Vf = nullptr;      // MPQR_PREC_FP32 only: fp32 reflectors [row][reflector], zero above the diagonal
     float* Yf = nullptr;      // MPQR_PREC_FP32 only: fp32 Y = X T'
     float* vdiag = nullptr;
@@ -160,7 +166,7 @@ int dalloc(mpqr_handle_t h, T** p, size_t elems) {
 void free_plan(mpqr_handle_t h) {
     void* ptrs[] = {h->dA, h->dA0, h->dQ, h->Vh, h->Vt, h->vdiag, h->Xt, h->Yt, h->S, h->P, h->tmp1, h->tmp2,
                     h->Tf, h->Th, h->Tth, h->dstage, h->Gp, h->Gs, h->Cv, h->dflag, h->Vf, h->Yf, h->Xt1, h->Yt1, h->Sp,
-                    h->rbTf, h->rbTh, h->rbTth, h->Sleaf};
+                    h->rbTf, h->rbTh, h->rbTth, h->Sleaf, h->V8n, h->V8t, h->A8t, h->Y8};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     h->dA = h->dA0 = h->dQ = nullptr; h->Vh = h->Vt = nullptr; h->vdiag = nullptr; h->Xt = nullptr; h->Yt = nullptr;
     h->S = nullptr; h->P = nullptr; h->tmp1 = h->tmp2 = nullptr; h->Tf = nullptr; h->Th = h->Tth = nullptr;
@@ -168,6 +174,7 @@ void free_plan(mpqr_handle_t h) {
     h->Gp = nullptr; h->Gs = nullptr; h->Cv = nullptr; h->dflag = nullptr; h->Vf = nullptr; h->Yf = nullptr;
     h->Xt1 = nullptr; h->Yt1 = nullptr; h->Sp = nullptr;
     h->rbTf = nullptr; h->rbTh = h->rbTth = nullptr; h->rb_elems = 0; h->nflag = 0; h->leaf_robust.clear(); h->Sleaf = nullptr;
+    h->V8n = h->V8t = h->A8t = h->Y8 = nullptr; h->v8_node = -1;
     for (hipEvent_t e : h->chain_ev) (void)hipEventDestroy(e);
     h->chain_ev.clear(); h->chain_used = 0; h->far_used = 0;
     for (hipEvent_t e : h->ev_node) (void)hipEventDestroy(e);
@@ -283,7 +290,7 @@ int gram(mpqr_handle_t h, const Node& L, const Node& R, int* nslab, long* slab, 
 
 // C[rows >= rdown(nd.c0,64)][cols clo..chi) <- (I - V T' V^T) C,  T' = T^T (trans_t) or T
 void apply_node(mpqr_handle_t h, const Node& nd, float* C, long ldc, int clo, int chi, bool trans_t, float in_scale,
-                bool record, int lane = 0) {
+                bool record, int lane = 0, bool far = false) {
     if (chi <= clo) return;
     hipStream_t st = lane ? h->s1 : h->s0;                 // lane 1: far-update stream with its own scratch
     float* const Xt = lane ? h->Xt1 : h->Xt;
@@ -332,8 +339,28 @@ void apply_node(mpqr_handle_t h, const Node& nd, float* C, long ldc, int clo, in
     g1.slab_out_stride = slab;
     if (record) (void)hipEventRecord(e0, st);
     hipStream_t st1 = (h->op1_stream && lane == 0) ? h->op1_stream : st;     // flat schedule: X on the side stream, T on the chain
+    // MPQR_PREC_FP8: the two large GEMMs of a FAR update take e4m3 operands (kernels_fp8.hip); shapes the fp8 kernel does
+    // not cover (K not a multiple of 128) stay on the fp16 path
+    const bool f8 = far && h->V8n && (Kr % 128) == 0 && (Kw % 128) == 0 && (rlo % 16) == 0 && nd.a0 == nd.c0;
+    if (f8) {
+        if (h->v8_node != nd.id) {                          // the block's reflectors, once per block: 2^8 V in both layouts
+            launch_quant_h16_fp8(h->Vh + (long)rlo * h->ldvh + nd.a0, h->ldvh, h->V8n, h->ld8k, Kw, Kr, 256.f, st);
+            launch_quant_h16_fp8(h->Vt + (long)nd.a0 * h->ldvt + rlo, h->ldvt, h->V8t, h->m_pad, Kr, Kw, 256.f, st);
+            h->v8_node = nd.id;
+        }
+        launch_quant_transpose_f32_fp8(C + (long)rlo * ldc + clo_al, ldc, h->A8t, h->m_pad, Kw, M1, in_scale, st);   // (s A2)^T
+        GemmArgs f1 = g1;
+        f1.A = h->A8t; f1.lda = h->m_pad; f1.Bt = (const half_t*)h->V8t; f1.ldb = h->m_pad; f1.alpha = 1.f / 256.f;
+        const int t256 = ((M1 + 255) / 256) * ((Kr + 255) / 256);
+        f1.nsplit = 1;
+        if (t256 < 192) f1.nsplit = std::max(1, std::min({(Kw / 128) / 8, (256 + t256 - 1) / t256, 16}));
+        while (f1.nsplit > 1 && (size_t)f1.nsplit * (size_t)slab > h->xt_elems) f1.nsplit--;
+        launch_gemm_fp8(E_STORE_F32, f1, st);
+        if (f1.nsplit > 1) launch_slab_reduce(Xt, f1.nsplit, slab, slab, Xt, st);
+    } else {
     gemm_dispatch(A_F32T, E_STORE_F32, g1, st1);
     if (g1.nsplit > 1) launch_slab_reduce(Xt, g1.nsplit, slab, slab, Xt, st1);
+    }
     if (st1 != st) { (void)hipEventRecord(h->ev_x, st1); (void)hipStreamWaitEvent(st, h->ev_x, 0); }
     if (record) (void)hipEventRecord(e1, st);
     // op2: Yt[M1 x Kr] = fp16( Xt * T' ) -- the first use of T: it was built on the T stream beside op1
@@ -353,6 +380,13 @@ void apply_node(mpqr_handle_t h, const Node& nd, float* C, long ldc, int clo, in
     g3.M = Kw; g3.N = M1; g3.K = Kr;
     g3.col_lo = clo - clo_al; g3.alpha = 1.0f / in_scale; g3.in_scale = 1.f; g3.nsplit = 1;
     if (record) (void)hipEventRecord(e2, st);
+    if (f8) {
+        launch_quant_h16_fp8(Yt, Kr, h->Y8, h->ld8k, M1, Kr, 0.25f, st);                       // 2^-2 Y
+        GemmArgs f3 = g3;
+        f3.A = h->V8n; f3.lda = h->ld8k; f3.Bt = (const half_t*)h->Y8; f3.ldb = h->ld8k;
+        f3.alpha = g3.alpha * (4.f / 256.f);
+        launch_gemm_fp8(E_SUB_F32, f3, st);
+    } else
     gemm_dispatch(A_H16, E_SUB_F32, g3, st);
     if (record) {
         (void)hipEventRecord(e3, st);
@@ -768,7 +802,7 @@ static int plan_common(mpqr_handle_t h, int m, int n, int r, const mpqr_opts* op
     HIPCHK(h, hipSetDevice(h->device));
     mpqr_opts o;
     if (opts) o = *opts; else mpqr_default_opts(&o);
-    if (o.precision != MPQR_PREC_FP16 && o.precision != MPQR_PREC_FP32)
+    if (o.precision != MPQR_PREC_FP16 && o.precision != MPQR_PREC_FP32 && o.precision != MPQR_PREC_FP8)
         return fail(h, MPQR_ERR_INVALID, "unknown precision");
     if (h->planned && h->m == m && h->n == n && h->r == r && h->world == world && h->rank == rank &&
         memcmp(&o, &h->opts, sizeof o) == 0)
@@ -781,7 +815,7 @@ static int plan_common(mpqr_handle_t h, int m, int n, int r, const mpqr_opts* op
         // sub-tree is longer than the GEMM it hides behind: 60.9 vs 59.0 ms at 16384^2); the flat block schedule
         // (factor_block_flat) needs only the leaf's own T on the chain and is what the T stream is for (53.0 ms).
         const char* e = getenv("MPQR_TSTREAM");
-        h->tq_on = h->sT != nullptr && o.precision == MPQR_PREC_FP16 && !(e && atoi(e) == 0);
+        h->tq_on = h->sT != nullptr && o.precision != MPQR_PREC_FP32 && !(e && atoi(e) == 0);
     }
     if (const char* e = getenv("MPQR_GH_MIN_ROWS")) h->gh_min_rows = atoi(e);      // tuning hook
     h->m_pad = rup(m, 256); h->n_pad = rup(n, 256);
@@ -823,11 +857,20 @@ static int plan_common(mpqr_handle_t h, int m, int n, int r, const mpqr_opts* op
         if ((rc = dalloc(h, &h->Vf, (size_t)(h->m_pad + 256) * h->n_pad))) return rc;
         if ((rc = dalloc(h, &h->Yf, maxdim * (size_t)max_ldt + (size_t)256 * max_ldt))) return rc;
     }
+    if (o.precision == MPQR_PREC_FP8) {
+        if (world != 1) return fail(h, MPQR_ERR_INVALID, "MPQR_PREC_FP8 is single-GPU only");
+        h->ld8k = rup(max_ldt, 128);
+        const size_t e1 = (size_t)(h->m_pad + 256) * h->ld8k, e2 = (size_t)(h->ld8k + 256) * h->m_pad;
+        const size_t e3 = (size_t)(h->n_pad + 256) * h->m_pad, e4 = (size_t)(h->n_pad + 256) * h->ld8k;
+        if ((rc = dalloc(h, &h->V8n, e1)) || (rc = dalloc(h, &h->V8t, e2)) || (rc = dalloc(h, &h->A8t, e3)) || (rc = dalloc(h, &h->Y8, e4))) return rc;
+        HIPCHK(h, hipMemsetAsync(h->V8n, 0, e1, h->s0)); HIPCHK(h, hipMemsetAsync(h->V8t, 0, e2, h->s0));
+        HIPCHK(h, hipMemsetAsync(h->A8t, 0, e3, h->s0)); HIPCHK(h, hipMemsetAsync(h->Y8, 0, e4, h->s0));
+    }
     if ((rc = dalloc(h, &h->Xt, h->xt_elems + (size_t)256 * max_ldt))) return rc;
     if ((rc = dalloc(h, &h->Yt, h->yt_elems + (size_t)256 * max_ldt))) return rc;
     HIPCHK(h, hipMemsetAsync(h->Xt, 0, (h->xt_elems + (size_t)256 * max_ldt) * sizeof(float), h->s0));
     HIPCHK(h, hipMemsetAsync(h->Yt, 0, (h->yt_elems + (size_t)256 * max_ldt) * sizeof(half_t), h->s0));
-    if (o.lookahead && world == 1 && o.precision == MPQR_PREC_FP16) {
+    if (o.lookahead && world == 1 && o.precision != MPQR_PREC_FP32) {
         if ((rc = dalloc(h, &h->Xt1, h->xt_elems + (size_t)256 * max_ldt))) return rc;
         if ((rc = dalloc(h, &h->Yt1, h->yt_elems + (size_t)256 * max_ldt))) return rc;
         HIPCHK(h, hipMemsetAsync(h->Xt1, 0, (h->xt_elems + (size_t)256 * max_ldt) * sizeof(float), h->s0));
@@ -927,7 +970,7 @@ int mpqr_generate_matrix(mpqr_handle_t h, uint64_t seed) {
 // enqueue copy-in + the whole block loop; flags[id] != 0: the Gram-Householder leaf `id` was too ill-conditioned
 static int run_block_loop(mpqr_handle_t h, std::vector<int>& flags) {
     int rc;
-    h->far_used = 0; h->far_flops.clear(); h->chain_used = 0;
+    h->far_used = 0; h->far_flops.clear(); h->chain_used = 0; h->v8_node = -1;
     HIPCHK(h, hipEventRecord(h->ev[0], h->s0));
     HIPCHK(h, hipMemcpyAsync(h->dA, h->dA0, (size_t)h->m_pad * h->lda * sizeof(float), hipMemcpyDeviceToDevice, h->s0));
     HIPCHK(h, hipMemsetAsync(h->dflag, 0, (size_t)h->nflag * sizeof(int), h->s0));
@@ -956,7 +999,7 @@ static int run_block_loop(mpqr_handle_t h, std::vector<int>& flags) {
         if (timed) { HIPCHK(h, hipEventRecord(h->chain_ev[h->chain_used + 1], h->s0)); h->chain_used += 2; }
         Range rg("mpqr:far_update");
         if (!la) {
-            apply_node(h, nd, h->dA, h->lda, nd.c1, h->n, true, h->a_scale, true);
+            apply_node(h, nd, h->dA, h->lda, nd.c1, h->n, true, h->a_scale, true, 0, true);
             continue;
         }
         HIPCHK(h, hipEventRecord(h->ev_node[t], h->s0));
@@ -966,11 +1009,11 @@ static int run_block_loop(mpqr_handle_t h, std::vector<int>& flags) {
             int fl = h->tops[t + 1];
             while (h->nodes[fl].left >= 0) fl = h->nodes[fl].left;
             const int c_first = h->nodes[fl].c1;                                           // end of the next block's first leaf
-            apply_node(h, nd, h->dA, h->lda, nx.c0, c_first, true, h->a_scale, false, 1);  // next block's first leaf first ...
+            apply_node(h, nd, h->dA, h->lda, nx.c0, c_first, true, h->a_scale, false, 1, true);  // next block's first leaf first ...
             HIPCHK(h, hipEventRecord(h->ev_cols[t + 1], h->s1));
-            apply_node(h, nd, h->dA, h->lda, c_first, nx.c1, true, h->a_scale, true, 1);   // ... then the rest of that block ...
+            apply_node(h, nd, h->dA, h->lda, c_first, nx.c1, true, h->a_scale, true, 1, true);   // ... then the rest of that block ...
             HIPCHK(h, hipEventRecord(h->ev_cols2[t + 1], h->s1));
-            apply_node(h, nd, h->dA, h->lda, nx.c1, h->n, true, h->a_scale, true, 1);      // ... the rest overlaps its panels
+            apply_node(h, nd, h->dA, h->lda, nx.c1, h->n, true, h->a_scale, true, 1, true);      // ... the rest overlaps its panels
         }
     }
     if (la) {   // join: everything after this point (Q formation, read-backs) is ordered after both streams
@@ -1244,7 +1287,7 @@ static int stage_load(mpqr_handle_t h, const float* A, int m, int n, int r, int 
     launch_unpack_factor(h->dstage, m, n, c0, c1, h->dA, h->lda, h->vdiag, h->Vh, h->ldvh, h->Vt, h->ldvt, h->s0);
     if (h->Vf && c1 > c0) launch_extract_vf(h->dA, h->lda, h->vdiag, h->Vf, h->n_pad, h->m, c0, c1, h->s0);
     HIPCHK(h, hipStreamSynchronize(h->s0));
-    h->Aeff = h->dA;
+    h->Aeff = h->dA; h->v8_node = -1;
     h->factored = false; h->q_formed = false; h->have_input = false;
     return MPQR_OK;
 }
@@ -1367,14 +1410,14 @@ int mpqr_wy_transform_f32(mpqr_handle_t h, const float* A, int m, int n, int go,
 int mpqr_apply_panel_to_trailing_f32(mpqr_handle_t h, float* A, int m, int n, int go, int pw, int precision) {
     int rc = check_shape(h, m, n, 1); if (rc) return rc;
     if (!A || go < 0 || pw < 1 || go + pw > n) return fail(h, MPQR_ERR_INVALID, "bad panel range");
-    if (precision != MPQR_PREC_FP16 && precision != MPQR_PREC_FP32) return fail(h, MPQR_ERR_INVALID, "unknown precision");
+    if (precision != MPQR_PREC_FP16 && precision != MPQR_PREC_FP32 && precision != MPQR_PREC_FP8) return fail(h, MPQR_ERR_INVALID, "unknown precision");
     const int c0 = go, c1 = go + pw;
     if ((rc = stage_load(h, A, m, n, pw, c0, c1, precision))) return rc;
     if ((rc = compute_scale(h, h->dA))) return rc;
     StageTree st;
     if ((rc = stage_tree_begin(h, st, c0, c1, pw))) { stage_tree_end(h, st); return rc; }
     if ((rc = factor_node(h, st.root, false))) { stage_tree_end(h, st); return rc; }
-    apply_node(h, h->nodes[st.root], h->dA, h->lda, c1, n, true, h->a_scale, false);
+    apply_node(h, h->nodes[st.root], h->dA, h->lda, c1, n, true, h->a_scale, false, 0, true);
     stage_tree_end(h, st);
     if (c1 < n) {
         // only A[go:m, tau:n] changes (Cuda/qr.cu:1098-1106)

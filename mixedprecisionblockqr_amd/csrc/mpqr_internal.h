@@ -41,6 +41,14 @@ bool launch_gemm2_f16(AMode am, EMode em, const GemmArgs& g, hipStream_t s, int 
 // number of CUs a stream may use (CU-masked streams): persistent GEMM grids are sized to it
 void gemm_register_stream_cus(hipStream_t s, int cus);
 
+// ------------------------------------------------------------------ fp8 (e4m3) operand path (kernels_fp8.hip)
+// C (-)= alpha A[M][K] Bt[N][K]^T with 1-byte e4m3 operands (g.A / g.Bt point at bytes, lda / ldb in bytes), K % 128 == 0;
+// E_SUB_F32 or E_STORE_F32 (split-K over g.nsplit slabs).  false: shape not supported.
+bool launch_gemm_fp8(EMode em, const GemmArgs& g, hipStream_t s);
+void launch_quant_h16_fp8(const half_t* src, long lds_, uint8_t* dst, long ldd, int rows, int cols, float scale, hipStream_t s);
+// dst[c][r] = fp8(scale * src[r][c]); rows % 64 == 0
+void launch_quant_transpose_f32_fp8(const float* src, long lds_, uint8_t* dst, long ldd, int rows, int cols, float scale, hipStream_t s);
+
 // ------------------------------------------------------------------ fp32 helper GEMM (T merges, metrics)
 // C[M x N] (ldc) = alpha * opA(A) * opB(B) + beta*C, plain fp32 FMA, any sizes.
 // slabs: A is summed over nslab_a slabs (stride slab_a) while loading.

@@ -223,3 +223,16 @@ def read_euroc_jacobian(path):
 
 def round_fp16(x):
     return np.asarray(x, np.float32).astype(np.float16).astype(np.float32)
+
+
+def round_e4m3(x):
+    """Round to OCP fp8 e4m3 (4 exponent bits, bias 7, 3 mantissa bits, max 448, subnormals down to 2^-9), round to
+    nearest even, saturating -- the conversion v_cvt_pk_fp8_f32 performs on gfx950 (test-side emulation of the fp8
+    operand path of BASELINE config 5)."""
+    x = np.clip(np.asarray(x, np.float64), -448.0, 448.0)
+    ax = np.abs(x)
+    e = np.floor(np.log2(np.maximum(ax, 2.0 ** -20)))
+    e = np.maximum(e, -6.0)                                  # subnormal range shares the exponent of 2^-6
+    q = 2.0 ** (e - 3)                                       # spacing: 3 mantissa bits
+    return (np.sign(x) * np.round(ax / q) * q).astype(np.float32)   # np.round: half to even
+

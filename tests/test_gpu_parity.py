@@ -509,6 +509,79 @@ def test_fp32_trailing_update(mp, h, po):
     np.testing.assert_allclose(Ag[go:m, go + pw:], want[go:, go + pw:], atol=2e-5)
 
 
+# ---------------------------------------------------------------- fp8 operand path (BASELINE config 5)
+def test_fp8_trailing_update_matches_e4m3_emulation(mp, h, po):
+    """The far-update GEMMs with e4m3 operands (v_mfma_scale_f32_32x32x64_f8f6f4, kernels_fp8.hip) against a NumPy emulation
+    that quantises the same operands the same way: X = (s A2)^T V with fp8(s A2), fp8(2^8 V); Y = fp16(X T);
+    A2 -= (1/s) V Y^T with fp8(2^8 V), fp8(2^-2 Y).  Also: the result is an fp8-accuracy update, not an fp16 one."""
+    m, n, go, pw = 1024, 768, 128, 128
+    A = po.generate(m, n, seed=3)
+    Ac = po.padded(A)
+    po.lib().orc_householder_qr(Ac, m, n, go, pw)
+    Ag = Ac.copy()
+    mp.apply_panel_to_trailing(Ag, m, n, go, pw, precision=mp.PREC_FP8, handle=h)
+    # --- emulation
+    V = po.extract_V(Ac, m, n, go, pw).astype(np.float64)                 # (m-go) x pw, unit-norm reflectors
+    Vh = po.round_fp16(V)
+    T = po.round_fp16(po.compact_T(Ac, m, n, go, pw, round_v_fp16=True))
+    A2 = Ac[go:m, go + pw:].astype(np.float64)
+    mx = float(np.abs(Ac[:m]).max())
+    s = 2.0 ** (8 - np.frexp(np.float32(mx) * np.sqrt(np.float32(m)))[1])     # the library's power-of-two scale
+    V8 = po.round_e4m3(256.0 * Vh).astype(np.float64)
+    X = (po.round_e4m3(s * A2).astype(np.float64).T @ V8) / 256.0
+    Y = po.round_fp16(X.astype(np.float32) @ T.astype(np.float32)).astype(np.float64)      # Q_panel^T = I - V T^T V^T: Y^T = T^T X^T
+    Y8 = po.round_e4m3(0.25 * Y).astype(np.float64)
+    want = A2 - (V8 @ Y8.T) / (64.0 * s)
+    exact = A2 - V @ (po.compact_T(Ac, m, n, go, pw).astype(np.float64).T @ (V.T @ A2))
+    got = Ag[go:m, go + pw:].astype(np.float64)
+    # same quantised operands -> the same update, element for element, except where the fp32 accumulation order moves an
+    # X or Y entry across an fp16 / e4m3 rounding boundary (one e4m3 ulp = 6 % of that entry)
+    assert relF(got, want) <= 1e-2, relF(got, want)
+    assert np.median(np.abs(got - want)) <= 1e-5 * np.abs(want).max()
+    e8 = relF(got, exact)
+    assert 2e-3 <= e8 <= 1e-1, e8                                          # 4 significant bits per operand, honestly
+    assert np.array_equal(Ag[:, :go + pw], Ac[:, :go + pw]) and np.array_equal(Ag[:go], Ac[:go])
+
+
+def test_fp8_factorisation_4096x2048(mp):
+    """MPQR_PREC_FP8 through the device-resident driver: far updates in fp8, everything else as in fp16 mode.  The
+    backward error is the fp8 operand error (reported, not hidden); Q stays orthogonal (it is formed in fp16)."""
+    hh = mp.Handle(0)
+    try:
+        m, n, r = 4096, 2048, 256
+        hh.plan(m, n, r, precision=mp.PREC_FP8)
+        hh.generate(1234); hh.factor(); hh.sync()
+        m8 = hh.metrics()
+        hh.plan(m, n, r, precision=mp.PREC_FP16)
+        hh.generate(1234); hh.factor(); hh.sync()
+        m16 = hh.metrics()
+        assert m16["backward_error"] <= 1e-3
+        # e4m3 keeps 4 significant bits: each far update carries a relative error of ~5 % of the UPDATE (stage test above),
+        # and on U[0,1) data the first updates are as large as the matrix itself -> backward error of a few 1e-2.
+        # Reported as measured (DESIGN.md section 4); the 1e-3 north-star bound is met by MPQR_PREC_FP16 only.
+        assert 2 * m16["backward_error"] <= m8["backward_error"] <= 6e-2, (m8, m16)
+        assert m8["q_error_fro"] <= 2e-3 * np.sqrt(m) and m8["lower_trapezoid"] == 0.0, m8
+    finally:
+        hh.close()
+
+
+def test_config5_full_size_fp8_properties(mp):
+    """BASELINE config 5 at full size with its stated arithmetic: 65536 x 8192, r = 256, fp8 far trailing update."""
+    hh = mp.Handle(0)
+    try:
+        m, n, r = 65536, 8192, 256
+        hh.plan(m, n, r, precision=mp.PREC_FP8)
+        hh.generate(1234); hh.factor(); hh.sync()
+        mt = hh.metrics()
+        assert np.isfinite(mt["backward_error"]) and 2e-3 <= mt["backward_error"] <= 6e-2, mt   # fp8 operands: 3.6e-2 measured, DESIGN.md
+        assert mt["q_error_fro"] <= 2e-3 * np.sqrt(m), mt
+        assert mt["lower_trapezoid"] == 0.0
+        t = hh.timings()
+        assert t["n_far_launches"] >= 1 and t["n_passes"] == 1
+    finally:
+        hh.close()
+
+
 # ---------------------------------------------------------------- distributed path on the one GPU of the box
 def _run_lockstep(mp, engines):
     """Drive `world` GpuEngines (all on cuda:0) through the distributed schedule in lock step: exactly the calls
