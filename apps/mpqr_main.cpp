@@ -6,8 +6,11 @@
 // for f in { householder + backward accumulation, fp32 block QR, mixed-precision block QR }, printing the three
 // error lines and appending the reference's CSV log rows (log/cpu_householder.txt, log/gpu_block.txt).
 //
-//   usage: mpqr_main [--jacobians DIR] [--m M --n N --r R] [--seed S]
-// build: make -C apps    (g++, links ../mixedprecisionblockqr_amd/libmpqr.so)
+//   usage: mpqr_main [--jacobians DIR] [--m M --n N --r R] [--seed S] [--dtype fp16|fp32|fp8] [--gpus N]
+//   --gpus N (with --m --n --r): the multi-GPU host driver -- one host thread per GPU of this node, column superblocks dealt
+//            round-robin (mpqr_dist_* step functions of the C ABI), V,T of every block broadcast with ncclBroadcast (RCCL over
+//            xGMI) on a communication stream of its own, look-ahead schedule of SURVEY.md 8e.  The reference is single-GPU.
+// build: make -C apps    (g++, links ../mixedprecisionblockqr_amd/libmpqr.so, librccl, libamdhip64)
 #include <algorithm>
 #include <chrono>
 #include <cmath>
@@ -15,6 +18,15 @@
 #include <cstdlib>
 #include <cstring>
 #include <vector>
+
+#include <atomic>
+#include <condition_variable>
+#include <mutex>
+#include <thread>
+
+#define __HIP_PLATFORM_AMD__ 1
+#include <hip/hip_runtime_api.h>
+#include <rccl/rccl.h>
 
 #include "../include/mpqr_reference_api.hpp"
 
@@ -62,6 +74,15 @@ static void test_dev_mixed_precision_block_qr(int m, int n, int r, float* A_in) 
              [](float* A, float* Q, int m_, int n_, int r_) { dev_mixed_precision_block_qr(A, Q, m_, n_, r_); });
 }
 
+static void test_dev_fp8_block_qr(int m, int n, int r, float* A_in) {
+    // fp8 operands: 4 significant bits -> criterion 2^-4 * m (the reference's form, qr.cu:120, with the operand precision)
+    run_case("GPU fp8 block QR (BASELINE config 5 arithmetic)", "gpu_block", 4, m, n, r, A_in,
+             [](float* A, float* Q, int m_, int n_, int r_) {
+                 mpqr_opts o; mpqr_default_opts(&o); o.precision = MPQR_PREC_FP8;
+                 mpqr_ref::check(mpqr_block_qr_f32(mpqr_ref::handle(), A, Q, m_, n_, r_, &o), "fp8 block QR");
+             });
+}
+
 static void test_qr_by_random_matrix(QR_FUNC f) {
     static const QRProblemSize dims[20] = {{6, 4, 2}, {6, 4, 1}, {6, 4, 3}, {12, 8, 4}, {12, 8, 5}, {12, 8, 6}, {12, 8, 2},
         {12, 8, 8}, {12, 8, 3}, {24, 16, 8}, {24, 16, 12}, {60, 40, 8}, {60, 40, 16}, {80, 80, 16}, {97, 90, 16},
@@ -90,18 +111,125 @@ static void test_qr(QR_FUNC f, const char* dir) {
     if (list.empty()) printf("no Jacobian files under %s (the reference's data blob is a git-LFS pointer)\n", dir);
 }
 
+// ---------------------------------------------------------------- multi-GPU host driver (RCCL)
+namespace {
+struct HostBarrier {                      // all rank threads meet here (absmax exchange, start / stop of the timed region)
+    std::mutex mu; std::condition_variable cv; int count = 0, gen = 0, n;
+    explicit HostBarrier(int n_) : n(n_) {}
+    void wait() {
+        std::unique_lock<std::mutex> lk(mu);
+        const int g = gen;
+        if (++count == n) { count = 0; gen++; cv.notify_all(); }
+        else cv.wait(lk, [&] { return gen != g; });
+    }
+};
+#define MG_CHK(call) do { int rc_ = (call); if (rc_ != MPQR_OK) { fprintf(stderr, "rank %d: %s failed: %d (%s)\n", rank, #call, rc_, mpqr_last_error(h)); failed = true; return; } } while (0)
+#define MG_HIP(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { fprintf(stderr, "rank %d: %s failed: %s\n", rank, #call, hipGetErrorString(e_)); failed = true; return; } } while (0)
+#define MG_NCCL(call) do { ncclResult_t r_ = (call); if (r_ != ncclSuccess) { fprintf(stderr, "rank %d: %s failed: %s\n", rank, #call, ncclGetErrorString(r_)); failed = true; return; } } while (0)
+}  // namespace
+
+static int run_multi_gpu(int world, int m, int n, int r, uint64_t seed, int steps) {
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < world) { fprintf(stderr, "error: %d GPUs requested, %d visible\n", world, ndev); return 1; }
+    std::vector<int> devs(world);
+    for (int i = 0; i < world; i++) devs[i] = i;
+    std::vector<ncclComm_t> comms(world);
+    if (ncclCommInitAll(comms.data(), world, devs.data()) != ncclSuccess) { fprintf(stderr, "error: ncclCommInitAll failed\n"); return 1; }
+    const bool comm_on = world > 1 || getenv("MPQR_MG_FORCE_BCAST") != nullptr;   // the env switch exercises RCCL on a 1-GPU box
+    HostBarrier bar(world);
+    std::vector<float> amax(world, 0.f);
+    std::vector<double> ms(world, 0.0);
+    std::atomic<bool> failed{false};
+    mpqr_opts o; mpqr_default_opts(&o);
+    if (world > 1) o.outer_block = std::max(r, std::min(1024, (n / (2 * world)) / r * r));   // >= 2 blocks per rank (see dist.py)
+    auto rank_main = [&](int rank) {
+        mpqr_handle_t h = nullptr;
+        hipStream_t cs = nullptr;                                       // communication stream: broadcasts only
+        void* bufs[2] = {nullptr, nullptr}; long cap[2] = {0, 0};
+        MG_HIP(hipSetDevice(rank));
+        MG_CHK(mpqr_create(&h, rank));
+        MG_CHK(mpqr_dist_plan(h, m, n, r, world, rank, &o));
+        MG_HIP(hipStreamCreateWithFlags(&cs, hipStreamNonBlocking));
+        MG_CHK(mpqr_dist_generate_matrix(h, seed));
+        const int nb = mpqr_dist_num_blocks(h);
+        auto buffer = [&](int s) -> void* {
+            const long need = mpqr_dist_block_bytes(h, s);
+            if (cap[s & 1] < need) { if (bufs[s & 1]) (void)hipFree(bufs[s & 1]); if (hipMalloc(&bufs[s & 1], (size_t)need) != hipSuccess) return nullptr; cap[s & 1] = need; }
+            return bufs[s & 1];
+        };
+        auto factor = [&]() {
+            MG_CHK(mpqr_dist_local_absmax(h, &amax[rank]));
+            bar.wait();
+            float gmax = 0.f; for (float v : amax) gmax = std::max(gmax, v);
+            bar.wait();
+            MG_CHK(mpqr_dist_begin(h, gmax));
+            if (mpqr_dist_block_owner(h, 0) == rank) { MG_CHK(mpqr_dist_factor_block(h, 0)); if (comm_on) MG_CHK(mpqr_dist_pack_block(h, 0, buffer(0))); }
+            for (int s = 0; s < nb; s++) {
+                const int owner = mpqr_dist_block_owner(h, s);
+                if (comm_on) {
+                    void* b = buffer(s);
+                    MG_NCCL(ncclBroadcast(b, b, (size_t)mpqr_dist_block_bytes(h, s), ncclUint8, owner, comms[rank], cs));
+                    MG_HIP(hipStreamSynchronize(cs));                   // the GPU keeps working on the previous update meanwhile
+                    MG_CHK(mpqr_dist_unpack_block(h, s, b));
+                }
+                if (s + 1 < nb && mpqr_dist_block_owner(h, s + 1) == rank) {     // look-ahead: my block first, the rest beside its factorisation
+                    MG_CHK(mpqr_dist_update_part(h, s, 0));
+                    MG_CHK(mpqr_dist_update_part(h, s, 1));
+                    MG_CHK(mpqr_dist_factor_block(h, s + 1));
+                    if (comm_on) MG_CHK(mpqr_dist_pack_block(h, s + 1, buffer(s + 1)));
+                } else {
+                    MG_CHK(mpqr_dist_update_part(h, s, 1));
+                }
+            }
+            MG_CHK(mpqr_dist_form_q(h));
+            MG_CHK(mpqr_sync(h));
+        };
+        factor();                                                        // warm-up
+        bar.wait();
+        const auto t0 = std::chrono::high_resolution_clock::now();
+        for (int it = 0; it < steps && !failed; it++) factor();
+        bar.wait();
+        ms[rank] = std::chrono::duration<double, std::milli>(std::chrono::high_resolution_clock::now() - t0).count() / steps;
+        for (void* b : bufs) if (b) (void)hipFree(b);
+        (void)hipStreamDestroy(cs);
+        (void)mpqr_destroy(h);
+    };
+    std::vector<std::thread> th;
+    for (int rk = 0; rk < world; rk++) th.emplace_back(rank_main, rk);
+    for (auto& t : th) t.join();
+    for (auto& c : comms) (void)ncclCommDestroy(c);
+    if (failed) return 1;
+    double t = 0; for (double v : ms) t = std::max(t, v);
+    const double gf = mpqr_flops_geqrf(m, n) / (t * 1e-3) / 1e9;
+    printf("multi-GPU block QR: %d GPU(s), %d x %d, r = %d, outer block %d: %.2f ms per factorisation incl. Q, %.1f GFLOP/s (GEQRF-equivalent)\n",
+           world, m, n, r, o.outer_block ? o.outer_block : 1024, t, gf);
+    return 0;
+}
+
 int main(int argc, char** argv) {
-    const char* jac = nullptr; int m = 0, n = 0, r = 0;
+    const char* jac = nullptr; int m = 0, n = 0, r = 0, gpus = 0, steps = 3; const char* dtype = "fp16";
     for (int i = 1; i < argc; i++) {
         if (!strcmp(argv[i], "--jacobians") && i + 1 < argc) jac = argv[++i];
         else if (!strcmp(argv[i], "--m") && i + 1 < argc) m = atoi(argv[++i]);
         else if (!strcmp(argv[i], "--n") && i + 1 < argc) n = atoi(argv[++i]);
         else if (!strcmp(argv[i], "--r") && i + 1 < argc) r = atoi(argv[++i]);
         else if (!strcmp(argv[i], "--seed") && i + 1 < argc) g_seed = strtoull(argv[++i], nullptr, 10);
-        else { fprintf(stderr, "usage: %s [--jacobians DIR] [--m M --n N --r R] [--seed S]\n", argv[0]); return 2; }
+        else if (!strcmp(argv[i], "--gpus") && i + 1 < argc) gpus = atoi(argv[++i]);
+        else if (!strcmp(argv[i], "--steps") && i + 1 < argc) steps = atoi(argv[++i]);
+        else if (!strcmp(argv[i], "--dtype") && i + 1 < argc) dtype = argv[++i];
+        else { fprintf(stderr, "usage: %s [--jacobians DIR] [--m M --n N --r R] [--seed S] [--dtype fp16|fp32|fp8] [--gpus N [--steps K]]\n", argv[0]); return 2; }
     }
     try {
-        if (m > 0 && n > 0 && r > 0) { test_dev_mixed_precision_block_qr(m, n, r, generate(m, n)); return 0; }
+        if (gpus > 0) {
+            if (!(m > 0 && n > 0 && r > 0)) { fprintf(stderr, "--gpus needs --m --n --r\n"); return 2; }
+            return run_multi_gpu(gpus, m, n, r, g_seed, std::max(1, steps));
+        }
+        if (m > 0 && n > 0 && r > 0) {
+            if (!strcmp(dtype, "fp32")) test_dev_block_qr(m, n, r, generate(m, n));
+            else if (!strcmp(dtype, "fp8")) test_dev_fp8_block_qr(m, n, r, generate(m, n));
+            else test_dev_mixed_precision_block_qr(m, n, r, generate(m, n));
+            return 0;
+        }
         test_qr_by_random_matrix(test_h_householder_qr);
         test_qr_by_random_matrix(test_dev_block_qr);
         test_qr_by_random_matrix(test_dev_mixed_precision_block_qr);

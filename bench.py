@@ -110,7 +110,7 @@ def main():
     prec_name = args.precision or ("fp8" if args.config == "c5" else "fp16")
     if world > 1 or os.environ.get("MPQR_FORCE_DIST") == "1":     # the env switch lets a 1-GPU box exercise the RCCL leg
         from mixedprecisionblockqr_amd import dist as mpdist
-        return mpdist.bench_main(args, m, n, r, world, rank, local_rank)
+        return mpdist.bench_main(args, m, n, r, world, rank, local_rank, cpu_baseline_fn=cpu_baseline)
 
     torch.cuda.set_device(0)
     h = mp.Handle(0)

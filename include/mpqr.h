@@ -230,7 +230,11 @@ int  mpqr_dist_factor_block(mpqr_handle_t h, int s);
 long mpqr_dist_block_bytes(mpqr_handle_t h, int s);
 int  mpqr_dist_pack_block(mpqr_handle_t h, int s, void* device_buf);
 int  mpqr_dist_unpack_block(mpqr_handle_t h, int s, const void* device_buf);
-int  mpqr_dist_update(mpqr_handle_t h, int s);
+int  mpqr_dist_update(mpqr_handle_t h, int s);               /* = mpqr_dist_update_part(h, s, 2) */
+/* look-ahead form: part 0 = the columns of block s+1 only (its owner factors that block next), chain stream;
+ * part 1 = the local columns right of block s+1, far-update stream, runs beside the factorisation of block s+1;
+ * part 2 = everything, chain stream.  Schedule: mixedprecisionblockqr_amd/dist.py:factor, apps/mpqr_main.cpp --gpus N. */
+int  mpqr_dist_update_part(mpqr_handle_t h, int s, int part);
 int  mpqr_dist_form_q(mpqr_handle_t h);
 /* results of this rank: (m+1) x local_cols in the reference's shifted layout; m x local_q_cols; the input */
 int  mpqr_dist_get_local_factor_host(mpqr_handle_t h, float* A_local);

@@ -108,6 +108,7 @@ SIGNATURES = {
     "mpqr_dist_pack_block": (_i, [_H, _i, _p]),
     "mpqr_dist_unpack_block": (_i, [_H, _i, _p]),
     "mpqr_dist_update": (_i, [_H, _i]),
+    "mpqr_dist_update_part": (_i, [_H, _i, _i]),
     "mpqr_dist_form_q": (_i, [_H]),
     "mpqr_dist_get_local_factor_host": (_i, [_H, _p]),
     "mpqr_dist_get_local_q_host": (_i, [_H, _p]),

@@ -66,6 +66,7 @@ struct mpqr_handle_s {
     bool tq_on = false;         // this plan builds its T's on sT (fp16 mode)
     hipStream_t op1_stream = nullptr;   // set by factor_block_flat: X = C2^T V (+ its slab sum) of the next apply runs there
     hipEvent_t ev_x = nullptr;          // ... and this event orders it before the apply's second GEMM
+    hipEvent_t ev_dist_chain = nullptr, ev_dist_far = nullptr;   // distributed look-ahead: chain -> far stream, far -> chain stream
     std::string err;
 
     bool planned = false;
@@ -756,7 +757,9 @@ int mpqr_create(mpqr_handle_t* out, int device) {
         hipStreamCreateWithPriority(&h->sT, hipStreamNonBlocking, prio_hi) != hipSuccess ||
         hipEventCreateWithFlags(&h->ev_v, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&h->ev_x, hipEventDisableTiming) != hipSuccess) {
+        hipEventCreateWithFlags(&h->ev_x, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&h->ev_dist_chain, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&h->ev_dist_far, hipEventDisableTiming) != hipSuccess) {
         g_create_err = "hipSetDevice/hipStreamCreate failed";
         delete h;
         return MPQR_ERR_HIP;
@@ -786,6 +789,8 @@ int mpqr_destroy(mpqr_handle_t h) {
     if (h->ev_v) (void)hipEventDestroy(h->ev_v);
     if (h->ev_join) (void)hipEventDestroy(h->ev_join);
     if (h->ev_x) (void)hipEventDestroy(h->ev_x);
+    if (h->ev_dist_chain) (void)hipEventDestroy(h->ev_dist_chain);
+    if (h->ev_dist_far) (void)hipEventDestroy(h->ev_dist_far);
     (void)hipStreamDestroy(h->s0);
     if (h->s1) (void)hipStreamDestroy(h->s1);
     if (h->sT) (void)hipStreamDestroy(h->sT);
@@ -870,7 +875,7 @@ static int plan_common(mpqr_handle_t h, int m, int n, int r, const mpqr_opts* op
     if ((rc = dalloc(h, &h->Yt, h->yt_elems + (size_t)256 * max_ldt))) return rc;
     HIPCHK(h, hipMemsetAsync(h->Xt, 0, (h->xt_elems + (size_t)256 * max_ldt) * sizeof(float), h->s0));
     HIPCHK(h, hipMemsetAsync(h->Yt, 0, (h->yt_elems + (size_t)256 * max_ldt) * sizeof(half_t), h->s0));
-    if (o.lookahead && world == 1 && o.precision != MPQR_PREC_FP32) {
+    if (o.lookahead && o.precision != MPQR_PREC_FP32) {
         if ((rc = dalloc(h, &h->Xt1, h->xt_elems + (size_t)256 * max_ldt))) return rc;
         if ((rc = dalloc(h, &h->Yt1, h->yt_elems + (size_t)256 * max_ldt))) return rc;
         HIPCHK(h, hipMemsetAsync(h->Xt1, 0, (h->xt_elems + (size_t)256 * max_ldt) * sizeof(float), h->s0));
@@ -1065,7 +1070,7 @@ int mpqr_sync(mpqr_handle_t h) {
 }
 
 int mpqr_get_timings(mpqr_handle_t h, mpqr_timings* t) {
-    int rc = need_plan(h); if (rc) return rc;
+    int rc = need_plan(h, true); if (rc) return rc;
     if (!t) return MPQR_ERR_INVALID;
     if (!h->factored) return fail(h, MPQR_ERR_STATE, "nothing has been factored");
     HIPCHK(h, hipStreamSynchronize(h->s0));
@@ -1608,8 +1613,14 @@ int mpqr_dist_begin(mpqr_handle_t h, float absmax) {
     float sc = 1.f;
     if (absmax > 0.f && std::isfinite(absmax)) { int e; frexpf(absmax * sqrtf((float)h->m), &e); sc = ldexpf(1.f, 8 - e); }
     h->a_scale = sc;
+    h->far_used = 0; h->far_flops.clear(); h->chain_used = 0; h->v8_node = -1; h->n_passes = 1; h->n_robust_leaves = 0;
     HIPCHK(h, hipEventRecord(h->ev[0], h->s0));
     HIPCHK(h, hipMemcpyAsync(h->dA, h->dA0, (size_t)h->m_pad * h->lda * sizeof(float), hipMemcpyDeviceToDevice, h->s0));
+    if (h->Xt1) {                                   // far stream starts behind the copy-in; its "done" event starts signalled
+        HIPCHK(h, hipEventRecord(h->ev_dist_chain, h->s0));
+        HIPCHK(h, hipStreamWaitEvent(h->s1, h->ev_dist_chain, 0));
+        HIPCHK(h, hipEventRecord(h->ev_dist_far, h->s1));
+    }
     if ((rc = clear_leaf_flags(h))) return rc;
     if ((rc = clear_reflectors(h))) return rc;
     h->factored = false; h->q_formed = false;
@@ -1630,6 +1641,8 @@ int mpqr_dist_factor_block(mpqr_handle_t h, int s) {
                                hipMemcpyDeviceToDevice, h->s0));
     h->Aeff = h->dA + (lc0 - nd.c0);
     bool saved_robust = h->robust;
+    const bool timed = h->chain_used + 2 <= h->chain_ev.size();
+    if (timed) HIPCHK(h, hipEventRecord(h->chain_ev[h->chain_used], h->s0));
     for (int attempt = 0; attempt < 2; attempt++) {
         if ((rc = factor_node(h, h->tops[s], true))) { h->robust = saved_robust; h->Aeff = h->dA; return rc; }
         int f = 0;
@@ -1644,6 +1657,7 @@ int mpqr_dist_factor_block(mpqr_handle_t h, int s) {
                                    h->m_pad, h->s0));
         HIPCHK(h, hipMemsetAsync(h->Vt + (size_t)nd.c0 * h->ldvt, 0, (size_t)(nd.c1 - nd.c0) * h->ldvt * sizeof(half_t), h->s0));
     }
+    if (timed) { HIPCHK(h, hipEventRecord(h->chain_ev[h->chain_used + 1], h->s0)); h->chain_used += 2; }
     h->robust = saved_robust;
     h->Aeff = h->dA;
     HIPCHK(h, hipGetLastError());
@@ -1685,24 +1699,52 @@ int mpqr_dist_unpack_block(mpqr_handle_t h, int s, const void* dbuf) {
     HIPCHK(h, hipMemcpyAsync(h->Tth + nd.toff, in + Kr * Wc + Kr * Kr, Kr * Kr * sizeof(half_t), hipMemcpyDeviceToDevice, h->s0));
     // Vh[rlo + c][a0 + k] = Vt[a0 + k][rlo + c]
     launch_transpose_h16(in, Wc, h->Vh + (size_t)rlo * h->ldvh + nd.a0, h->ldvh, (int)Kr, (int)Wc, h->s0);
+    HIPCHK(h, hipStreamSynchronize(h->s0));              // the caller may refill the buffer (double-buffered broadcasts)
     return MPQR_OK;
 }
 
-// apply block s's reflectors to this rank's columns right of it
-int mpqr_dist_update(mpqr_handle_t h, int s) {
+// apply block s's reflectors to this rank's columns right of it.
+//   part 0: only the columns of block s+1 (non-empty on its owner), on the CHAIN stream: the owner then factors block s+1
+//   part 1: the local columns right of block s+1, on the FAR stream: runs beside that factorisation (look-ahead)
+//   part 2: everything on the chain stream (no look-ahead)
+int mpqr_dist_update_part(mpqr_handle_t h, int s, int part) {
     int rc = need_plan(h, true); if (rc) return rc;
-    if (s < 0 || s >= (int)h->tops.size()) return fail(h, MPQR_ERR_INVALID, "bad block index");
+    if (s < 0 || s >= (int)h->tops.size() || part < 0 || part > 2) return fail(h, MPQR_ERR_INVALID, "bad block index / part");
     const Node nd = h->nodes[h->tops[s]];
-    const int lc_next = mpqr_part_local_cols(std::min(h->n, nd.c1), h->Ko, h->world, h->rank);
-    apply_node(h, nd, h->dA, h->lda, lc_next, h->nloc, true, h->a_scale, false);
-    if (s + 1 == (int)h->tops.size()) { HIPCHK(h, hipEventRecord(h->ev[1], h->s0)); h->factored = true; }
+    const bool last = s + 1 == (int)h->tops.size();
+    const int c_next = last ? h->n : h->nodes[h->tops[s + 1]].c1;                         // global end of block s+1
+    const int lc0 = mpqr_part_local_cols(std::min(h->n, nd.c1), h->Ko, h->world, h->rank);      // local columns left of nd.c1
+    const int lc1 = mpqr_part_local_cols(std::min(h->n, c_next), h->Ko, h->world, h->rank);     // ... left of the end of block s+1
+    const bool two_streams = h->Xt1 != nullptr;
+    if (part == 2 || !two_streams) {
+        if (part == 0) { /* covered by part 1 below */ }
+        else {
+            if (two_streams) (void)hipStreamWaitEvent(h->s0, h->ev_dist_far, 0);         // earlier far-stream parts first
+            apply_node(h, nd, h->dA, h->lda, lc0, h->nloc, true, h->a_scale, true, 0, true);
+        }
+    } else if (part == 0) {
+        // block s+1's columns carry every earlier update once the previous far-stream part is done
+        (void)hipStreamWaitEvent(h->s0, h->ev_dist_far, 0);
+        apply_node(h, nd, h->dA, h->lda, lc0, lc1, true, h->a_scale, false, 0, true);
+    } else {
+        (void)hipEventRecord(h->ev_dist_chain, h->s0);                                   // the block's V, T (unpack / factor) are on the chain stream
+        (void)hipStreamWaitEvent(h->s1, h->ev_dist_chain, 0);
+        apply_node(h, nd, h->dA, h->lda, lc1, h->nloc, true, h->a_scale, true, 1, true);
+        (void)hipEventRecord(h->ev_dist_far, h->s1);
+    }
+    if (last && part != 0) {
+        if (two_streams) (void)hipStreamWaitEvent(h->s0, h->ev_dist_far, 0);
+        HIPCHK(h, hipEventRecord(h->ev[1], h->s0)); h->factored = true;
+    }
     HIPCHK(h, hipGetLastError());
     return MPQR_OK;
 }
+int mpqr_dist_update(mpqr_handle_t h, int s) { return mpqr_dist_update_part(h, s, 2); }
 
 int mpqr_dist_form_q(mpqr_handle_t h) {
     int rc = need_plan(h, true); if (rc) return rc;
     if (!h->factored) return fail(h, MPQR_ERR_STATE, "factor first");
+    if (h->Xt1) (void)hipStreamWaitEvent(h->s0, h->ev_dist_far, 0);
     HIPCHK(h, hipMemsetAsync(h->dQ, 0, (size_t)h->m_pad * h->ldq * sizeof(float), h->s0));
     launch_identity_cyclic(h->dQ, h->ldq, h->m, h->qloc, h->Ko, h->world, h->rank, h->s0);
     for (int t = (int)h->tops.size() - 1; t >= 0; t--) {

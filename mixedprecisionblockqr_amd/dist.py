@@ -109,6 +109,9 @@ class GpuEngine:
             self._bufs[nbytes] = self.torch.empty(nbytes, dtype=self.torch.uint8, device=self.device)
         return self._bufs[nbytes]
 
+    def new_buffer(self, nbytes):
+        return self.torch.empty(nbytes, dtype=self.torch.uint8, device=self.device)
+
     def pack(self, s, buf): self._chk(L.lib().mpqr_dist_pack_block(self._h, s, C.c_void_p(buf.data_ptr())))
 
     def unpack(self, s, buf):
@@ -116,6 +119,12 @@ class GpuEngine:
         self._chk(L.lib().mpqr_dist_unpack_block(self._h, s, C.c_void_p(buf.data_ptr())))
 
     def update(self, s): self._chk(L.lib().mpqr_dist_update(self._h, s))
+    def update_part(self, s, part): self._chk(L.lib().mpqr_dist_update_part(self._h, s, part))
+
+    def timings(self):
+        t = L.MpqrTimings()
+        self._chk(L.lib().mpqr_get_timings(self._h, C.byref(t)))
+        return {k: getattr(t, k) for k, _ in L.MpqrTimings._fields_ if k != "reserved"}
     def form_q(self): self._chk(L.lib().mpqr_dist_form_q(self._h))
     def sync(self): self._chk(L.lib().mpqr_sync(self._h))
 
@@ -130,19 +139,51 @@ class GpuEngine:
     def local_input(self): return self._get(L.lib().mpqr_dist_get_local_input_host, self.m, self.local_cols())
 
 
-def factor(engine, comm, form_q=True):
-    """The distributed block loop.  Every rank calls this with its own engine."""
+def factor(engine, comm, form_q=True, lookahead=True):
+    """The distributed block loop.  Every rank calls this with its own engine.
+
+    Look-ahead: after block s has been broadcast, the owner of block s+1 updates THAT block's columns
+    first (update_part(s, 0), chain stream), starts the update of its other columns on the far-update stream
+    (update_part(s, 1)), and factors and packs block s+1 while that update -- and everybody else's -- is still running;
+    the other ranks go straight to the next broadcast and wait there with their GPUs busy.  The packed buffers are
+    double-buffered.  With one rank nothing is packed or broadcast: the schedule degenerates to the single-GPU one."""
     engine.begin(comm.allreduce_max(engine.local_absmax()))
-    for s in range(engine.num_blocks()):
+    nb = engine.num_blocks()
+    multi = comm.world > 1
+    bufs = {}
+
+    def buffer(s):
+        nbytes = engine.block_bytes(s)
+        key = (s % 2, nbytes)
+        if key not in bufs:
+            bufs[key] = engine.new_buffer(nbytes) if hasattr(engine, "new_buffer") else engine.buffer(nbytes)
+        return bufs[key]
+
+    if comm.rank == engine.owner(0):
+        engine.factor_block(0)
+        if multi:
+            engine.pack(0, buffer(0))
+    for s in range(nb):
         owner = engine.owner(s)
-        buf = engine.buffer(engine.block_bytes(s))
-        if comm.rank == owner:
-            engine.factor_block(s)
-            engine.pack(s, buf)
-        comm.broadcast(buf, owner)
-        engine.unpack(s, buf)
-        engine.update(s)
-        engine.sync()              # the buffer is reused by the next block
+        if multi:
+            buf = buffer(s)
+            comm.broadcast(buf, owner)
+            engine.unpack(s, buf)
+        if not lookahead:
+            engine.update_part(s, 2)
+            if s + 1 < nb and comm.rank == engine.owner(s + 1):
+                engine.factor_block(s + 1)
+                if multi:
+                    engine.pack(s + 1, buffer(s + 1))
+            continue
+        if s + 1 < nb and comm.rank == engine.owner(s + 1):
+            engine.update_part(s, 0)           # the next block's columns first ...
+            engine.update_part(s, 1)           # ... the rest is enqueued on the far stream and runs beside ...
+            engine.factor_block(s + 1)         # ... the factorisation of the next block (chain stream)
+            if multi:
+                engine.pack(s + 1, buffer(s + 1))
+        else:
+            engine.update_part(s, 1)
     if form_q:
         engine.form_q()
     engine.sync()
@@ -194,40 +235,56 @@ def residual_check(engine, comm, nvec=4, seed=7, group=None):
     return {"randomized_residual": res, "q_shard_orth_fro": float(torch.sqrt(qe))}
 
 
-def bench_main(args, m, n, r, world, rank, local_rank):
-    """bench.py leg for N > 1 (launched by torch.distributed.run, one rank per GPU, RCCL)."""
+def bench_main(args, m, n, r, world, rank, local_rank, cpu_baseline_fn=None):
+    """bench.py leg for N > 1 (launched by torch.distributed.run, one rank per GPU, RCCL); MPQR_FORCE_DIST=1 runs it at N = 1."""
     import torch
     import torch.distributed as dist
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    dist.init_process_group(backend="nccl", device_id=dev)
-    comm = TorchComm(device=dev)
-    eng = GpuEngine(local_rank, m, n, r, world, rank, outer_block=args.outer_block)
+    own_pg = not dist.is_initialized()
+    if world > 1 and own_pg:
+        dist.init_process_group(backend="nccl", device_id=dev)
+    comm = TorchComm(device=dev) if world > 1 else NullComm()
+    # distribution unit = the far update's aggregation width; with many ranks keep at least two blocks per rank so that
+    # every rank still owns trailing columns late in the factorisation (config 5: 8192 columns on 8 GPUs -> 512)
+    ko = args.outer_block
+    if not ko and world > 1:
+        ko = max(r, min(1024, (n // (2 * world)) // r * r))
+    eng = GpuEngine(local_rank, m, n, r, world, rank, outer_block=ko, lookahead=not args.no_lookahead)
     eng.generate(1234)
     eng.sync()
 
     for _ in range(args.warmup):
-        factor(eng, comm)
+        factor(eng, comm, lookahead=not args.no_lookahead)
     comm.barrier(); torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        factor(eng, comm)
+        factor(eng, comm, lookahead=not args.no_lookahead)
     comm.barrier(); torch.cuda.synchronize()
-    dt = torch.tensor([(time.perf_counter() - t0) / args.steps], dtype=torch.float64, device=dev)
-    dist.all_reduce(dt, op=dist.ReduceOp.MAX)
-    dt = float(dt.item())
+    dt = (time.perf_counter() - t0) / args.steps
+    if world > 1:
+        dtt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(dtt, op=dist.ReduceOp.MAX)
+        dt = float(dtt.item())
 
-    # host-side verification uses gloo-free CPU math + the default (nccl) group needs device tensors:
-    # run the check on a gloo side group so the m-vectors can stay on the host
+    # host-side verification on a gloo side group (the m-vectors stay on the host)
     chk = None
     try:
-        g = dist.new_group(backend="gloo")
+        g = dist.new_group(backend="gloo") if world > 1 else None
         chk = residual_check(eng, comm, group=g)
     except Exception as e:  # verification must never take the benchmark down
         chk = {"error": repr(e)}
     if rank == 0:
         from . import api
         fl = api.flops(m, n, r)
+        tm = eng.timings()              # rank 0's own HIP-event timings of the last step
+        roof = None
+        if tm["n_far_launches"] > 0 and tm["ms_far_nn"] > 0:
+            ach = tm["flops_far_nn"] / (tm["ms_far_nn"] * 1e-3) / 1e12
+            roof = {"bound": "mfma", "kernel": "gemm6_f16_kernel<E_SUB_F32> (far A2 -= V*Y^T on rank 0's column shard, fp16 x fp16 -> fp32, K = outer block)",
+                    "achieved": ach, "peak": 2500.0, "unit": "TFLOP/s", "frac": ach / 2500.0, "traffic": None,
+                    "launches": tm["n_far_launches"], "avg_launch_ms": tm["ms_far_nn"] / tm["n_far_launches"],
+                    "tn_achieved": (tm["flops_far_tn"] / (tm["ms_far_tn"] * 1e-3) / 1e12) if tm["ms_far_tn"] > 0 else None}
         out = {
             "metric": "GFLOP/s block QR (fp16 MFMA trailing)", "value": fl["geqrf"] / dt / 1e9, "unit": "GFLOP/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt * 1e3,
@@ -235,11 +292,18 @@ def bench_main(args, m, n, r, world, rank, local_rank):
             "data": "synthetic U[0,1) fp32, seed 1234",
             "config": {"workload": f"{m}x{n} random dense, block={r}, full Q formed", "m": m, "n": n, "block": r,
                        "outer_block": eng.block(),
-                       "parallelism": f"{world} gpus, 1-D block-cyclic column superblocks, RCCL broadcast of V,T per block"},
+                       "parallelism": f"{world} gpu(s), 1-D block-cyclic column superblocks, look-ahead, RCCL broadcast of V,T per block"},
             "error": chk,
+            "breakdown_ms_rank0": {k: tm[k] for k in ("ms_total", "ms_factor", "ms_form_q", "ms_trailing", "ms_panel", "ms_far_tn", "ms_far_nn")},
             "gflops_with_q_flops": (fl["geqrf"] + fl["form_q"]) / dt / 1e9,
-            "roofline": None, "cpu_baseline": None,
+            "roofline": roof,
         }
+        if cpu_baseline_fn is not None and not args.no_cpu_baseline:
+            out["cpu_baseline"], port = cpu_baseline_fn()
+            if port is not None:
+                out["cpu_baseline_port"] = port
         print(json.dumps(out), flush=True)
-    dist.barrier()
-    dist.destroy_process_group()
+    if world > 1:
+        dist.barrier()
+        if own_pg:
+            dist.destroy_process_group()

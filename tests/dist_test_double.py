@@ -20,6 +20,7 @@ class OracleEngine:
         self.qcols = global_columns(m, self.ko, world, rank)
         self.A0 = np.zeros((m, len(self.cols)), np.float32)
         self.VT = {}
+        self.log = []                      # call sequence, for the look-ahead order test
 
     def block(self): return self.ko
     def num_blocks(self): return (self.n + self.ko - 1) // self.ko
@@ -37,6 +38,7 @@ class OracleEngine:
     def _range(self, s): return s * self.ko, min(self.n, (s + 1) * self.ko)
 
     def factor_block(self, s):
+        self.log.append(("factor_block", s))
         c0, c1 = self._range(s)
         assert self.owner(s) == self.rank
         lc0 = L.lib().mpqr_part_local_index(c0, self.ko, self.world)
@@ -69,21 +71,31 @@ class OracleEngine:
     def buffer(self, nbytes): return torch.empty(nbytes, dtype=torch.uint8)
 
     def pack(self, s, buf):
+        self.log.append(("pack", s))
         V, T = self.VT[s]
         raw = np.concatenate([V.ravel(), T.ravel()]).astype(np.float32).view(np.uint8)
         buf.copy_(torch.from_numpy(raw.copy()))
 
     def unpack(self, s, buf):
+        self.log.append(("unpack", s))
         c0, c1 = self._range(s); w = c1 - c0
         f = buf.numpy().view(np.float32)
         V = f[:(self.m - c0) * w].reshape(self.m - c0, w).copy(); T = f[(self.m - c0) * w:].reshape(w, w).copy()
         self.VT[s] = (V, T)
 
     def update(self, s):
+        self.update_part(s, 2)
+
+    def update_part(self, s, part):
+        """part 0: the columns of block s+1 only; part 1: the local columns right of block s+1; part 2: everything"""
+        self.log.append(("update_part", s, part))
         c0, c1 = self._range(s)
-        lc_next = L.lib().mpqr_part_local_cols(min(self.n, c1), self.ko, self.world, self.rank)
+        c2 = self._range(s + 1)[1] if s + 1 < self.num_blocks() else self.n
+        lc0 = L.lib().mpqr_part_local_cols(min(self.n, c1), self.ko, self.world, self.rank)
+        lc1 = L.lib().mpqr_part_local_cols(min(self.n, c2), self.ko, self.world, self.rank)
+        lo, hi = {0: (lc0, lc1), 1: (lc1, self.A.shape[1]), 2: (lc0, self.A.shape[1])}[part]
         V, T = self.VT[s]
-        blk = self.A[c0:, lc_next:]
+        blk = self.A[c0:, lo:hi]
         if blk.shape[1]:
             blk -= V @ (T.T @ (V.T @ blk))
 

@@ -70,3 +70,33 @@ def test_cpp_entry_point_default_run_list(tmp_path):
     assert sum("householder" in t for t, _, _ in cases) == 20 and sum("mixed" in t for t, _, _ in cases) == 20
     assert len((tmp_path / "log" / "cpu_householder.txt").read_text().strip().splitlines()) == 21
     assert len((tmp_path / "log" / "gpu_block.txt").read_text().strip().splitlines()) == 41
+
+
+@pytest.mark.gpu
+def test_cpp_entry_point_dtype_flag(tmp_path):
+    """--dtype selects the arithmetic of the single-case run: fp32 twin (p = 23 criteria), fp8 far updates (config 5 arithmetic)."""
+    _build()
+    p = subprocess.run([EXE, "--m", "600", "--n", "400", "--r", "16", "--dtype", "fp32"], cwd=tmp_path, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr
+    (title, shape, crit), = _parse(p.stdout)
+    assert "GPU block QR" in title and all(ok for _, ok in crit.values()), crit
+    p = subprocess.run([EXE, "--m", "4096", "--n", "2048", "--r", "256", "--dtype", "fp8"], cwd=tmp_path, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr
+    (title, shape, crit), = _parse(p.stdout)
+    assert "fp8" in title and 2e-3 <= crit["||A - QR||/||A||"][0] <= 6e-2, crit
+
+
+@pytest.mark.gpu
+def test_cpp_multi_gpu_host_driver_on_one_gpu(tmp_path):
+    """apps/mpqr_main --gpus N: the C++ host of the distributed schedule (threads + mpqr_dist_* + ncclBroadcast).  The test box
+    has one GPU: N = 1, once without communication and once with the RCCL broadcast leg forced on (1-rank communicator)."""
+    _build()
+    for env_extra in ({}, {"MPQR_MG_FORCE_BCAST": "1"}):
+        env = dict(os.environ, **env_extra)
+        p = subprocess.run([EXE, "--gpus", "1", "--m", "4096", "--n", "3072", "--r", "128", "--steps", "2"], cwd=tmp_path, env=env,
+                           capture_output=True, text=True, timeout=900)
+        assert p.returncode == 0, (p.stdout, p.stderr)
+        mt = re.search(r"multi-GPU block QR: 1 GPU\(s\), 4096 x 3072, r = 128, outer block (\d+): ([0-9.]+) ms per factorisation incl. Q, ([0-9.]+) GFLOP/s", p.stdout)
+        assert mt, p.stdout
+        assert float(mt.group(2)) > 0 and float(mt.group(3)) > 100.0
+

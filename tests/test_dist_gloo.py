@@ -10,7 +10,7 @@ import torch.multiprocessing as mp
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _worker(rank, world, port, m, n, r, ko, q):
+def _worker(rank, world, port, m, n, r, ko, q, la=True):
     sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
@@ -20,19 +20,20 @@ def _worker(rank, world, port, m, n, r, ko, q):
     eng = OracleEngine(m, n, r, world, rank, outer_block=ko)
     eng.generate(1234)
     comm = mpdist.TorchComm()
-    mpdist.factor(eng, comm)
+    mpdist.factor(eng, comm, lookahead=la)
     chk = mpdist.residual_check(eng, comm)
-    q.put((rank, eng.cols, eng.qcols, eng.local_factor(), eng.local_q(), chk))
+    q.put((rank, eng.cols, eng.qcols, eng.local_factor(), eng.local_q(), chk, eng.log))
     dist.barrier()
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("m,n,r,ko,world", [(96, 80, 16, 32, 2), (130, 100, 8, 32, 2), (64, 64, 16, 32, 3)])
-def test_two_rank_schedule_matches_serial(po, m, n, r, ko, world):
+@pytest.mark.parametrize("m,n,r,ko,world,la", [(96, 80, 16, 32, 2, True), (130, 100, 8, 32, 2, True), (64, 64, 16, 32, 3, True),
+                                                (130, 100, 8, 32, 2, False)])
+def test_two_rank_schedule_matches_serial(po, m, n, r, ko, world, la):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29500 + (os.getpid() % 500) + n
-    procs = [ctx.Process(target=_worker, args=(rk, world, port, m, n, r, ko, q)) for rk in range(world)]
+    port = 29500 + (os.getpid() % 500) + n + (7 if la else 0)
+    procs = [ctx.Process(target=_worker, args=(rk, world, port, m, n, r, ko, q, la)) for rk in range(world)]
     for p in procs: p.start()
     got = [q.get(timeout=180) for _ in range(world)]
     for p in procs: p.join(timeout=60)
@@ -41,10 +42,24 @@ def test_two_rank_schedule_matches_serial(po, m, n, r, ko, world):
     A0, Q0, R0 = po.householder_qr(A)
     F = np.zeros((m + 1, n), np.float32); Q = np.zeros((m, m), np.float32)
     seen_a, seen_q = [], []
-    for rank, cols, qcols, Fl, Ql, chk in got:
+    for rank, cols, qcols, Fl, Ql, chk, log in got:
         F[:, cols] = Fl; Q[:, qcols] = Ql
         seen_a += list(cols); seen_q += list(qcols)
         assert chk["randomized_residual"] < 1e-5 and chk["q_shard_orth_fro"] < 1e-4
+        if la:
+            # look-ahead order on the owner of block s+1: its own block's columns first, the rest of update s
+            # ENQUEUED before the factorisation of block s+1, which is packed before anybody can ask for broadcast s+1
+            nb = (n + ko - 1) // ko
+            for s in range(nb - 1):
+                if (s + 1) % world != rank:
+                    assert ("factor_block", s + 1) not in log
+                    assert ("update_part", s, 0) not in log          # non-owners have nothing of block s+1
+                    continue
+                i0, i1 = log.index(("update_part", s, 0)), log.index(("update_part", s, 1))
+                i2, i3 = log.index(("factor_block", s + 1)), log.index(("pack", s + 1))
+                assert i0 < i1 < i2 < i3, (rank, s, log)
+                if s + 2 < nb:
+                    assert i3 < log.index(("unpack", s + 1))
     assert sorted(seen_a) == list(range(n)) and sorted(seen_q) == list(range(m))
     np.testing.assert_allclose(F, A0, atol=3e-5 * np.sqrt(m))          # R and shifted reflectors, all columns
     np.testing.assert_allclose(Q, Q0, atol=3e-5 * np.sqrt(m))

@@ -583,26 +583,49 @@ def test_config5_full_size_fp8_properties(mp):
 
 
 # ---------------------------------------------------------------- distributed path on the one GPU of the box
-def _run_lockstep(mp, engines):
+def _run_lockstep(mp, engines, lookahead=True):
     """Drive `world` GpuEngines (all on cuda:0) through the distributed schedule in lock step: exactly the calls
-    dist.factor() makes on each rank, with the RCCL broadcast replaced by a device-to-device copy."""
+    dist.factor() makes on each rank (look-ahead order included), with the RCCL broadcast replaced by a device-to-device copy."""
     import torch
     amax = max(e.local_absmax() for e in engines)
     for e in engines: e.begin(amax)
-    for s in range(engines[0].num_blocks()):
+    nb = engines[0].num_blocks()
+    multi = len(engines) > 1
+    bufs = [[e.new_buffer(e.block_bytes(0)) for _ in range(2)] for e in engines]
+
+    def buf(rk, s):
+        need = engines[rk].block_bytes(s)
+        if bufs[rk][s % 2].numel() != need:
+            bufs[rk][s % 2] = engines[rk].new_buffer(need)
+        return bufs[rk][s % 2]
+
+    o0 = engines[0].owner(0)
+    engines[o0].factor_block(0)
+    if multi: engines[o0].pack(0, buf(o0, 0))
+    for s in range(nb):
         owner = engines[0].owner(s)
-        bufs = [e.buffer(e.block_bytes(s)) for e in engines]
-        engines[owner].factor_block(s); engines[owner].pack(s, bufs[owner])
+        if multi:
+            for rk, e in enumerate(engines):
+                if rk != owner: buf(rk, s).copy_(buf(owner, s))
+            torch.cuda.synchronize()
+            for rk, e in enumerate(engines): e.unpack(s, buf(rk, s))
+        nxt = engines[0].owner(s + 1) if s + 1 < nb else -1
         for rk, e in enumerate(engines):
-            if rk != owner: bufs[rk].copy_(bufs[owner])
-        torch.cuda.synchronize()
-        for rk, e in enumerate(engines):
-            e.unpack(s, bufs[rk]); e.update(s); e.sync()
+            if not lookahead:
+                e.update_part(s, 2)
+            elif rk == nxt:
+                e.update_part(s, 0); e.update_part(s, 1)
+            else:
+                e.update_part(s, 1)
+        if nxt >= 0:
+            engines[nxt].factor_block(s + 1)
+            if multi: engines[nxt].pack(s + 1, buf(nxt, s + 1))
     for e in engines: e.form_q(); e.sync()
 
 
-@pytest.mark.parametrize("m,n,r,ko,world", [(300, 200, 16, 64, 2), (1500, 700, 64, 128, 3), (260, 260, 32, 64, 2), (200, 120, 8, 32, 1)])
-def test_distributed_schedule_on_one_gpu(mp, po, m, n, r, ko, world):
+@pytest.mark.parametrize("m,n,r,ko,world,la", [(300, 200, 16, 64, 2, True), (1500, 700, 64, 128, 3, True), (260, 260, 32, 64, 2, True),
+                                                (200, 120, 8, 32, 1, True), (1500, 700, 64, 128, 2, False), (2600, 1536, 128, 512, 2, True)])
+def test_distributed_schedule_on_one_gpu(mp, po, m, n, r, ko, world, la):
     from mixedprecisionblockqr_amd import dist as mpdist
     A = po.generate(m, n, seed=1234)
     engines = [mpdist.GpuEngine(0, m, n, r, world, rk, outer_block=ko) for rk in range(world)]
@@ -611,7 +634,7 @@ def test_distributed_schedule_on_one_gpu(mp, po, m, n, r, ko, world):
         cols = [mpdist.global_columns(n, e.block(), world, e.rank) for e in engines]
         for e, c in zip(engines, cols):
             assert np.array_equal(e.local_input(), A[:, c])           # device generator == oracle generator, sharded
-        _run_lockstep(mp, engines)
+        _run_lockstep(mp, engines, lookahead=la)
         F = np.zeros((m + 1, n), np.float32); Q = np.zeros((m, m), np.float32)
         for e, c in zip(engines, cols):
             F[:, c] = e.local_factor()
