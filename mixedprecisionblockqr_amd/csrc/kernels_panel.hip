@@ -708,6 +708,316 @@ __global__ __launch_bounds__(GH_SOLVE_THREADS) void gh_solve_kernel(LeafArgs a, 
     }
 }
 
+// ------------------------------------------------------------------ gh_solve2: blocked form of gh_solve
+// Same inputs and outputs as gh_solve_kernel (R, V_top, vdiag, the coefficient matrix C of V_low = A_low C, the flag),
+// computed by Householder RECONSTRUCTION instead of a reflector-by-reflector recursion (128 barrier-separated steps of
+// ~2050 cycles each, one LDS round trip per step).  With G = A^T A over the leaf's rows and B0 its top w x w block:
+//   1. G = Cc^T Cc          Cholesky, fp64 (this is where cond(A)^2 lives), blocked by 16
+//   2. Qt = B0 Cc^-1        the top block of the thin orthogonal factor A Cc^-1
+//   3. Qt - S = L U         LU without pivoting, S = diag(s_k), s_k = -sgn(diagonal entry met at step k) (sgn(0) = +1):
+//                           |pivot| >= 1, so this is stable in fp32 (Ballard et al., "Reconstructing Householder vectors
+//                           from TSQR"); the sign rule is the reference's  R_kk = -sgn(u0) ||u||  (qr.cu:229-235)
+//   4. R = S Cc,  v_kk = sgn(U_kk) sqrt(|U_kk| / 2),  V_top = L diag(v_kk),  C = Cc^-1 U^-1 diag(v_kk)
+// In exact arithmetic these are the reference's Householder vectors (unit 2-norm) and its R.  Sequential steps run
+// inside one wave on a 16 x 16 block held in registers (cross-lane moves by v_readlane, no LDS, no barrier); everything
+// else is a small matrix product.  One workgroup of 1024 threads; LDS: the fp64 Gram matrix during step 1, two fp32
+// 128 x 129 matrices afterwards; Cc and Cc^-1 are parked in a global scratch (2 x 64 KiB, L2 resident).
+constexpr int GD = 130;                                   // LDS row stride (doubles) of the Gram matrix
+__device__ __forceinline__ double bcast_lane_d(double v, int srclane) {
+    const long b = __builtin_bit_cast(long, v);
+    const int lo = __builtin_amdgcn_readlane((int)(b & 0xffffffffL), srclane);
+    const int hi = __builtin_amdgcn_readlane((int)(b >> 32), srclane);
+    return __builtin_bit_cast(double, ((long)hi << 32) | ((long)lo & 0xffffffffL));
+}
+__device__ __forceinline__ float bcast_lane_f(float v, int srclane) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), srclane));
+}
+// 32 x 32 tile product as lds_mm32, but k runs over [0, kn) in steps of 2 (kn even, any multiple of 2)
+__device__ __forceinline__ floatx16p lds_mm32_k(const float* A, int lda, const float* B, int ldb, int kn, int lane) {
+    const int r = lane & 31, kk = lane >> 5;
+    floatx16p acc;
+#pragma unroll
+    for (int e = 0; e < 16; e++) acc[e] = 0.f;
+    for (int k1 = 0; k1 < kn; k1 += 2) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(A[r * lda + k1 + kk], B[(k1 + kk) * ldb + r], acc, 0, 0, 0);
+    return acc;
+}
+
+__global__ __launch_bounds__(1024) void gh_solve2_kernel(LeafArgs a, const double* __restrict__ G, float* __restrict__ Cv,
+                                                         int* __restrict__ flag, float* __restrict__ Wk /* 2 x 16384 */) {
+    double* Gd = (double*)gh_smem;                         // [128][GD]   (step 1)
+    float* Ss = (float*)gh_smem;                           // [TP][TPS]   (steps 2-4)
+    float* Ts = Ss + TP * TPS;                             // [TP][TPS]
+    __shared__ double col0[GW];
+    __shared__ double rdiag[16];
+    __shared__ float tdiag[GW], sgn_s[GW], udiag[GW], dv[GW];
+    __shared__ int lflag, cmask[GW];
+    float* const W1 = Wk;                                  // Cc (fp32, upper)
+    float* const W2 = Wk + GW * GW;                        // Cc^-1
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int w = a.c1 - a.c0, off = a.c0 - a.cb;
+    const int nb16 = (w + 15) / 16, nb32 = (w + 31) / 32;
+    KT_DECL; KT();
+
+    // ---- load G (identity outside the leaf: the padding decouples)
+    for (int e = tid; e < GW * GW; e += 1024) {
+        const int i = e >> 7, j = e & 127;
+        double g = (i == j) ? 1.0 : 0.0;
+        if (i < w && j < w) g = G[(off + i) * GW + off + j];
+        Gd[i * GD + j] = g;
+        if (i == j) { col0[i] = g; cmask[i] = 1; }
+    }
+    if (tid == 0) lflag = 0;
+    __syncthreads();
+
+    KT();
+    // ---- 1. Cholesky, right-looking, blocks of 16 (upper triangle of Gd becomes Cc; only upper 16 x 16 tiles are maintained)
+    for (int b = 0; b < nb16; b++) {
+        const int k0 = 16 * b;
+        if (wave == 0) {
+            // diagonal block in registers: lane i < 16 holds row i (mirrored from the upper triangle)
+            const int i = lane & 15;
+            double d[16];
+#pragma unroll
+            for (int j = 0; j < 16; j++) d[j] = (j >= i) ? Gd[(k0 + i) * GD + k0 + j] : Gd[(k0 + j) * GD + k0 + i];
+#pragma unroll
+            for (int kk = 0; kk < 16; kk++) {
+                const double p = bcast_lane_d(d[kk], kk);                  // N[k][k] after the earlier steps
+                const bool ok = p > 1e-30 && p < 1e30;
+                const double pd = ok ? p : 1.0;
+                double y = refine_rsqrt(pd, (double)rsqrtf((float)pd));
+                y = ok ? y : 0.0;
+                if (lane == 0) {
+                    if (!ok || p < GH_RHO_MIN * col0[k0 + kk]) lflag = 1;
+                    cmask[k0 + kk] = ok ? 1 : 0;
+                    rdiag[kk] = y;                                          // 1 / Cc[k][k]
+                }
+                const double mi = d[kk] * y;                               // Cc[k][i] by symmetry (lanes i > kk)
+#pragma unroll
+                for (int j = kk; j < 16; j++) {
+                    const double ckj = bcast_lane_d(d[j], kk) * y;         // Cc[k][j]
+                    if (i == kk) d[j] = ckj;                               // row k is final
+                    else if (i > kk && j > kk) d[j] = fma(-mi, ckj, d[j]);
+                }
+            }
+            if (lane < 16) {
+#pragma unroll
+                for (int j = 0; j < 16; j++) if (j >= i) Gd[(k0 + i) * GD + k0 + j] = d[j];
+            }
+        }
+        __syncthreads();
+        // row panel: Cc[blk][j] = Cdd^-T N[blk][j] for the columns right of the block, one thread per column
+        if (tid < GW && tid >= k0 + 16 && tid < 16 * nb16) {
+            const int j = tid;
+            double x[16];
+#pragma unroll
+            for (int i = 0; i < 16; i++) x[i] = Gd[(k0 + i) * GD + j];
+#pragma unroll
+            for (int i = 0; i < 16; i++) {
+                double sacc = x[i];
+#pragma unroll
+                for (int p = 0; p < i; p++) sacc = fma(-Gd[(k0 + p) * GD + k0 + i], x[p], sacc);
+                x[i] = sacc * rdiag[i];
+            }
+#pragma unroll
+            for (int i = 0; i < 16; i++) Gd[(k0 + i) * GD + j] = x[i];
+        }
+        __syncthreads();
+        // trailing update of the upper 16 x 16 tiles (ti <= tj, both right of the block) on v_mfma_f64_16x16x4_f64
+        {
+            typedef double double4g __attribute__((ext_vector_type(4)));
+            const int nt = nb16 - 1 - b;                                     // tile rows / columns right of the block
+            const int ntile = nt * (nt + 1) / 2;
+            const int li = lane & 15, lk = lane >> 4;
+            for (int t = wave; t < ntile; t += 16) {
+                int ti = 0, rem = t;
+                while (rem >= nt - ti) { rem -= nt - ti; ti++; }
+                const int tj = ti + rem;
+                const int I0 = k0 + 16 * (ti + 1), J0 = k0 + 16 * (tj + 1);
+                double4g acc = {0, 0, 0, 0};
+#pragma unroll
+                for (int q = 0; q < 4; q++)
+                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Gd[(k0 + 4 * q + lk) * GD + I0 + li], Gd[(k0 + 4 * q + lk) * GD + J0 + li], acc, 0, 0, 0);
+#pragma unroll
+                for (int v = 0; v < 4; v++) Gd[(I0 + lk + 4 * v) * GD + J0 + li] -= acc[v];     // D[i][j]: lane j + 16 (i % 4), element i / 4
+            }
+        }
+        __syncthreads();
+    }
+    KT();
+    // ---- park Cc (fp32) in the scratch; build the inverse's inputs
+    for (int e = tid; e < GW * GW; e += 1024) {
+        const int i = e >> 7, j = e & 127;
+        W1[e] = (j >= i) ? (float)Gd[i * GD + j] : 0.f;
+    }
+    __syncthreads();                                         // Gd is dead: its LDS becomes Ss / Ts
+    for (int e = tid; e < GW * GW; e += 1024) {
+        const int i = e >> 7, j = e & 127;
+        const float c = W1[e];
+        if (i == j) tdiag[i] = (cmask[i] && c > 0.f) ? 1.0f / c : 0.f;
+        Ss[i * TPS + j] = (j > i) ? c : 0.f;
+        Ts[i * TPS + j] = 0.f;
+    }
+    __syncthreads();
+    KT();
+    tri_inverse_128(Ss, tdiag, Ts, nb32, tid);                // Ts = Cc^-1 (identity on the padding: tdiag = 1)
+    KT();
+    // ---- 2. Qt = B0 Cc^-1
+    for (int e = tid; e < GW * GW; e += 1024) {
+        const int i = e >> 7, j = e & 127;
+        W2[e] = Ts[i * TPS + j];
+        float bv = (i == j) ? 1.f : 0.f;
+        if (i < w && j < w) bv = a.A[(long)(a.c0 + i) * a.lda + a.c0 + j];
+        Ss[i * TPS + j] = bv;
+    }
+    __syncthreads();
+    {
+        const int bi = wave >> 2, bj = wave & 3;
+        const floatx16p acc = lds_mm32(&Ss[32 * bi * TPS], TPS, &Ts[32 * bj], TPS, 0, 32 * (bj + 1), lane);    // Cc^-1 upper
+        __syncthreads();
+        lds_store32(&Ss[32 * bi * TPS + 32 * bj], TPS, acc, 1.f, lane);
+    }
+    __syncthreads();
+    KT();
+    // ---- 3. LU with the sign choice, blocks of 16, in place in Ss (L strictly below the diagonal, U on and above it)
+    for (int b = 0; b < nb16; b++) {
+        const int k0 = 16 * b;
+        const int wa = k0 >> 6;                                // the wave (of waves 0 / 1: lane = row) that holds the block's rows
+        if (wave == wa) {
+            const int row = 64 * wa + lane;
+            float d[16];
+#pragma unroll
+            for (int j = 0; j < 16; j++) d[j] = Ss[row * TPS + k0 + j];
+            const int lp0 = k0 & 63;
+#pragma unroll
+            for (int kk = 0; kk < 16; kk++) {
+                const int lp = lp0 + kk;                                       // lane of the pivot row (uniform)
+                const float qkk = bcast_lane_f(d[kk], lp);
+                const float sk = (qkk >= 0.f) ? -1.f : 1.f;                    // s_k = -sgn(q_kk), sgn(0) = +1
+                const float piv = qkk - sk;                                    // |piv| >= 1
+                const float rp = 1.0f / piv;
+                if (lane == lp) d[kk] = piv;
+                if (lane == 0) { sgn_s[k0 + kk] = sk; udiag[k0 + kk] = piv; }
+                const float l = d[kk] * rp;
+                if (lane > lp) d[kk] = l;
+#pragma unroll
+                for (int j = kk + 1; j < 16; j++) {
+                    const float ukj = bcast_lane_f(d[j], lp);
+                    if (lane > lp) d[j] = fmaf(-l, ukj, d[j]);
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 16; j++) Ss[row * TPS + k0 + j] = d[j];
+        }
+        __syncthreads();
+        if (wave == 1 && wa == 0) {
+            // the other 64 rows (all below the block): L[i][blk] U_dd = M[i][blk]
+            const int row = 64 + lane;
+            float x[16];
+#pragma unroll
+            for (int j = 0; j < 16; j++) x[j] = Ss[row * TPS + k0 + j];
+#pragma unroll
+            for (int kk = 0; kk < 16; kk++) {
+                const float l = x[kk] / udiag[k0 + kk];
+                x[kk] = l;
+#pragma unroll
+                for (int j = kk + 1; j < 16; j++) x[j] = fmaf(-l, Ss[(k0 + kk) * TPS + k0 + j], x[j]);
+            }
+#pragma unroll
+            for (int j = 0; j < 16; j++) Ss[row * TPS + k0 + j] = x[j];
+        } else if (wave >= 2 && wave < 4) {
+            // U row panel: columns right of the block, one thread per column: U[blk][j] = L_dd^-1 M[blk][j] (unit lower L_dd)
+            const int j = tid - 128;
+            if (j >= k0 + 16 && j < GW) {
+                float y[16];
+#pragma unroll
+                for (int i = 0; i < 16; i++) y[i] = Ss[(k0 + i) * TPS + j];
+#pragma unroll
+                for (int i = 1; i < 16; i++) {
+                    float sacc = y[i];
+#pragma unroll
+                    for (int p = 0; p < i; p++) sacc = fmaf(-Ss[(k0 + i) * TPS + k0 + p], y[p], sacc);
+                    y[i] = sacc;
+                }
+#pragma unroll
+                for (int i = 0; i < 16; i++) Ss[(k0 + i) * TPS + j] = y[i];
+            }
+        }
+        __syncthreads();
+        {   // trailing update M[i][j] -= L[i][blk] U[blk][j] for i, j > k0 + 15, 32 x 32 tiles on the exact-f32 MFMA (K = 16)
+            const int bi = wave >> 2, bj = wave & 3;
+            const int lim = k0 + 15;
+            const bool has = (32 * bi + 31 > lim) && (32 * bj + 31 > lim);
+            floatx16p acc;
+            if (has) acc = lds_mm32_k(&Ss[32 * bi * TPS + k0], TPS, &Ss[k0 * TPS + 32 * bj], TPS, 16, lane);
+            __syncthreads();                                                   // everybody has read the panels
+            if (has) {
+                const int r = lane & 31, kk = lane >> 5;
+                const int j = 32 * bj + r;
+#pragma unroll
+                for (int e = 0; e < 16; e++) {
+                    const int i = 32 * bi + (e & 3) + 8 * (e >> 2) + 4 * kk;
+                    if (i > lim && j > lim) Ss[i * TPS + j] -= acc[e];
+                }
+            }
+        }
+        __syncthreads();
+    }
+    KT();
+    // ---- 4. outputs
+    if (tid < GW) {
+        const float u = udiag[tid];
+        dv[tid] = (tid < 16 * nb16) ? ((u >= 0.f) ? sqrtf(0.5f * u) : -sqrtf(-0.5f * u)) : 1.f;
+        tdiag[tid] = (tid < 16 * nb16) ? 1.0f / u : 1.f;      // for U^-1 (|u| >= 1)
+    }
+    __syncthreads();
+    for (int e = tid; e < GW * GW; e += 1024) {                // k fastest: rows of A and Vh
+        const int i = e >> 7, k = e & 127;
+        if (i < w && k < w) {
+            float v;
+            if (i <= k) v = sgn_s[i] * W1[i * GW + k];                         // R = S Cc
+            else v = Ss[i * TPS + k] * dv[k];                                  // V_top = L diag(v_kk)
+            a.A[(long)(a.c0 + i) * a.lda + a.c0 + k] = v;
+            if (i >= k) a.Vh[(long)(a.c0 + i) * a.ldvh + a.c0 + k] = (half_t)((i == k) ? dv[k] : v);
+        }
+    }
+    for (int e = tid; e < GW * GW; e += 1024) {                // i fastest: rows of V^T
+        const int k = e >> 7, i = e & 127;
+        if (i < w && k < w && i >= k)
+            a.Vt[(long)(a.c0 + k) * a.ldvt + a.c0 + i] = (half_t)((i == k) ? dv[k] : Ss[i * TPS + k] * dv[k]);
+    }
+    if (tid < w) a.vdiag[a.c0 + tid] = dv[tid];
+    if (tid == 0 && lflag) atomicOr(flag, 1);
+    __syncthreads();
+    // U^-1: strictly upper part of U is in place in Ss (tri_inverse_128 never reads the lower triangle), Ts zeroed
+    for (int e = tid; e < TP * TPS; e += 1024) Ts[e] = 0.f;
+    __syncthreads();
+    KT();
+    tri_inverse_128(Ss, tdiag, Ts, nb32, tid);                // Ts = U^-1
+    KT();
+    for (int e = tid; e < GW * GW; e += 1024) Ss[(e >> 7) * TPS + (e & 127)] = W2[e];      // Cc^-1
+    __syncthreads();
+    {   // C = Cc^-1 U^-1 diag(v_kk), upper triangular, window coordinates, flagged reflectors zeroed
+        const int bi = wave >> 2, bj = wave & 3;
+        floatx16p acc;
+#pragma unroll
+        for (int e = 0; e < 16; e++) acc[e] = 0.f;
+        if (bi <= bj) acc = lds_mm32(&Ss[32 * bi * TPS], TPS, &Ts[32 * bj], TPS, 32 * bi, 32 * (bj + 1), lane);
+        const int r = lane & 31, kk = lane >> 5;
+        const int k = 32 * bj + r;
+#pragma unroll
+        for (int e = 0; e < 16; e++) {
+            const int i = 32 * bi + (e & 3) + 8 * (e >> 2) + 4 * kk;
+            const int wi = i + off, wk = k + off;
+            if (wi < GW && wk < GW) Cv[wi * GW + wk] = (i <= k && k < w && cmask[k]) ? acc[e] * dv[k] : 0.f;
+        }
+    }
+    // window entries left of / above the leaf (off > 0) are zero
+    if (off > 0)
+        for (int e = tid; e < GW * GW; e += 1024) { const int wi = e >> 7, wk = e & 127; if (wi < off || wk < off) Cv[e] = 0.f; }
+    KT(); KT_DUMP(2, "gh_solve2 load|chol|park|prep|inv1|qtop|lu|out|inv2|cm");
+}
+
 typedef half_t half8p __attribute__((ext_vector_type(8)));
 // partial Gram of the fp16 reflectors held in Ts ([128 columns][72]: the 64 rows of this workgroup, k contiguous):
 // upper 32 x 32 tiles of Ts Ts^T on v_mfma_f32_32x32x16_f16, written to Sp (fp32, 128 x 128, window coordinates)
@@ -856,13 +1166,19 @@ void launch_leaf_gram_householder(const LeafArgs& a, double* Gp, double* G, floa
     if (!attr) {
         (void)hipFuncSetAttribute((const void*)gh_gram_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, GH_ROWS * GH_TD * 8);
         (void)hipFuncSetAttribute((const void*)gh_solve_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * TP * TPS * 4);
+        (void)hipFuncSetAttribute((const void*)gh_solve2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, GW * GD * 8);
         (void)hipFuncSetAttribute((const void*)gh_apply_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (8256 + GW * GH_TS) * 4);
         attr = true;
     }
     const int nwg = (a.mrows - a.c0 + GH_ROWS - 1) / GH_ROWS;
     hipLaunchKernelGGL(gh_gram_kernel, dim3(2 * nwg), dim3(256), GH_ROWS * GH_TD * 8, s, a, Gp);
     hipLaunchKernelGGL(gh_reduce_kernel, dim3(256), dim3(256), 0, s, Gp, nwg, G);
-    hipLaunchKernelGGL(gh_solve_kernel, dim3(1), dim3(GH_SOLVE_THREADS), 2 * TP * TPS * 4, s, a, G, Cv, flag);
+    // gh_solve2 (blocked Householder reconstruction) is correct but measured SLOWER than the step-by-step kernel at w = 128
+    // (162 vs 111 us: ~500 cycles per column for the fp64 in-wave Cholesky, ~300 for the LU, plus two triangular inverses
+    // -- in-kernel stamps, make EXTRA=-DMPQR_KTRACE): opt-in only
+    static const int solve2 = []() { const char* e = getenv("MPQR_SOLVE2"); return e ? atoi(e) : 0; }();
+    if (solve2 && a.Wk) hipLaunchKernelGGL(gh_solve2_kernel, dim3(1), dim3(1024), GW * GD * 8, s, a, G, Cv, flag, a.Wk);
+    else hipLaunchKernelGGL(gh_solve_kernel, dim3(1), dim3(GH_SOLVE_THREADS), 2 * TP * TPS * 4, s, a, G, Cv, flag);
     const int nlow = (a.mrows - a.c1 + 63) / 64;
     const int ntop = Sp ? (a.c1 - a.c0 + 63) / 64 : 0;      // extra workgroups: Gram contribution of the top block
     if (nlow + ntop == 0) return;

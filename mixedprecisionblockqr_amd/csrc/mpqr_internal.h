@@ -74,6 +74,7 @@ struct LeafArgs {
     float* vdiag;               // diagonal element of each reflector
     float* P;                   // partial dot products, 2 x maxwg x 32
     int maxwg;
+    float* Wk;                  // gh_solve2 scratch, 2 x 16384 floats (nullptr: the step-by-step gh_solve is used)
 };
 void launch_leaf_factor(const LeafArgs& a, hipStream_t s);   // robust path: one workgroup (<=2048 rows) or one launch per column
 // tall leaves (up to 128 columns inside a 128-aligned window, a.cb): Gram-Householder, 4 launches; raises *flag

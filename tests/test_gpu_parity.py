@@ -642,9 +642,13 @@ def test_distributed_schedule_on_one_gpu(mp, po, m, n, r, ko, world, la):
     finally:
         for e in engines: e.close()
     R = np.triu(F[:m])
-    A0, Q0, R0 = po.householder_qr(A)
+    # oracle: the reference's unblocked panel routine; for the large case its compact-WY block loop on all host cores
+    A0, Q0, R0 = po.householder_qr(A) if m * n <= 1000000 else po.block_qr(A, r, "compact32", omp=True)
     mt = po.metrics(A, R, Q)
     assert mt["backward_error_f64"] <= 1e-3 and mt["q_error_fro"] <= 2e-3 * np.sqrt(m), mt
     if m > n:                                                          # well conditioned: factors agree element-wise
-        assert relF(R, R0) <= 3e-3 and relF(Q, Q0) <= 3e-3
-        assert relF(po.extract_V(F, m, n, 0, n), po.extract_V(A0, m, n, 0, n)) <= 3e-3
+        V = po.extract_V(F, m, n, 0, n); V0 = po.extract_V(A0, m, n, 0, n)
+        D, first = align_pivot_signs(V, V0, R, R0, n)                   # sign ambiguity of tiny pivots (checked to BE tiny)
+        Dm = np.ones(m, np.float32); Dm[:n] = D
+        assert relF(R * Dm[:, None], R0) <= 3e-3 and relF(Q[:, :n] * D[None, :], Q0[:, :n]) <= 3e-3
+        assert relF(V[:, :first], V0[:, :first]) <= 3e-3
