@@ -1,7 +1,8 @@
 #!/bin/bash
 # Collects everything profiles/ holds for one round, on the GPU box:  bash tools/collect_profiles.sh <tag>
-# (kernel stats, HBM counters in two separate PMC passes, SQ stall counters, bench lines).  Outputs: gpurun_out/final/
-tag=${1:-r01}
+# (kernel stats, stream gaps, HBM counters in two separate PMC passes, SQ stall counters, L2 hit rates, bench lines).
+# Outputs: gpurun_out/final/ ; copy what is to be judged into profiles/.
+tag=${1:-r02}
 root=${GRAFT_REPO_ROOT:-/root/repo}
 out=$root/gpurun_out/final
 mkdir -p $out
@@ -11,16 +12,21 @@ rocprofv3 --pmc FETCH_SIZE -d $out/fetch -o c4 --output-format csv -- python3 $r
 rocprofv3 --pmc WRITE_SIZE -d $out/write -o c4 --output-format csv -- python3 $root/bench.py --steps 1 --warmup 0 --no-cpu-baseline > $out/write.log 2>&1 && echo "write ok"
 cd $root
 bash tools/pmc_sq.sh c4 > $out/${tag}_c4_sq_stalls.txt 2>&1 && echo "sq ok"
+bash tools/pmc_l2.sh $tag > $out/${tag}_c4_l2_hit.txt 2>&1 && echo "l2 ok"
 cp $(find $out/ks -name "c4_kernel_stats.csv" | head -1) $out/${tag}_c4_kernel_stats.csv
 python3 tools/trace_gaps.py $(find $out/ks -name "c4_kernel_trace.csv" | head -1) > $out/${tag}_c4_stream_gaps.txt
 F=$(find $out/fetch -name "c4_counter_collection.csv" | head -1); W=$(find $out/write -name "c4_counter_collection.csv" | head -1)
-grep -E "Kernel_Name|gemm3_f16|gemm2_f16" $F > $out/${tag}_c4_pmc_FETCH_SIZE_gemm.csv
-grep -E "Kernel_Name|gemm3_f16|gemm2_f16" $W > $out/${tag}_c4_pmc_WRITE_SIZE_gemm.csv
-python3 tools/pmc_traffic.py $F $W "gemm3_f16_kernel<2>" $out/${tag}_traffic_far_nn.json > /dev/null
+grep -E "Kernel_Name|gemm6_f16|gemm2_f16" $F > $out/${tag}_c4_pmc_FETCH_SIZE_gemm.csv
+grep -E "Kernel_Name|gemm6_f16|gemm2_f16" $W > $out/${tag}_c4_pmc_WRITE_SIZE_gemm.csv
+python3 tools/pmc_traffic.py $F $W "gemm6_f16_kernel<2, 1>" $out/${tag}_traffic_far_nn.json > /dev/null
 python3 tools/pmc_traffic.py $F $W "gemm2_f16_kernel<1, 0" $out/${tag}_traffic_far_tn.json > /dev/null
 cp $out/${tag}_traffic_far_nn.json profiles/${tag}_traffic_far_nn.json        # bench.py reads roofline.traffic from here
 python3 bench.py > $out/${tag}_c4_bench.json 2> $out/bench_c4.err && echo "bench c4 ok"
 python3 bench.py --config c2 --no-cpu-baseline > $out/${tag}_c2_bench.json 2> $out/bench_c2.err && echo "bench c2 ok"
-python3 bench.py --config c5 --no-cpu-baseline --steps 3 --warmup 1 > $out/${tag}_c5_bench.json 2> $out/bench_c5.err && echo "bench c5 ok"
+python3 bench.py --config c3 --no-cpu-baseline > $out/${tag}_c3_bench.json 2> $out/bench_c3.err && echo "bench c3 ok"
+python3 bench.py --config c5 --no-cpu-baseline --steps 3 --warmup 1 > $out/${tag}_c5_bench.json 2> $out/bench_c5.err && echo "bench c5 (fp8) ok"
+python3 bench.py --config c5 --precision fp16 --no-cpu-baseline --steps 3 --warmup 1 > $out/${tag}_c5_fp16_bench.json 2> $out/bench_c5b.err && echo "bench c5 (fp16) ok"
+MPQR_FORCE_DIST=1 python3 bench.py --no-cpu-baseline > $out/${tag}_c4_forced_dist_n1_bench.json 2> $out/bench_dist.err && echo "bench forced dist ok"
+python3 tools/precision_study.py $out/${tag}_precision_study.md > /dev/null 2>&1 && echo "precision study ok"
 rm -rf $out/ks $out/fetch $out/write
 ls -la $out

@@ -55,7 +55,7 @@ def main():
     print(text)
     if len(sys.argv) > 1:
         open(sys.argv[1], "w").write(
-            "# Precision study, round 1 (tools/precision_study.py; layout of the reference's error.md)\n\n"
+            "# Precision study (tools/precision_study.py; layout of the reference's error.md)\n\n"
             "Backward error ||A - QR||_F / ||A||_F; SPD test matrices with prescribed condition number, seed 2024, r = min(32, n).\n"
             "The reference's fp16 column is NaN from condition 1e6 on; the mixed path here scales its operands by a power of two\n"
             "and keeps the panel in fp32, so it stays at the fp16 operand accuracy (~1e-3) for every condition number.\n\n" + text + "\n")
