@@ -62,6 +62,8 @@ struct mpqr_handle_s {
     std::vector<hipEvent_t> ev_T;     // per node: T of that node is complete (recorded on sT)
     hipEvent_t ev_v = nullptr, ev_join = nullptr;   // chain -> T stream (reflectors written), T stream -> chain (join)
     hipEvent_t wait_after_first_leaf = nullptr;     // look-ahead: the rest of the block's columns become valid with this event
+    int ext_c1 = 0;                     // flat schedule under look-ahead: in-block updates run on to this column (the NEXT block's first leaf)
+    bool defer_join = false;            // block loop with look-ahead: the chain does not wait for a block's T (its users wait on ev_T)
     std::vector<hipEvent_t> ev_cols2;
     bool tq_on = false;         // this plan builds its T's on sT (fp16 mode)
     hipStream_t op1_stream = nullptr;   // set by factor_block_flat: X = C2^T V (+ its slab sum) of the next apply runs there
@@ -614,11 +616,14 @@ int factor_block_flat(mpqr_handle_t h, int top, const std::vector<int>& leaves) 
             launch_t_leaf(h->Sleaf + (long)sh * 128 + sh, 1, 0, 128, lf.a0, lf.c0, lf.c1, h->Tf + lf.toff, h->Th + lf.toff,
                           h->Tth + lf.toff, lf.ldt, h->s0, ld);
         }
-        // the chain: this leaf alone onto the rest of the block
-        if (lf.c1 < tp.c1) {
+        // the chain: this leaf alone onto the rest of the block -- and, under look-ahead, onto the next block's first
+        // leaf as well (ext_c1): that leaf then needs nothing from this block's far update and the chain crosses the block
+        // boundary without waiting for the block's T and a skinny far update (~350 us per boundary at 16384^2)
+        const int upd_end = std::max(tp.c1, h->ext_c1);
+        if (lf.c1 < upd_end) {
             Range rg("mpqr:in_block_update");
             h->op1_stream = tq ? h->sT : nullptr;
-            apply_node(h, lf, h->Aeff, h->lda, lf.c1, tp.c1, true, h->a_scale, false);
+            apply_node(h, lf, h->Aeff, h->lda, lf.c1, upd_end, true, h->a_scale, false);
             h->op1_stream = nullptr;
         }
         // background, behind this leaf's X GEMM in the side stream's queue: the PREVIOUS leaf's column block of T
@@ -631,8 +636,10 @@ int factor_block_flat(mpqr_handle_t h, int top, const std::vector<int>& leaves) 
         t_column_block(prev, prev_o);
     }
     if (tq) {
-        for (int id : leaves) (void)hipEventRecord(h->ev_T[id], h->sT);
+        // the block's T first: the far update waits for it (every event operation costs its stream ~6 us); the leaves' T's
+        // are diagonal blocks of it
         (void)hipEventRecord(h->ev_T[top], h->sT);
+        if (!h->defer_join) for (int id : leaves) (void)hipEventRecord(h->ev_T[id], h->sT);
     }
     return MPQR_OK;
 }
@@ -649,7 +656,7 @@ int factor_node(mpqr_handle_t h, int id, bool do_panel) {
     std::vector<int> leaves;
     const bool is_top = std::find(h->tops.begin(), h->tops.end(), id) != h->tops.end();
     const int rc = (do_panel && is_top && flat_block_ok(h, id, leaves)) ? factor_block_flat(h, id, leaves) : factor_rec(h, id, do_panel);
-    if (h->tq_on) {
+    if (h->tq_on && !(h->defer_join && !h->force32)) {
         (void)hipEventRecord(h->ev_join, h->sT);
         (void)hipStreamWaitEvent(h->s0, h->ev_join, 0);
     }
@@ -988,17 +995,37 @@ static int run_block_loop(mpqr_handle_t h, std::vector<int>& flags) {
         HIPCHK(h, hipEventRecord(h->ev[3], h->s0));
         HIPCHK(h, hipStreamWaitEvent(h->s1, h->ev[3], 0));
     }
-    for (size_t t = 0; t < h->tops.size(); t++) {
+    // Look-ahead.  Far update t (stream s1) is released in two parts: (a) the columns the chain needs next, (b) the rest,
+    // which overlaps the next block's panels.  With the flat block schedule (ext[t]) block t's own in-block updates also
+    // cover the first leaf of block t+1, so the chain runs across the boundary and (a) = the other columns of block t+1
+    // plus the first leaf of block t+2 (when that block is flat too), waited for after block t+1's first leaf is enqueued.
+    // Tree-scheduled blocks keep the older split: first leaf of block t+1 first (ev_cols, waited for before the block).
+    const size_t nt = h->tops.size();
+    std::vector<char> ext(nt + 1, 0);
+    std::vector<int> cfirst(nt + 2, h->n);                  // end of block t's first leaf
+    {
+        std::vector<int> lv;
+        for (size_t t = 0; t < nt; t++) {
+            int fl = h->tops[t];
+            while (h->nodes[fl].left >= 0) fl = h->nodes[fl].left;
+            cfirst[t] = h->nodes[fl].c1;
+            static const int ext_on = []() { const char* e = getenv("MPQR_EXT_LOOKAHEAD"); return e ? atoi(e) : 1; }();
+            ext[t] = la && ext_on && h->tq_on && t + 1 < nt && flat_block_ok(h, h->tops[t], lv);
+        }
+    }
+    h->defer_join = la && h->tq_on;
+    for (size_t t = 0; t < nt; t++) {
         const Node nd = h->nodes[h->tops[t]];
         if (la && t > 0) {
-            // the first leaf's columns carry all earlier updates; the rest of the block follows with ev_cols2 (waited
-            // for right after the first leaf's kernels are enqueued, factor_rec)
-            HIPCHK(h, hipStreamWaitEvent(h->s0, h->ev_cols[t], 0));
+            if (!ext[t - 1]) HIPCHK(h, hipStreamWaitEvent(h->s0, h->ev_cols[t], 0));
             h->wait_after_first_leaf = h->ev_cols2[t];
         }
+        h->ext_c1 = ext[t] ? cfirst[t + 1] : 0;
         const bool timed = h->chain_used + 2 <= h->chain_ev.size();
         if (timed) HIPCHK(h, hipEventRecord(h->chain_ev[h->chain_used], h->s0));
-        if ((rc = factor_node(h, h->tops[t], true))) return rc;
+        rc = factor_node(h, h->tops[t], true);
+        h->ext_c1 = 0;
+        if (rc) { h->defer_join = false; return rc; }
         if (h->wait_after_first_leaf) {       // (no leaf launched: cannot happen, but never leave the wait pending)
             HIPCHK(h, hipStreamWaitEvent(h->s0, h->wait_after_first_leaf, 0));
             h->wait_after_first_leaf = nullptr;
@@ -1011,17 +1038,23 @@ static int run_block_loop(mpqr_handle_t h, std::vector<int>& flags) {
         }
         HIPCHK(h, hipEventRecord(h->ev_node[t], h->s0));
         HIPCHK(h, hipStreamWaitEvent(h->s1, h->ev_node[t], 0));
-        if (t + 1 < h->tops.size()) {
+        if (t + 1 < nt) {
             const Node nx = h->nodes[h->tops[t + 1]];
-            int fl = h->tops[t + 1];
-            while (h->nodes[fl].left >= 0) fl = h->nodes[fl].left;
-            const int c_first = h->nodes[fl].c1;                                           // end of the next block's first leaf
-            apply_node(h, nd, h->dA, h->lda, nx.c0, c_first, true, h->a_scale, false, 1, true);  // next block's first leaf first ...
-            HIPCHK(h, hipEventRecord(h->ev_cols[t + 1], h->s1));
-            apply_node(h, nd, h->dA, h->lda, c_first, nx.c1, true, h->a_scale, true, 1, true);   // ... then the rest of that block ...
+            const int cf1 = cfirst[t + 1];
+            const int a_end = ext[t + 1] ? cfirst[t + 2] : nx.c1;
+            if (!ext[t]) {
+                apply_node(h, nd, h->dA, h->lda, nx.c0, cf1, true, h->a_scale, false, 1, true);   // next block's first leaf first ...
+                HIPCHK(h, hipEventRecord(h->ev_cols[t + 1], h->s1));
+            }
+            apply_node(h, nd, h->dA, h->lda, cf1, a_end, true, h->a_scale, true, 1, true);        // ... then what its first apply touches ...
             HIPCHK(h, hipEventRecord(h->ev_cols2[t + 1], h->s1));
-            apply_node(h, nd, h->dA, h->lda, nx.c1, h->n, true, h->a_scale, true, 1, true);      // ... the rest overlaps its panels
+            apply_node(h, nd, h->dA, h->lda, a_end, h->n, true, h->a_scale, true, 1, true);       // ... the rest overlaps its panels
         }
+    }
+    if (h->defer_join) {                                    // the T stream's work of every block, once
+        h->defer_join = false;
+        HIPCHK(h, hipEventRecord(h->ev_join, h->sT));
+        HIPCHK(h, hipStreamWaitEvent(h->s0, h->ev_join, 0));
     }
     if (la) {   // join: everything after this point (Q formation, read-backs) is ordered after both streams
         HIPCHK(h, hipEventRecord(h->ev[3], h->s1));
