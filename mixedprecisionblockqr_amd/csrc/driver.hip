@@ -66,6 +66,20 @@ struct mpqr_handle_s {
     bool defer_join = false;            // block loop with look-ahead: the chain does not wait for a block's T (its users wait on ev_T)
     std::vector<hipEvent_t> ev_cols2;
     bool tq_on = false;         // this plan builds its T's on sT (fp16 mode)
+    // Gram-level look-ahead of the panel chain (factor_block_la): the chain stream runs solve -> glue -> solve ..., every
+    // pass over the tall data (apply, in-block updates, the pair Gram of the next two leaves) runs on sA
+    hipStream_t sA = nullptr;
+    hipEvent_t ev_glue = nullptr, ev_pg = nullptr, ev_cold = nullptr;   // chain -> sA (C, Y ready), sA -> chain (pair Gram ready), sA -> chain (join)
+    bool la_on = false;          // set by the block loop while look-ahead blocks may be used
+    bool la_warm = false;        // the next leaf's N (GsN) and top block are predicted already
+    bool la_pg_issued = false;   // ... and the pair Gram its glue needs is enqueued on sA
+    bool la_dirty = false;       // sA holds work the chain stream has not been ordered after
+    bool la_next_robust = false; // the next block's first leaf takes the robust path (no look-ahead into it)
+    int la_idx = 0;              // leaf counter: parity selects the ping-pong buffers
+    hipStream_t node_done_stream = nullptr;   // stream on which the last factor_node left the block's reflectors complete
+    hipStream_t inblock_stream = nullptr;     // apply_node, lane 0: run on this stream instead of s0
+    double* GsN[2] = {nullptr, nullptr}; double* Gp2 = nullptr; double* G2 = nullptr;
+    float* Bsv[2] = {nullptr, nullptr}; float* Cv2[2] = {nullptr, nullptr}; float* Yg = nullptr;
     hipStream_t op1_stream = nullptr;   // set by factor_block_flat: X = C2^T V (+ its slab sum) of the next apply runs there
     hipEvent_t ev_x = nullptr;          // ... and this event orders it before the apply's second GEMM
     hipEvent_t ev_dist_chain = nullptr, ev_dist_far = nullptr;   // distributed look-ahead: chain -> far stream, far -> chain stream
@@ -170,8 +184,10 @@ int dalloc(mpqr_handle_t h, T** p, size_t elems) {
 void free_plan(mpqr_handle_t h) {
     void* ptrs[] = {h->dA, h->dA0, h->dQ, h->Vh, h->Vt, h->vdiag, h->Xt, h->Yt, h->S, h->P, h->tmp1, h->tmp2,
                     h->Tf, h->Th, h->Tth, h->dstage, h->Gp, h->Gs, h->Cv, h->dflag, h->Vf, h->Yf, h->Xt1, h->Yt1, h->Sp,
-                    h->rbTf, h->rbTh, h->rbTth, h->Sleaf, h->Wk, h->V8n, h->V8t, h->A8t, h->Y8};
+                    h->rbTf, h->rbTh, h->rbTth, h->Sleaf, h->Wk, h->V8n, h->V8t, h->A8t, h->Y8,
+                    h->GsN[0], h->GsN[1], h->Gp2, h->G2, h->Bsv[0], h->Bsv[1], h->Cv2[1], h->Yg};
     for (void* p : ptrs) if (p) (void)hipFree(p);
+    h->GsN[0] = h->GsN[1] = nullptr; h->Gp2 = h->G2 = nullptr; h->Bsv[0] = h->Bsv[1] = nullptr; h->Cv2[0] = h->Cv2[1] = nullptr; h->Yg = nullptr;
     h->dA = h->dA0 = h->dQ = nullptr; h->Vh = h->Vt = nullptr; h->vdiag = nullptr; h->Xt = nullptr; h->Yt = nullptr;
     h->S = nullptr; h->P = nullptr; h->tmp1 = h->tmp2 = nullptr; h->Tf = nullptr; h->Th = h->Tth = nullptr;
     h->dstage = nullptr; h->stage_elems = 0;
@@ -296,7 +312,7 @@ int gram(mpqr_handle_t h, const Node& L, const Node& R, int* nslab, long* slab, 
 void apply_node(mpqr_handle_t h, const Node& nd, float* C, long ldc, int clo, int chi, bool trans_t, float in_scale,
                 bool record, int lane = 0, bool far = false) {
     if (chi <= clo) return;
-    hipStream_t st = lane ? h->s1 : h->s0;                 // lane 1: far-update stream with its own scratch
+    hipStream_t st = lane ? h->s1 : (h->inblock_stream ? h->inblock_stream : h->s0);   // lane 1: far-update stream with its own scratch
     float* const Xt = lane ? h->Xt1 : h->Xt;
     half_t* const Yt = lane ? h->Yt1 : h->Yt;
     const int rlo = rdown(nd.c0, 64);
@@ -644,6 +660,141 @@ int factor_block_flat(mpqr_handle_t h, int top, const std::vector<int>& leaves) 
     return MPQR_OK;
 }
 
+// ---- flat block schedule with the Gram-level look-ahead (kernels_panel.hip, "Gram-level look-ahead")
+// Chain stream s0:  [gram + save top, cold start only] solve_j -> glue_j -> solve_{j+1} -> ...
+// Tall stream  sA:  apply_j (+ fp32 update of leaf j+1's tall rows) -> T_j -> fp16 update of the block's columns beyond leaf
+//                   j+1 -> pair Gram for glue_{j+1}
+// T stream     sT:  column block j of the block's T (as in factor_block_flat)
+// glue_j waits for the pair Gram (ev_pg), apply_j for glue_j (ev_glue).  A leaf on the robust path, a leaf without a
+// following full leaf, or the first leaf ever is a cold start: the chain joins sA and takes its Gram matrix from the data.
+int factor_block_la(mpqr_handle_t h, int top, const std::vector<int>& leaves) {
+    const Node tp = h->nodes[top];
+    const int ld = tp.ldt;
+    const int nl = (int)leaves.size();
+    hipStream_t s0 = h->s0, sA = h->sA, sT = h->sT;
+    int rc;
+    const int upd_end = std::max(tp.c1, h->ext_c1);
+    auto is_robust = [&](int jj) { return h->robust || (leaves[jj] < (int)h->leaf_robust.size() && h->leaf_robust[leaves[jj]]); };
+    // leaf jj hands predicted inputs to the leaf after it?
+    auto can_la = [&](int jj) {
+        if (is_robust(jj)) return false;
+        const Node& lf = h->nodes[leaves[jj]];
+        if (jj + 1 < nl) return !is_robust(jj + 1);
+        return h->ext_c1 == lf.c1 + 128 && !h->la_next_robust && lf.c1 + 128 <= h->n;
+    };
+    auto tall_waits_far = [&]() {                            // the block's other columns become valid with this event
+        if (h->wait_after_first_leaf) { (void)hipStreamWaitEvent(sA, h->wait_after_first_leaf, 0); h->wait_after_first_leaf = nullptr; }
+    };
+    auto t_column_block = [&](const Node& lf, int o) {
+        if (o <= 0) return;
+        Range rg("mpqr:wy_T_merge");
+        Node P = tp; P.c1 = lf.c0; P.a1 = lf.c0; P.ldt = o;
+        int nslab; long slab;
+        gram(h, P, lf, &nslab, &slab, sT);
+        SgemmArgs s1{};
+        s1.A = h->S; s1.lda = lf.ldt; s1.transA = 0; s1.nslab_a = nslab; s1.slab_a = slab;
+        s1.B = h->Tf + lf.toff; s1.ldb = ld; s1.transB = 0;
+        s1.C = h->tmp1; s1.ldc = lf.ldt; s1.M = o; s1.N = lf.ldt; s1.K = lf.ldt; s1.alpha = 1.f; s1.beta = 0.f; s1.upperB = 1;
+        launch_sgemm(s1, sT);
+        SgemmArgs s2{};
+        s2.A = h->Tf + tp.toff; s2.lda = ld; s2.transA = 0; s2.nslab_a = 1;
+        s2.B = h->tmp1; s2.ldb = lf.ldt; s2.transB = 0;
+        s2.C = h->Tf + tp.toff + o; s2.ldc = ld; s2.M = o; s2.N = lf.ldt; s2.K = o; s2.alpha = -1.f; s2.beta = 0.f; s2.upperA = 1;
+        launch_sgemm(s2, sT);
+        launch_t_colblock_h16(h->Tf + tp.toff, h->Th + tp.toff, h->Tth + tp.toff, ld, o, o, lf.ldt, sT);
+    };
+    for (int j = 0; j < nl; j++) {
+        const int id = leaves[j];
+        Node lf = h->nodes[id];
+        const int o = lf.c0 - tp.c0;
+        lf.toff = tp.toff + (size_t)o * (ld + 1);
+        lf.tld = ld;
+        lf.id = -1;                                          // no per-leaf T event in this schedule
+        const int par = h->la_idx & 1;
+        const bool la = can_la(j);
+        bool warm_next = false;
+        if (is_robust(j)) {
+            // column-by-column kernels on the chain stream, after everything the tall stream still holds
+            if (h->la_dirty) { (void)hipEventRecord(h->ev_cold, sA); (void)hipStreamWaitEvent(s0, h->ev_cold, 0); h->la_dirty = false; }
+            if (h->wait_after_first_leaf) { (void)hipStreamWaitEvent(s0, h->wait_after_first_leaf, 0); h->wait_after_first_leaf = nullptr; }
+            const size_t keep = h->nodes[id].toff;
+            if ((rc = robust_tall_leaf(h, h->nodes[id], true))) return rc;
+            (void)hipMemcpy2DAsync(h->Tf + lf.toff, (size_t)ld * 4, h->Tf + keep, (size_t)lf.ldt * 4, (size_t)lf.ldt * 4, lf.ldt, hipMemcpyDeviceToDevice, s0);
+            (void)hipMemcpy2DAsync(h->Th + lf.toff, (size_t)ld * 2, h->Th + keep, (size_t)lf.ldt * 2, (size_t)lf.ldt * 2, lf.ldt, hipMemcpyDeviceToDevice, s0);
+            (void)hipMemcpy2DAsync(h->Tth + lf.toff, (size_t)ld * 2, h->Tth + keep, (size_t)lf.ldt * 2, (size_t)lf.ldt * 2, lf.ldt, hipMemcpyDeviceToDevice, s0);
+            (void)hipEventRecord(h->ev_glue, s0);
+            (void)hipStreamWaitEvent(sA, h->ev_glue, 0);
+            h->la_warm = false; h->la_pg_issued = false;
+        } else {
+            Range rg("mpqr:panel");
+            LeafArgs a{};
+            a.A = h->Aeff; a.lda = h->lda; a.mrows = h->m; a.cb = rdown(lf.c0, 128); a.c0 = lf.c0; a.c1 = lf.c1;
+            a.Vh = h->Vh; a.ldvh = h->ldvh; a.Vt = h->Vt; a.ldvt = h->ldvt; a.vdiag = h->vdiag;
+            a.P = h->P; a.maxwg = h->maxwg; a.Wk = h->Wk;
+            if (!h->la_warm) {
+                // cold start: the Gram matrix comes from the data, i.e. after every update the tall stream still holds
+                if (h->la_dirty) { (void)hipEventRecord(h->ev_cold, sA); (void)hipStreamWaitEvent(s0, h->ev_cold, 0); h->la_dirty = false; }
+                launch_gh_gram(a, h->Gp, h->GsN[par], s0);
+                if (la) launch_gh_save_top(h->Aeff, h->lda, lf.c0, h->Bsv[par], s0);
+                h->la_pg_issued = false;
+            }
+            launch_gh_solve(a, h->GsN[par], h->Cv2[par], h->dflag + (id < h->nflag ? id : 0), s0);
+            if (la) {
+                if (!h->la_pg_issued) {                      // the pair Gram of (this leaf, next leaf): data without this leaf's update
+                    tall_waits_far();
+                    launch_gh_pair_gram(h->Aeff, h->lda, h->m, lf.c1, lf.c0, h->Gp2, h->maxwg, h->G2, sA);
+                    (void)hipEventRecord(h->ev_pg, sA);
+                    h->la_dirty = true;
+                }
+                (void)hipStreamWaitEvent(s0, h->ev_pg, 0);
+                GlueArgs g{};
+                g.A = h->Aeff; g.lda = h->lda; g.c0 = lf.c0; g.vdiag = h->vdiag; g.Cv = h->Cv2[par];
+                g.N = h->GsN[par]; g.Glx = h->G2; g.Gld = h->G2 + 16384; g.Bs = h->Bsv[par];
+                g.Bn = h->Bsv[par ^ 1]; g.Nn = h->GsN[par ^ 1]; g.Yg = h->Yg;
+                launch_gh_glue(g, s0);
+                warm_next = true;
+            }
+            (void)hipEventRecord(h->ev_glue, s0);             // C_j (and Y_j) are ready
+            (void)hipStreamWaitEvent(sA, h->ev_glue, 0);
+            tall_waits_far();
+            launch_gh_apply(a, h->Cv2[par], h->Sp, la ? h->Yg : nullptr, sA);
+            Range rt("mpqr:wy_T");
+            launch_gh_reduce_f32(h->Sp, gh_num_partials(a), h->Sleaf, sA);
+            const int sh = lf.a0 - a.cb;
+            launch_t_leaf(h->Sleaf + (long)sh * 128 + sh, 1, 0, 128, lf.a0, lf.c0, lf.c1, h->Tf + lf.toff, h->Th + lf.toff,
+                          h->Tth + lf.toff, lf.ldt, sA, ld);
+            h->la_warm = warm_next;
+        }
+        h->la_dirty = true;
+        // this leaf's reflectors and T are complete on sA from here on: its column block of the block's T on the T stream
+        (void)hipEventRecord(h->ev_v, sA);
+        (void)hipStreamWaitEvent(sT, h->ev_v, 0);
+        t_column_block(lf, o);
+        // the block's remaining columns (beyond the next leaf when that one got the fp32 update): fp16 path on the tall stream
+        const int u0 = warm_next ? lf.c1 + 128 : lf.c1;
+        if (u0 < upd_end) {
+            Range rg("mpqr:in_block_update");
+            tall_waits_far();
+            h->inblock_stream = sA;
+            apply_node(h, lf, h->Aeff, h->lda, u0, upd_end, true, h->a_scale, false);
+            h->inblock_stream = nullptr;
+        }
+        // the pair Gram for the NEXT leaf's glue, if that leaf is in this block (across a block boundary it is issued by the
+        // next block, behind the far update its columns are waiting for)
+        h->la_pg_issued = false;
+        if (warm_next && j + 1 < nl && can_la(j + 1)) {
+            const Node& nx = h->nodes[leaves[j + 1]];
+            launch_gh_pair_gram(h->Aeff, h->lda, h->m, nx.c1, nx.c0, h->Gp2, h->maxwg, h->G2, sA);
+            (void)hipEventRecord(h->ev_pg, sA);
+            h->la_pg_issued = true;
+        }
+        h->la_idx++;
+    }
+    (void)hipEventRecord(h->ev_T[top], sT);
+    h->node_done_stream = sA;
+    return MPQR_OK;
+}
+
 // factor the sub-tree `id`; on return every T below it is ordered before whatever is enqueued on the chain stream next
 int factor_node(mpqr_handle_t h, int id, bool do_panel) {
     if (h->tq_on) {
@@ -655,7 +806,13 @@ int factor_node(mpqr_handle_t h, int id, bool do_panel) {
     }
     std::vector<int> leaves;
     const bool is_top = std::find(h->tops.begin(), h->tops.end(), id) != h->tops.end();
-    const int rc = (do_panel && is_top && flat_block_ok(h, id, leaves)) ? factor_block_flat(h, id, leaves) : factor_rec(h, id, do_panel);
+    h->node_done_stream = h->s0;
+    const bool flat = do_panel && is_top && flat_block_ok(h, id, leaves);
+    if (!(flat && h->la_on) && h->la_dirty) {            // leaving the look-ahead schedule: the chain stream takes over
+        (void)hipEventRecord(h->ev_cold, h->sA); (void)hipStreamWaitEvent(h->s0, h->ev_cold, 0);
+        h->la_dirty = false; h->la_warm = false; h->la_pg_issued = false;
+    }
+    const int rc = flat ? (h->la_on ? factor_block_la(h, id, leaves) : factor_block_flat(h, id, leaves)) : factor_rec(h, id, do_panel);
     if (h->tq_on && !(h->defer_join && !h->force32)) {
         (void)hipEventRecord(h->ev_join, h->sT);
         (void)hipStreamWaitEvent(h->s0, h->ev_join, 0);
@@ -763,9 +920,13 @@ int mpqr_create(mpqr_handle_t* out, int device) {
         hipStreamCreateWithPriority(&h->s0, hipStreamNonBlocking, prio_hi) != hipSuccess ||
         create_update_stream(&h->s1, prio_lo) != hipSuccess ||
         hipStreamCreateWithPriority(&h->sT, hipStreamNonBlocking, prio_hi) != hipSuccess ||
+        hipStreamCreateWithPriority(&h->sA, hipStreamNonBlocking, prio_hi) != hipSuccess ||
         hipEventCreateWithFlags(&h->ev_v, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&h->ev_x, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&h->ev_glue, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&h->ev_pg, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&h->ev_cold, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&h->ev_dist_chain, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&h->ev_dist_far, hipEventDisableTiming) != hipSuccess) {
         g_create_err = "hipSetDevice/hipStreamCreate failed";
@@ -789,6 +950,7 @@ int mpqr_destroy(mpqr_handle_t h) {
     (void)hipStreamSynchronize(h->s0);
     if (h->s1) (void)hipStreamSynchronize(h->s1);
     if (h->sT) (void)hipStreamSynchronize(h->sT);
+    if (h->sA) (void)hipStreamSynchronize(h->sA);
     free_plan(h);
     if (h->dmetric) (void)hipFree(h->dmetric);
     if (h->dscalar) (void)hipFree(h->dscalar);
@@ -797,11 +959,15 @@ int mpqr_destroy(mpqr_handle_t h) {
     if (h->ev_v) (void)hipEventDestroy(h->ev_v);
     if (h->ev_join) (void)hipEventDestroy(h->ev_join);
     if (h->ev_x) (void)hipEventDestroy(h->ev_x);
+    if (h->ev_glue) (void)hipEventDestroy(h->ev_glue);
+    if (h->ev_pg) (void)hipEventDestroy(h->ev_pg);
+    if (h->ev_cold) (void)hipEventDestroy(h->ev_cold);
     if (h->ev_dist_chain) (void)hipEventDestroy(h->ev_dist_chain);
     if (h->ev_dist_far) (void)hipEventDestroy(h->ev_dist_far);
     (void)hipStreamDestroy(h->s0);
     if (h->s1) (void)hipStreamDestroy(h->s1);
     if (h->sT) (void)hipStreamDestroy(h->sT);
+    if (h->sA) (void)hipStreamDestroy(h->sA);
     delete h;
     return MPQR_OK;
 }
@@ -906,6 +1072,12 @@ static int plan_common(mpqr_handle_t h, int m, int n, int r, const mpqr_opts* op
     if ((rc = dalloc(h, &h->Gs, (size_t)16384))) return rc;
     if ((rc = dalloc(h, &h->Sp, (size_t)(h->m_pad / 64 + 4) * 16384))) return rc;
     if ((rc = dalloc(h, &h->Cv, (size_t)16384))) return rc;
+    // Gram-level look-ahead (factor_block_la): ping-pong Gram / top-block / coefficient buffers, pair-Gram partials
+    h->Cv2[0] = h->Cv;
+    if ((rc = dalloc(h, &h->Cv2[1], (size_t)16384)) || (rc = dalloc(h, &h->Yg, (size_t)16384)) ||
+        (rc = dalloc(h, &h->GsN[0], (size_t)16384)) || (rc = dalloc(h, &h->GsN[1], (size_t)16384)) ||
+        (rc = dalloc(h, &h->Bsv[0], (size_t)16384)) || (rc = dalloc(h, &h->Bsv[1], (size_t)16384)) ||
+        (rc = dalloc(h, &h->G2, (size_t)2 * 16384)) || (rc = dalloc(h, &h->Gp2, (size_t)64 * 2 * 16384))) return rc;
     h->nflag = (int)h->nodes.size() + 1024;               // one flag per tree node (+ room for the stage calls' private trees)
     if ((rc = dalloc(h, &h->dflag, (size_t)h->nflag))) return rc;
     h->leaf_robust.assign(h->nodes.size(), 0);
@@ -1013,7 +1185,18 @@ static int run_block_loop(mpqr_handle_t h, std::vector<int>& flags) {
             ext[t] = la && ext_on && h->tq_on && t + 1 < nt && flat_block_ok(h, h->tops[t], lv);
         }
     }
+    std::vector<int> lvtmp;
     h->defer_join = la && h->tq_on;
+    {   // Gram-level look-ahead inside flat blocks: OPT-IN (MPQR_LA=1).  Parity-green and slightly more accurate (the next
+        // leaf's columns get an fp32 update), but measured slower at 16384^2: the pair Gram for glue_{j+1} needs leaf j's
+        // update in the data, so glue_j -> apply_j -> update -> pair Gram -> glue_{j+1} is a serial cycle (~195 us of small
+        // tall kernels + the glue) that only the solve overlaps; per leaf 377 us with the exact-f32 glue (154 us), ~265 us
+        // projected with split-fp16 products, against 224 us for the flat schedule.  Kept as a tested experiment.
+        static const int la_env = []() { const char* e = getenv("MPQR_LA"); return e ? atoi(e) : 0; }();
+        h->la_on = la && h->tq_on && h->sA && la_env && !h->robust;
+        h->la_warm = false; h->la_pg_issued = false; h->la_dirty = false; h->la_idx = 0;
+        if (h->la_on) HIPCHK(h, hipStreamWaitEvent(h->sA, h->ev[3], 0));     // sA sees the copy-in / clears as s1 does
+    }
     for (size_t t = 0; t < nt; t++) {
         const Node nd = h->nodes[h->tops[t]];
         if (la && t > 0) {
@@ -1021,11 +1204,19 @@ static int run_block_loop(mpqr_handle_t h, std::vector<int>& flags) {
             h->wait_after_first_leaf = h->ev_cols2[t];
         }
         h->ext_c1 = ext[t] ? cfirst[t + 1] : 0;
+        h->la_next_robust = false;
+        if (t + 1 < nt) {
+            int fl = h->tops[t + 1];
+            while (h->nodes[fl].left >= 0) fl = h->nodes[fl].left;
+            // (a glue + fp32 update into a leaf that then starts cold is still a complete, exact update: only wasted work)
+            h->la_next_robust = h->robust || (fl < (int)h->leaf_robust.size() && h->leaf_robust[fl]) ||
+                                !flat_block_ok(h, h->tops[t + 1], lvtmp);
+        }
         const bool timed = h->chain_used + 2 <= h->chain_ev.size();
         if (timed) HIPCHK(h, hipEventRecord(h->chain_ev[h->chain_used], h->s0));
         rc = factor_node(h, h->tops[t], true);
         h->ext_c1 = 0;
-        if (rc) { h->defer_join = false; return rc; }
+        if (rc) { h->defer_join = false; h->la_on = false; return rc; }
         if (h->wait_after_first_leaf) {       // (no leaf launched: cannot happen, but never leave the wait pending)
             HIPCHK(h, hipStreamWaitEvent(h->s0, h->wait_after_first_leaf, 0));
             h->wait_after_first_leaf = nullptr;
@@ -1036,7 +1227,7 @@ static int run_block_loop(mpqr_handle_t h, std::vector<int>& flags) {
             apply_node(h, nd, h->dA, h->lda, nd.c1, h->n, true, h->a_scale, true, 0, true);
             continue;
         }
-        HIPCHK(h, hipEventRecord(h->ev_node[t], h->s0));
+        HIPCHK(h, hipEventRecord(h->ev_node[t], h->node_done_stream ? h->node_done_stream : h->s0));
         HIPCHK(h, hipStreamWaitEvent(h->s1, h->ev_node[t], 0));
         if (t + 1 < nt) {
             const Node nx = h->nodes[h->tops[t + 1]];
@@ -1051,6 +1242,11 @@ static int run_block_loop(mpqr_handle_t h, std::vector<int>& flags) {
             apply_node(h, nd, h->dA, h->lda, a_end, h->n, true, h->a_scale, true, 1, true);       // ... the rest overlaps its panels
         }
     }
+    if (h->la_dirty) {                                      // the tall stream's work, once
+        HIPCHK(h, hipEventRecord(h->ev_cold, h->sA));
+        HIPCHK(h, hipStreamWaitEvent(h->s0, h->ev_cold, 0));
+    }
+    h->la_on = false; h->la_dirty = false; h->la_warm = false; h->la_pg_issued = false;
     if (h->defer_join) {                                    // the T stream's work of every block, once
         h->defer_join = false;
         HIPCHK(h, hipEventRecord(h->ev_join, h->sT));
@@ -1101,6 +1297,7 @@ int mpqr_sync(mpqr_handle_t h) {
     HIPCHK(h, hipStreamSynchronize(h->s0));
     if (h->s1) HIPCHK(h, hipStreamSynchronize(h->s1));
     if (h->sT) HIPCHK(h, hipStreamSynchronize(h->sT));
+    if (h->sA) HIPCHK(h, hipStreamSynchronize(h->sA));
     return MPQR_OK;
 }
 

@@ -1046,7 +1046,10 @@ __device__ __forceinline__ void gh_partial_gram(const half_t* Ts, float* __restr
 
 // blockIdx < nlow: rows c1 + 64 b .. of A_low (apply, and the partial Gram when Sp is given);  blockIdx >= nlow:
 // 64 rows of the TOP block (final already, written by gh_solve): partial Gram only.
-__global__ __launch_bounds__(256) void gh_apply_kernel(LeafArgs a, const float* __restrict__ Cv, float* __restrict__ Sp, int nlow) {
+// Yg != nullptr (look-ahead): the tall rows (>= c1 + 128) of the NEXT leaf's columns [c1, c1+128) also receive this leaf's
+// update in fp32,  A[row, c1 + c] -= sum_k V[row][k] Yg[k][c]  (exact-f32 MFMA; Y comes from gh_glue).
+__global__ __launch_bounds__(256) void gh_apply_kernel(LeafArgs a, const float* __restrict__ Cv, float* __restrict__ Sp, int nlow,
+                                                       const float* __restrict__ Yg) {
     float* As = (float*)gh_smem;                         // [64][129] = 8256 floats
     float* Cs = (float*)gh_smem + 8256;                  // [128][GH_TS], 16-B aligned
     half_t* Ts = (half_t*)gh_smem;                       // [128][72] halves, reuses the As region after the MFMAs
@@ -1112,9 +1115,46 @@ __global__ __launch_bounds__(256) void gh_apply_kernel(LeafArgs a, const float* 
                 a.Vh[(long)row * a.ldvh + gc] = (half_t)v;
             }
             Ts[(n0 + r) * 72 + lm] = (half_t)v;
+            if (Yg) Cs[lm * 129 + n0 + r] = v;          // fp32 V tile [64][129] for the next leaf's update (Cs is dead)
         }
     }
     __syncthreads();
+    if (Yg && row0 >= a.c1 + GW) {
+        float* Ys = Cs + 8256;                           // [64][GH_TS]: half of Y's rows at a time
+        floatx16p u0, u1;
+#pragma unroll
+        for (int e = 0; e < 16; e++) { u0[e] = 0.f; u1[e] = 0.f; }
+        for (int hk = 0; hk < 2; hk++) {
+#pragma unroll
+            for (int q = 0; q < 8; q++) {
+                const int e4 = tid + 256 * q, k = e4 >> 5, c = (e4 & 31) * 4;
+                *(float4*)&Ys[k * GH_TS + c] = *(const float4*)&Yg[(64 * hk + k) * GW + c];
+            }
+            __syncthreads();
+            for (int k1 = 0; k1 < 64; k1 += 16) {
+                float a0[8], a1[8], b[8];
+#pragma unroll
+                for (int u = 0; u < 8; u++) {
+                    const int k = k1 + 2 * u + kk;
+                    a0[u] = Cs[r * 129 + 64 * hk + k]; a1[u] = Cs[(32 + r) * 129 + 64 * hk + k]; b[u] = Ys[k * GH_TS + n0 + r];
+                }
+#pragma unroll
+                for (int u = 0; u < 8; u++) {
+                    u0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[u], b[u], u0, 0, 0, 0);
+                    u1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[u], b[u], u1, 0, 0, 0);
+                }
+            }
+            __syncthreads();
+        }
+        const int gn = a.c1 + n0 + r;                     // column of the next leaf
+#pragma unroll
+        for (int mt = 0; mt < 2; mt++)
+#pragma unroll
+            for (int e = 0; e < 16; e++) {
+                const int row = row0 + mt * 32 + (e & 3) + 8 * (e >> 2) + 4 * kk;
+                if (row < a.mrows) a.A[(long)row * a.lda + gn] -= (mt == 0 ? u0[e] : u1[e]);
+            }
+    }
     if (Sp) gh_partial_gram(Ts, Sp + (long)blockIdx.x * (GW * GW), lane, wave);
     // V^T rows: 128 columns x 64 rows of this workgroup, 16-B chunks along the row index
     for (int e = tid; e < GW * 8; e += 256) {
@@ -1154,36 +1194,330 @@ __global__ __launch_bounds__(256) void gh_reduce_f32_kernel(const float* __restr
     if (wave == 0) S[e] = (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
 }
 
+// ------------------------------------------------------------------ Gram-level look-ahead of the panel chain
+// The chain of a block is  gram -> solve -> apply -> (update of the next leaf's columns) -> gram -> ...: four passes over
+// the tall data between two solves.  With the quantities below the NEXT leaf's inputs (N = Gram matrix of its remaining
+// rows, B = its top block) follow from this leaf's small results and a Gram pass over data that does not contain this
+// leaf's update yet, so the chain shrinks to  solve -> glue -> solve -> ...  and every tall pass runs beside it:
+//   leaf j: columns J = [c0, c0+128), rows Rj = [c0, c0+128);  next leaf: columns J+1, rows R' = [c0+128, c0+256)
+//   Glx = A[>= c0+128, J]^T A[>= c0+128, J+1],  Gld = A[>= c0+128, J+1]^T A[>= c0+128, J+1]      (gh_pair_gram, fp64)
+//   E = A[Rj, J+1],  F = A[R', J],  D = A[R', J+1],  B = A[Rj, J] before the solve,  N = Gram of leaf j's rows
+//   S = Vtop^T Vtop + C^T (N - B^T B) C,   T = (striu(S) + diag(S)/2)^-1                       (exact reflectors)
+//   Z = Vtop^T E + C^T Glx  (= V^T A[:, J+1]),   Y = T^T Z
+//   R rows of the next columns   Rx = E - Vtop Y      -> A[Rj, J+1]
+//   next top block               B' = D - (F C) Y     -> A[R', J+1]
+//   next Gram matrix             N' = Gld + E^T E - Rx^T Rx     (the update is orthogonal: column norms over rows >= c0 stay)
+// gh_apply then gives the tall rows of the next leaf's columns exactly this update, A[>= c0+256, J+1] -= V_low Y, in fp32
+// (the prediction has to agree with the data to fp32 level), and the other columns of the block keep the fp16 path.
+
+// rows >= r0 of the 256 adjacent columns [cx, cx+256): partial Glx (64 tiles of 16 x 16) and Gld (36 upper tiles), fp64 MFMA.
+// Workgroup b takes `cpw` consecutive 64-row chunks; partial b = [Glx | Gld] (2 x 16384 doubles).
+constexpr int PG_ROWS = 64, PG_TD = 258;
+__global__ __launch_bounds__(512) void gh_pair_gram_kernel(const float* __restrict__ A, long lda, int mrows, int r0, int cx,
+                                                           int cpw, double* __restrict__ Gp2) {
+    double* tile = (double*)gh_smem;                       // [PG_ROWS][PG_TD]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, lk = lane >> 4;
+    typedef double double4g __attribute__((ext_vector_type(4)));
+    int ca[13], cbv[13], oi[13], oj[13];                    // operand columns inside the 256-wide tile, output tile origin
+    double4g acc[13];
+#pragma unroll
+    for (int s = 0; s < 13; s++) {
+        int t = wave + 8 * s;
+        if (t < 64) { ca[s] = 16 * (t >> 3); cbv[s] = 128 + 16 * (t & 7); oi[s] = 16 * (t >> 3); oj[s] = 16 * (t & 7); }
+        else if (t < 100) {
+            int u = t - 64, ti = 0;
+            while (u >= 8 - ti) { u -= 8 - ti; ti++; }
+            ca[s] = 128 + 16 * ti; cbv[s] = 128 + 16 * (ti + u); oi[s] = 128 + 16 * ti; oj[s] = 16 * (ti + u);   // oi >= 128: Gld
+        } else { ca[s] = -1; cbv[s] = 0; oi[s] = 0; oj[s] = 0; }
+        acc[s] = double4g{0, 0, 0, 0};
+    }
+    for (int c = 0; c < cpw; c++) {
+        const int row0 = r0 + ((int)blockIdx.x * cpw + c) * PG_ROWS;
+        if (row0 >= mrows) break;
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            const int id = tid + 512 * i, lr = id >> 6, c4 = id & 63, row = row0 + lr;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (row < mrows) v = *(const float4*)(A + (long)row * lda + cx + 4 * c4);
+            double* d = &tile[lr * PG_TD + 4 * c4];
+            *(double2*)d = make_double2((double)v.x, (double)v.y);
+            *(double2*)(d + 2) = make_double2((double)v.z, (double)v.w);
+        }
+        __syncthreads();
+        for (int k0 = 0; k0 < PG_ROWS; k0 += 4) {
+            const double* tr = &tile[(k0 + lk) * PG_TD + li];
+#pragma unroll
+            for (int s = 0; s < 13; s++)
+                if (ca[s] >= 0) acc[s] = __builtin_amdgcn_mfma_f64_16x16x4f64(tr[ca[s]], tr[cbv[s]], acc[s], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+    double* out = Gp2 + (long)blockIdx.x * (2 * GW * GW);
+#pragma unroll
+    for (int s = 0; s < 13; s++)
+        if (ca[s] >= 0) {
+#pragma unroll
+            for (int v = 0; v < 4; v++) {
+                const int i = oi[s] + lk + 4 * v, j = oj[s] + li;        // i >= 128 addresses the second matrix
+                out[i * GW + j] = acc[s][v];
+            }
+        }
+}
+// [Glx | Gld] = sum of the partials (fixed order); Gld's lower tiles are mirrored
+__global__ __launch_bounds__(256) void gh_pair_reduce_kernel(const double* __restrict__ Gp2, int nwg, double* __restrict__ G2) {
+    __shared__ double part[4][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int e = blockIdx.x * 64 + lane;                   // 0 .. 32767
+    const int m2 = e >> 14, i = (e >> 7) & 127, j = e & 127;
+    const bool act = m2 == 0 || (i >> 4) <= (j >> 4);
+    double s = 0;
+    if (act) {
+        double s0 = 0, s1 = 0;
+        int q = wave;
+        for (; q + 4 < nwg; q += 8) { s0 += Gp2[(long)q * (2 * GW * GW) + e]; s1 += Gp2[(long)(q + 4) * (2 * GW * GW) + e]; }
+        for (; q < nwg; q += 4) s0 += Gp2[(long)q * (2 * GW * GW) + e];
+        s = s0 + s1;
+    }
+    part[wave][lane] = s;
+    __syncthreads();
+    if (wave == 0 && act) {
+        const double g = (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
+        G2[e] = g;
+        if (m2 == 1 && (i >> 4) != (j >> 4)) G2[GW * GW + j * GW + i] = g;
+    }
+}
+void launch_gh_pair_gram(const float* A, long lda, int mrows, int r0, int cx, double* Gp2, int max_wg, double* G2, hipStream_t s) {
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute((const void*)gh_pair_gram_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, PG_ROWS * PG_TD * 8);
+        attr = true;
+    }
+    const int nchunk = std::max(0, (mrows - r0 + PG_ROWS - 1) / PG_ROWS);
+    int nwg = std::min(std::max(nchunk, 1), std::min(max_wg, 64));
+    const int cpw = std::max(1, (nchunk + nwg - 1) / nwg);
+    nwg = std::max(1, (nchunk + cpw - 1) / cpw);
+    hipLaunchKernelGGL(gh_pair_gram_kernel, dim3(nwg), dim3(512), PG_ROWS * PG_TD * 8, s, A, lda, mrows, r0, cx, cpw, Gp2);
+    hipLaunchKernelGGL(gh_pair_reduce_kernel, dim3(512), dim3(256), 0, s, Gp2, nwg, G2);
+}
+
+// 32 x 32 tile product accumulated into acc; A read as A[r][k] or (TA) transposed A[k][r]; optionally negated (exact)
+template <bool TA>
+__device__ __forceinline__ void lds_mm32x(floatx16p& acc, const float* A, int lda, const float* B, int ldb, int klo, int khi,
+                                          int lane, bool neg = false) {
+    const int r = lane & 31, kk = lane >> 5;
+    for (int k1 = klo; k1 < khi; k1 += 16) {
+        float av[8], bv[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const int k = k1 + 2 * u + kk;
+            av[u] = TA ? A[k * lda + r] : A[r * lda + k];
+            bv[u] = B[k * ldb + r];
+        }
+        if (neg) {
+#pragma unroll
+            for (int u = 0; u < 8; u++) av[u] = -av[u];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; u++) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u], bv[u], acc, 0, 0, 0);
+    }
+}
+
+__global__ __launch_bounds__(1024) void gh_glue_kernel(GlueArgs g) {
+    float* P = (float*)gh_smem;                            // two 128 x 129 operand slots
+    float* Q = P + TP * TPS;
+    __shared__ float tdiag[GW];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int bi = wave >> 2, bj = wave & 3, r = lane & 31, kk = lane >> 5;
+    const long lda = g.lda;
+    const int c0 = g.c0, c1 = g.c0 + GW;
+    float* const Eg = g.A + (long)c0 * lda + c1;           // rows Rj, columns J+1 (becomes Rx)
+    const float* const Fg = g.A + (long)c1 * lda + c0;     // rows R', columns J
+    float* const Dg = g.A + (long)c1 * lda + c1;           // rows R', columns J+1 (becomes B')
+    auto ldmat = [&](float* slot, const float* src, long ld) {
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int e4 = tid + 1024 * q, i = e4 >> 5, j = (e4 & 31) * 4;
+            const float4 v = *(const float4*)&src[(long)i * ld + j];
+            float* d = &slot[i * TPS + j];
+            d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+        }
+    };
+    auto ldvtop = [&](float* slot) {                       // reflector values of the top block: v below, vdiag on, 0 above the diagonal
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int e4 = tid + 1024 * q, i = e4 >> 5, j = (e4 & 31) * 4;
+            const float4 v = *(const float4*)&g.A[(long)(c0 + i) * lda + c0 + j];
+            const float vd = g.vdiag[c0 + i];
+            float* d = &slot[i * TPS + j];
+            d[0] = i > j ? v.x : (i == j ? vd : 0.f);
+            d[1] = i > j + 1 ? v.y : (i == j + 1 ? vd : 0.f);
+            d[2] = i > j + 2 ? v.z : (i == j + 2 ? vd : 0.f);
+            d[3] = i > j + 3 ? v.w : (i == j + 3 ? vd : 0.f);
+        }
+    };
+    auto zero16 = [](floatx16p& a) {
+#pragma unroll
+        for (int e = 0; e < 16; e++) a[e] = 0.f;
+    };
+#define GLUE_ROW(e) (32 * bi + ((e) & 3) + 8 * ((e) >> 2) + 4 * kk)
+    const int col = 32 * bj + r;
+    floatx16p acc, accS, accZ, accFC, accN;
+    // ---- Glow = N - B^T B
+    ldmat(P, g.Bs, GW);
+    __syncthreads();
+    zero16(acc);
+    lds_mm32x<true>(acc, P + 32 * bi, TPS, P + 32 * bj, TPS, 0, GW, lane);
+#pragma unroll
+    for (int e = 0; e < 16; e++) { const int i = GLUE_ROW(e); Q[i * TPS + col] = (float)(g.N[i * GW + col] - (double)acc[e]); }
+    __syncthreads();
+    // ---- S = C^T (Glow C) + Vtop^T Vtop
+    ldmat(P, g.Cv, GW);
+    __syncthreads();
+    zero16(acc);
+    lds_mm32x<false>(acc, Q + 32 * bi * TPS, TPS, P + 32 * bj, TPS, 0, GW, lane);
+    __syncthreads();
+    lds_store32(&Q[32 * bi * TPS + 32 * bj], TPS, acc, 1.f, lane);
+    __syncthreads();
+    zero16(accS);
+    lds_mm32x<true>(accS, P + 32 * bi, TPS, Q + 32 * bj, TPS, 0, GW, lane);
+    __syncthreads();
+    ldvtop(Q);
+    ldmat(P, Eg, lda);
+    __syncthreads();
+    lds_mm32x<true>(accS, Q + 32 * bi, TPS, Q + 32 * bj, TPS, 0, GW, lane);
+    // ---- Z = Vtop^T E + C^T Glx ;  E^T E
+    zero16(accZ); zero16(accN);
+    lds_mm32x<true>(accZ, Q + 32 * bi, TPS, P + 32 * bj, TPS, 0, GW, lane);
+    lds_mm32x<true>(accN, P + 32 * bi, TPS, P + 32 * bj, TPS, 0, GW, lane);
+    __syncthreads();
+    ldmat(P, g.Cv, GW);
+#pragma unroll
+    for (int q = 0; q < 16; q++) { const int e1 = tid + 1024 * q; Q[(e1 >> 7) * TPS + (e1 & 127)] = (float)g.Glx[e1]; }
+    __syncthreads();
+    lds_mm32x<true>(accZ, P + 32 * bi, TPS, Q + 32 * bj, TPS, 0, GW, lane);
+    __syncthreads();
+    // ---- F C
+    ldmat(Q, Fg, lda);
+    __syncthreads();
+    zero16(accFC);
+    lds_mm32x<false>(accFC, Q + 32 * bi * TPS, TPS, P + 32 * bj, TPS, 0, GW, lane);
+    __syncthreads();
+    // ---- T = (striu(S) + diag(S)/2)^-1
+#pragma unroll
+    for (int e = 0; e < 16; e++) {
+        const int i = GLUE_ROW(e);
+        P[i * TPS + col] = (col > i) ? accS[e] : 0.f;
+        if (i == col) tdiag[i] = 2.0f / accS[e];
+    }
+    for (int e1 = tid; e1 < TP * TPS; e1 += 1024) Q[e1] = 0.f;
+    __syncthreads();
+    tri_inverse_128(P, tdiag, Q, 4, tid);                  // Q = T
+    // ---- Y = T^T Z
+    lds_store32(&P[32 * bi * TPS + 32 * bj], TPS, accZ, 1.f, lane);
+    __syncthreads();
+    zero16(acc);
+    lds_mm32x<true>(acc, Q + 32 * bi, TPS, P + 32 * bj, TPS, 0, GW, lane);
+    __syncthreads();
+    lds_store32(&P[32 * bi * TPS + 32 * bj], TPS, acc, 1.f, lane);       // P = Y
+#pragma unroll
+    for (int e = 0; e < 16; e++) g.Yg[GLUE_ROW(e) * GW + col] = acc[e];
+    ldvtop(Q);
+    __syncthreads();
+    // ---- Rx = E - Vtop Y
+    zero16(acc);
+    lds_mm32x<false>(acc, Q + 32 * bi * TPS, TPS, P + 32 * bj, TPS, 0, GW, lane);
+#pragma unroll
+    for (int e = 0; e < 16; e++) {
+        const long o = (long)GLUE_ROW(e) * lda + col;
+        const float v = Eg[o] - acc[e];
+        Eg[o] = v; acc[e] = v;
+    }
+    __syncthreads();
+    // ---- B' = D - (F C) Y
+    lds_store32(&Q[32 * bi * TPS + 32 * bj], TPS, accFC, 1.f, lane);
+    __syncthreads();
+    zero16(accFC);
+    lds_mm32x<false>(accFC, Q + 32 * bi * TPS, TPS, P + 32 * bj, TPS, 0, GW, lane);
+#pragma unroll
+    for (int e = 0; e < 16; e++) {
+        const int i = GLUE_ROW(e);
+        const float v = Dg[(long)i * lda + col] - accFC[e];
+        Dg[(long)i * lda + col] = v;
+        g.Bn[i * GW + col] = v;
+    }
+    __syncthreads();
+    // ---- N' = Gld + E^T E - Rx^T Rx
+    lds_store32(&Q[32 * bi * TPS + 32 * bj], TPS, acc, 1.f, lane);       // Q = Rx
+    __syncthreads();
+    lds_mm32x<true>(accN, Q + 32 * bi, TPS, Q + 32 * bj, TPS, 0, GW, lane, true);
+#pragma unroll
+    for (int e = 0; e < 16; e++) { const int i = GLUE_ROW(e); g.Nn[i * GW + col] = g.Gld[i * GW + col] + (double)accN[e]; }
+#undef GLUE_ROW
+}
+void launch_gh_glue(const GlueArgs& g, hipStream_t s) {
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute((const void*)gh_glue_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * TP * TPS * 4);
+        attr = true;
+    }
+    hipLaunchKernelGGL(gh_glue_kernel, dim3(1), dim3(1024), 2 * TP * TPS * 4, s, g);
+}
+// the top block of a leaf before its solve (the glue of the look-ahead needs it)
+__global__ __launch_bounds__(256) void gh_save_top_kernel(const float* __restrict__ A, long lda, int c0, float* __restrict__ Bs) {
+    for (int e4 = threadIdx.x + 256 * blockIdx.x; e4 < GW * GW / 4; e4 += 256 * gridDim.x) {
+        const int i = e4 >> 5, j = (e4 & 31) * 4;
+        *(float4*)&Bs[i * GW + j] = *(const float4*)&A[(long)(c0 + i) * lda + c0 + j];
+    }
+}
+void launch_gh_save_top(const float* A, long lda, int c0, float* Bs, hipStream_t s) {
+    hipLaunchKernelGGL(gh_save_top_kernel, dim3(16), dim3(256), 0, s, A, lda, c0, Bs);
+}
+
 int gh_num_partials(const LeafArgs& a) {
     return (a.mrows - a.c1 + 63) / 64 + (a.c1 - a.c0 + 63) / 64;
 }
 void launch_gh_reduce_f32(const float* Sp, int nslab, float* S, hipStream_t s) {
     hipLaunchKernelGGL(gh_reduce_f32_kernel, dim3(256), dim3(256), 0, s, Sp, nslab, S);
 }
-void launch_leaf_gram_householder(const LeafArgs& a, double* Gp, double* G, float* Cv, int* flag, float* Sp, float* S,
-                                  hipStream_t s) {
+static void gh_set_attrs() {
     static bool attr = false;
-    if (!attr) {
-        (void)hipFuncSetAttribute((const void*)gh_gram_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, GH_ROWS * GH_TD * 8);
-        (void)hipFuncSetAttribute((const void*)gh_solve_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * TP * TPS * 4);
-        (void)hipFuncSetAttribute((const void*)gh_solve2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, GW * GD * 8);
-        (void)hipFuncSetAttribute((const void*)gh_apply_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (8256 + GW * GH_TS) * 4);
-        attr = true;
-    }
+    if (attr) return;
+    (void)hipFuncSetAttribute((const void*)gh_gram_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, GH_ROWS * GH_TD * 8);
+    (void)hipFuncSetAttribute((const void*)gh_solve_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * TP * TPS * 4);
+    (void)hipFuncSetAttribute((const void*)gh_solve2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, GW * GD * 8);
+    (void)hipFuncSetAttribute((const void*)gh_apply_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (8256 + GW * GH_TS) * 4);
+    attr = true;
+}
+// the four steps of a Gram-Householder leaf, separately launchable (the look-ahead schedule puts them on different streams)
+void launch_gh_gram(const LeafArgs& a, double* Gp, double* G, hipStream_t s) {
+    gh_set_attrs();
     const int nwg = (a.mrows - a.c0 + GH_ROWS - 1) / GH_ROWS;
     hipLaunchKernelGGL(gh_gram_kernel, dim3(2 * nwg), dim3(256), GH_ROWS * GH_TD * 8, s, a, Gp);
     hipLaunchKernelGGL(gh_reduce_kernel, dim3(256), dim3(256), 0, s, Gp, nwg, G);
+}
+void launch_gh_solve(const LeafArgs& a, const double* G, float* Cv, int* flag, hipStream_t s) {
+    gh_set_attrs();
     // gh_solve2 (blocked Householder reconstruction) is correct but measured SLOWER than the step-by-step kernel at w = 128
     // (162 vs 111 us: ~500 cycles per column for the fp64 in-wave Cholesky, ~300 for the LU, plus two triangular inverses
     // -- in-kernel stamps, make EXTRA=-DMPQR_KTRACE): opt-in only
     static const int solve2 = []() { const char* e = getenv("MPQR_SOLVE2"); return e ? atoi(e) : 0; }();
     if (solve2 && a.Wk) hipLaunchKernelGGL(gh_solve2_kernel, dim3(1), dim3(1024), GW * GD * 8, s, a, G, Cv, flag, a.Wk);
     else hipLaunchKernelGGL(gh_solve_kernel, dim3(1), dim3(GH_SOLVE_THREADS), 2 * TP * TPS * 4, s, a, G, Cv, flag);
+}
+void launch_gh_apply(const LeafArgs& a, const float* Cv, float* Sp, const float* Yg, hipStream_t s) {
+    gh_set_attrs();
     const int nlow = (a.mrows - a.c1 + 63) / 64;
     const int ntop = Sp ? (a.c1 - a.c0 + 63) / 64 : 0;      // extra workgroups: Gram contribution of the top block
     if (nlow + ntop == 0) return;
-    hipLaunchKernelGGL(gh_apply_kernel, dim3(nlow + ntop), dim3(256), (8256 + GW * GH_TS) * 4, s, a, Cv, Sp, nlow);
-    if (Sp && S) hipLaunchKernelGGL(gh_reduce_f32_kernel, dim3(256), dim3(256), 0, s, Sp, nlow + ntop, S);
+    hipLaunchKernelGGL(gh_apply_kernel, dim3(nlow + ntop), dim3(256), (8256 + GW * GH_TS) * 4, s, a, Cv, Sp, nlow, Yg);
+}
+void launch_leaf_gram_householder(const LeafArgs& a, double* Gp, double* G, float* Cv, int* flag, float* Sp, float* S,
+                                  hipStream_t s) {
+    launch_gh_gram(a, Gp, G, s);
+    launch_gh_solve(a, G, Cv, flag, s);
+    launch_gh_apply(a, Cv, Sp, nullptr, s);
+    if (Sp && S) launch_gh_reduce_f32(Sp, gh_num_partials(a), S, s);
 }
 
 void launch_leaf_factor(const LeafArgs& a, hipStream_t s) {

@@ -85,6 +85,28 @@ void launch_leaf_factor(const LeafArgs& a, hipStream_t s);   // robust path: one
 void launch_leaf_gram_householder(const LeafArgs& a, double* Gp /* nwg x 16384 */, double* G /* 16384 */,
                                   float* Cv /* 16384 */, int* flag, float* Sp, float* S, hipStream_t s);
 int gh_num_partials(const LeafArgs& a);
+// the same leaf in separately launchable steps (Gram-level look-ahead, kernels_panel.hip)
+void launch_gh_gram(const LeafArgs& a, double* Gp, double* G, hipStream_t s);
+void launch_gh_solve(const LeafArgs& a, const double* G, float* Cv, int* flag, hipStream_t s);
+void launch_gh_apply(const LeafArgs& a, const float* Cv, float* Sp, const float* Yg /* or nullptr */, hipStream_t s);
+// look-ahead inputs: rows >= r0 of the 256 columns [cx, cx+256): G2 = [A_x^T A_d | A_d^T A_d] (2 x 16384 doubles);
+// Gp2: max_wg x 32768 doubles of partials
+void launch_gh_pair_gram(const float* A, long lda, int mrows, int r0, int cx, double* Gp2, int max_wg, double* G2, hipStream_t s);
+struct GlueArgs {
+    float* A; long lda;
+    int c0;                     // leaf j = columns [c0, c0+128) (full, 128-aligned); next leaf = [c0+128, c0+256)
+    const float* vdiag;
+    const float* Cv;            // C_j from gh_solve
+    const double* N;            // Gram matrix leaf j was solved from
+    const double* Glx;          // pair Gram of the rows >= c0+128: cross and (Gld) next-diagonal part
+    const double* Gld;
+    const float* Bs;            // leaf j's top block before the solve
+    float* Bn;                  // out: the next leaf's top block (also written into A)
+    double* Nn;                 // out: the next leaf's Gram matrix
+    float* Yg;                  // out: Y_j (reflector x column), for gh_apply's exact update of the next leaf's columns
+};
+void launch_gh_glue(const GlueArgs& g, hipStream_t s);
+void launch_gh_save_top(const float* A, long lda, int c0, float* Bs, hipStream_t s);
 void launch_gh_reduce_f32(const float* Sp, int nslab, float* S, hipStream_t s);
 
 // T of a leaf (<= 128 reflectors) from its Gram slabs S (row stride lds_, aligned range starting at a0)

@@ -652,3 +652,37 @@ def test_distributed_schedule_on_one_gpu(mp, po, m, n, r, ko, world, la):
         Dm = np.ones(m, np.float32); Dm[:n] = D
         assert relF(R * Dm[:, None], R0) <= 3e-3 and relF(Q[:, :n] * D[None, :], Q0[:, :n]) <= 3e-3
         assert relF(V[:, :first], V0[:, :first]) <= 3e-3
+
+
+# ---- opt-in schedules and kernels (measured alternatives kept behind MPQR_* switches): every one of them must still
+# produce the same factorisation.  The switches are read once per process, hence one child interpreter per setting.
+OPT_IN = [
+    {},                                            # the default path, the others are compared with it
+    {"MPQR_LA": "1"},                              # Gram-level look-ahead of the panel chain (glue kernel, fp32 next-leaf update)
+    {"MPQR_SOLVE2": "1"},                          # blocked Householder-reconstruction form of the leaf solve
+    {"MPQR_GEMM7": "1"},                           # persistent-workgroup variant of the dominant GEMM
+    {"MPQR_GEMM6": "0"},                           # 4-stage ring GEMM of round 1
+    {"MPQR_FLAT": "0"},                            # tree schedule inside a block
+    {"MPQR_TSTREAM": "0"},                         # compact-WY T on the chain stream
+    {"MPQR_EXT_LOOKAHEAD": "0"},                   # block boundary: first leaf of the next block through the far update
+]
+
+
+@pytest.mark.gpu
+def test_opt_in_schedules_and_kernels():
+    import json, os, subprocess, sys
+    child = os.path.join(os.path.dirname(os.path.abspath(__file__)), "optin_child.py")
+    m, n, r = 3072, 2304, 128                      # three 1024-column blocks (the last one partial): look-ahead across boundaries
+    ref = None
+    for extra in OPT_IN:
+        env = dict(os.environ); env.update(extra)
+        p = subprocess.run([sys.executable, child, str(m), str(n), str(r)], env=env, capture_output=True, text=True, timeout=600)
+        assert p.returncode == 0, (extra, p.stderr[-2000:])
+        out = json.loads(p.stdout.strip().splitlines()[-1])
+        assert out["backward_error"] <= 1e-3, (extra, out["backward_error"])          # north_star tolerance
+        assert out["orth_max"] <= 2e-3, (extra, out["orth_max"])
+        d = np.array(out["absdiag"])
+        if ref is None:
+            ref = d
+        else:                                       # same R up to the fp16-level differences between update orders
+            assert np.max(np.abs(d - ref) / ref) <= 2e-2, (extra, float(np.max(np.abs(d - ref) / ref)))
