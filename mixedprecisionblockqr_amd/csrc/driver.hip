@@ -131,6 +131,15 @@ struct mpqr_handle_s {
 
     std::vector<Node> nodes;
     std::vector<int> tops;
+    // Q formation over PAIRS of top-level blocks (K = 2 outer_block: the GEMMs run at a higher rate; the pair's T is merged
+    // in the background, T_LR = -T_L (V_L^T V_R) T_R, on the far-update stream with its own scratch)
+    std::vector<int> qpair;       // per top index t: id of the pair node whose RIGHT child is top t, else -1
+    bool pairs_ready = false;     // the pair T's of the current factorisation are (enqueued to be) complete
+    float* S2 = nullptr; size_t s2_elems = 0; float* tmp1b = nullptr; float* tmp2b = nullptr;
+    // transposed fp16 shadow of Q, Qt[column][row], kept up to date by the epilogue of Q -= V Y^T: the next X = Q2^T V
+    // reads it with LDS-DMA like any fp16 operand (the fp32 operand path converts and transposes in registers: 620 TFLOP/s)
+    half_t* Qt = nullptr; long ldqt = 0;
+    half_t* shadow = nullptr; long ldshadow = 0;      // set by form_q around its applies (apply_node, lane 0)
     // 1-D block-cyclic column distribution (world == 1: everything local)
     int world = 1, rank = 0;
     int nloc = 0;        // local columns of A
@@ -185,8 +194,9 @@ void free_plan(mpqr_handle_t h) {
     void* ptrs[] = {h->dA, h->dA0, h->dQ, h->Vh, h->Vt, h->vdiag, h->Xt, h->Yt, h->S, h->P, h->tmp1, h->tmp2,
                     h->Tf, h->Th, h->Tth, h->dstage, h->Gp, h->Gs, h->Cv, h->dflag, h->Vf, h->Yf, h->Xt1, h->Yt1, h->Sp,
                     h->rbTf, h->rbTh, h->rbTth, h->Sleaf, h->Wk, h->V8n, h->V8t, h->A8t, h->Y8,
-                    h->GsN[0], h->GsN[1], h->Gp2, h->G2, h->Bsv[0], h->Bsv[1], h->Cv2[1], h->Yg};
+                    h->GsN[0], h->GsN[1], h->Gp2, h->G2, h->Bsv[0], h->Bsv[1], h->Cv2[1], h->Yg, h->S2, h->tmp1b, h->tmp2b, h->Qt};
     for (void* p : ptrs) if (p) (void)hipFree(p);
+    h->S2 = h->tmp1b = h->tmp2b = nullptr; h->s2_elems = 0; h->Qt = nullptr; h->shadow = nullptr; h->qpair.clear(); h->pairs_ready = false;
     h->GsN[0] = h->GsN[1] = nullptr; h->Gp2 = h->G2 = nullptr; h->Bsv[0] = h->Bsv[1] = nullptr; h->Cv2[0] = h->Cv2[1] = nullptr; h->Yg = nullptr;
     h->dA = h->dA0 = h->dQ = nullptr; h->Vh = h->Vt = nullptr; h->vdiag = nullptr; h->Xt = nullptr; h->Yt = nullptr;
     h->S = nullptr; h->P = nullptr; h->tmp1 = h->tmp2 = nullptr; h->Tf = nullptr; h->Th = h->Tth = nullptr;
@@ -282,13 +292,15 @@ int choose_split(int M, int N, int K, size_t cap_elems, long slab) {
 }
 
 // S (slabs, KrL x KrR, ld = KrR) = V_L^T V_R over rows >= 64-aligned start of R
-int gram(mpqr_handle_t h, const Node& L, const Node& R, int* nslab, long* slab, hipStream_t st) {
+int gram(mpqr_handle_t h, const Node& L, const Node& R, int* nslab, long* slab, hipStream_t st, float* Sbuf = nullptr,
+         size_t s_cap = 0) {
+    if (!Sbuf) { Sbuf = h->S; s_cap = h->s_elems; }
     const int rlo = rdown(R.c0, 64);
     if (h->opts.precision == MPQR_PREC_FP32) {            // exact-f32 products of the fp32 reflectors
         SgemmArgs g{};
         g.A = h->Vf + (long)rlo * h->n_pad + L.a0; g.lda = h->n_pad; g.transA = 1;
         g.B = h->Vf + (long)rlo * h->n_pad + R.a0; g.ldb = h->n_pad; g.transB = 0;
-        g.C = h->S; g.ldc = R.ldt; g.M = L.ldt; g.N = R.ldt; g.K = h->m_pad - rlo; g.alpha = 1.f; g.beta = 0.f; g.nslab_a = 1;
+        g.C = Sbuf; g.ldc = R.ldt; g.M = L.ldt; g.N = R.ldt; g.K = h->m_pad - rlo; g.alpha = 1.f; g.beta = 0.f; g.nslab_a = 1;
         launch_sgemm(g, st);
         *nslab = 1; *slab = (long)L.ldt * R.ldt;
         return MPQR_OK;
@@ -296,14 +308,14 @@ int gram(mpqr_handle_t h, const Node& L, const Node& R, int* nslab, long* slab, 
     GemmArgs g{};
     g.A = h->Vt + (long)L.a0 * h->ldvt + rlo;  g.lda = h->ldvt;
     g.Bt = h->Vt + (long)R.a0 * h->ldvt + rlo; g.ldb = h->ldvt;
-    g.C = h->S; g.ldc = R.ldt;
+    g.C = Sbuf; g.ldc = R.ldt;
     g.M = L.ldt; g.N = R.ldt; g.K = h->m_pad - rlo;
     g.alpha = 1.f; g.in_scale = 1.f;
     *slab = (long)L.ldt * R.ldt;
-    g.nsplit = choose_split(g.M, g.N, g.K, h->s_elems, *slab);
+    g.nsplit = choose_split(g.M, g.N, g.K, s_cap, *slab);
     g.slab_out_stride = *slab;
     launch_gemm_f16(A_H16, E_STORE_F32, g, st);
-    if (g.nsplit > 1) launch_slab_reduce(h->S, g.nsplit, *slab, *slab, h->S, st);
+    if (g.nsplit > 1) launch_slab_reduce(Sbuf, g.nsplit, *slab, *slab, Sbuf, st);
     *nslab = 1;
     return MPQR_OK;
 }
@@ -378,6 +390,11 @@ void apply_node(mpqr_handle_t h, const Node& nd, float* C, long ldc, int clo, in
         launch_gemm_fp8(E_STORE_F32, f1, st);
         if (f1.nsplit > 1) launch_slab_reduce(Xt, f1.nsplit, slab, slab, Xt, st);
     } else {
+    if (h->shadow && lane == 0 && !far) {                  // fp16 operand, already [column][row]: C2^T = shadow rows
+        g1.A = h->shadow + (long)clo_al * h->ldshadow + rlo; g1.lda = h->ldshadow;
+        g1.in_scale = 1.f;
+        gemm_dispatch(A_H16, E_STORE_F32, g1, st1);
+    } else
     gemm_dispatch(A_F32T, E_STORE_F32, g1, st1);
     if (g1.nsplit > 1) launch_slab_reduce(Xt, g1.nsplit, slab, slab, Xt, st1);
     }
@@ -399,6 +416,7 @@ void apply_node(mpqr_handle_t h, const Node& nd, float* C, long ldc, int clo, in
     g3.C = C + (long)rlo * ldc + clo_al; g3.ldc = ldc;
     g3.M = Kw; g3.N = M1; g3.K = Kr;
     g3.col_lo = clo - clo_al; g3.alpha = 1.0f / in_scale; g3.in_scale = 1.f; g3.nsplit = 1;
+    if (h->shadow && lane == 0 && !far) { g3.Ct = h->shadow + (long)clo_al * h->ldshadow + rlo; g3.ldct = h->ldshadow; g3.ct_scale = in_scale; }
     if (record) (void)hipEventRecord(e2, st);
     if (f8) {
         launch_quant_h16_fp8(Yt, Kr, h->Y8, h->ld8k, M1, Kr, 0.25f, st);                       // 2^-2 Y
@@ -845,14 +863,52 @@ int compute_scale(mpqr_handle_t h, const float* src) {
     return MPQR_OK;
 }
 
+// T of a pair of top-level blocks from its children's: T_LR = -T_L (V_L^T V_R) T_R  (enqueued on `st`, own scratch)
+static void merge_pair(mpqr_handle_t h, int pid, hipStream_t st) {
+    Range rg("mpqr:wy_T_pair");
+    const Node nd = h->nodes[pid];
+    const Node L = h->nodes[nd.left], R = h->nodes[nd.right];
+    if (h->tq_on) {                                       // the children's T's come from the T stream
+        (void)hipStreamWaitEvent(st, h->ev_T[L.id], 0);
+        (void)hipStreamWaitEvent(st, h->ev_T[R.id], 0);
+    }
+    int nslab; long slab;
+    gram(h, L, R, &nslab, &slab, st, h->S2, h->s2_elems);
+    SgemmArgs s1{};
+    s1.A = h->S2; s1.lda = R.ldt; s1.transA = 0; s1.nslab_a = nslab; s1.slab_a = slab;
+    s1.B = h->Tf + R.toff; s1.ldb = R.ldt; s1.transB = 0;
+    s1.C = h->tmp1b; s1.ldc = R.ldt; s1.M = L.ldt; s1.N = R.ldt; s1.K = R.ldt; s1.alpha = 1.f; s1.beta = 0.f; s1.upperB = 1;
+    launch_sgemm(s1, st);
+    SgemmArgs s2{};
+    s2.A = h->Tf + L.toff; s2.lda = L.ldt; s2.transA = 0; s2.nslab_a = 1;
+    s2.B = h->tmp1b; s2.ldb = R.ldt; s2.transB = 0;
+    s2.C = h->tmp2b; s2.ldc = R.ldt; s2.M = L.ldt; s2.N = R.ldt; s2.K = L.ldt; s2.alpha = -1.f; s2.beta = 0.f; s2.upperA = 1;
+    launch_sgemm(s2, st);
+    launch_t_assemble(h->Tf + nd.toff, h->Th + nd.toff, h->Tth + nd.toff, nd.ldt, nd.a0, h->Tf + L.toff, L.ldt, L.a0,
+                      nd.c0, L.c1, h->Tf + R.toff, R.ldt, R.a0, nd.c1, h->tmp2b, R.ldt, st);
+    if (h->tq_on && nd.id < (int)h->ev_T.size()) (void)hipEventRecord(h->ev_T[nd.id], st);
+}
+
 int form_q(mpqr_handle_t h) {
     Range rg("mpqr:form_q");
     HIPCHK(h, hipMemsetAsync(h->dQ, 0, (size_t)h->m_pad * h->ldq * sizeof(float), h->s0));
     launch_set_identity(h->dQ, h->ldq, h->m, h->m, h->s0);
+    if (h->Qt && h->world == 1) {
+        HIPCHK(h, hipMemsetAsync(h->Qt, 0, (size_t)(h->m_pad + 256) * h->ldqt * sizeof(half_t), h->s0));
+        launch_set_identity_h16(h->Qt, h->ldqt, h->m, h->s0);
+        h->shadow = h->Qt; h->ldshadow = h->ldqt;
+    }
     for (int t = (int)h->tops.size() - 1; t >= 0; t--) {
+        if (h->pairs_ready && t < (int)h->qpair.size() && h->qpair[t] >= 0) {      // two blocks at once, K = 2 outer_block
+            const Node& pr = h->nodes[h->qpair[t]];
+            apply_node(h, pr, h->dQ, h->ldq, pr.c0, h->m, false, 1.f, false);
+            t--;
+            continue;
+        }
         const Node& nd = h->nodes[h->tops[t]];
         apply_node(h, nd, h->dQ, h->ldq, nd.c0, h->m, false, 1.f, false);
     }
+    h->shadow = nullptr;
     h->q_formed = true;
     return MPQR_OK;
 }
@@ -1018,10 +1074,30 @@ static int plan_common(mpqr_handle_t h, int m, int n, int r, const mpqr_opts* op
     for (int c = 0; c < n; c += Ko) h->tops.push_back(build_tree(h, c, std::min(n, c + Ko)));
     size_t toff = 0; int max_ldt = 64;
     for (Node& nd : h->nodes) { nd.toff = toff; toff += (size_t)nd.ldt * nd.ldt; max_ldt = std::max(max_ldt, nd.ldt); }
+    // pair nodes for Q formation (single GPU, fp16 / fp8 operands, both blocks 64-aligned): appended after the tree
+    h->qpair.assign(h->tops.size(), -1);
+    int q_ldt = 0;
+    {
+        static const int qp_on = []() { const char* e = getenv("MPQR_QPAIR"); return e ? atoi(e) : 1; }();
+        if (qp_on && world == 1 && o.form_q && o.precision != MPQR_PREC_FP32) {
+            for (size_t p = 0; p + 1 < h->tops.size(); p += 2) {
+                const Node L = h->nodes[h->tops[p]], R = h->nodes[h->tops[p + 1]];
+                if (L.a0 != L.c0 || R.a0 != R.c0 || L.a1 != R.a0 || L.ldt < 256 || R.ldt < 256) continue;
+                Node pr;
+                pr.c0 = L.c0; pr.c1 = R.c1; pr.a0 = L.a0; pr.a1 = R.a1; pr.ldt = pr.a1 - pr.a0;
+                pr.left = h->tops[p]; pr.right = h->tops[p + 1]; pr.toff = toff; pr.tld = pr.ldt; pr.id = (int)h->nodes.size();
+                toff += (size_t)pr.ldt * pr.ldt;
+                q_ldt = std::max(q_ldt, pr.ldt);
+                h->qpair[p + 1] = pr.id;
+                h->nodes.push_back(pr);
+            }
+        }
+    }
     h->t_elems = toff;
     const size_t maxdim = (size_t)std::max(h->m_pad, h->n_pad);
-    h->xt_elems = std::max(maxdim * (size_t)max_ldt, (size_t)64 * max_ldt * max_ldt);
-    h->yt_elems = maxdim * (size_t)max_ldt;
+    const int x_ldt = std::max(max_ldt, q_ldt);
+    h->xt_elems = std::max(maxdim * (size_t)x_ldt, (size_t)64 * max_ldt * max_ldt);
+    h->yt_elems = maxdim * (size_t)x_ldt;
     h->s_elems = (size_t)64 * max_ldt * max_ldt;
     h->tmp_elems = (size_t)max_ldt * max_ldt;
     h->maxwg = h->m_pad / 256 + 2;
@@ -1045,15 +1121,15 @@ static int plan_common(mpqr_handle_t h, int m, int n, int r, const mpqr_opts* op
         HIPCHK(h, hipMemsetAsync(h->V8n, 0, e1, h->s0)); HIPCHK(h, hipMemsetAsync(h->V8t, 0, e2, h->s0));
         HIPCHK(h, hipMemsetAsync(h->A8t, 0, e3, h->s0)); HIPCHK(h, hipMemsetAsync(h->Y8, 0, e4, h->s0));
     }
-    if ((rc = dalloc(h, &h->Xt, h->xt_elems + (size_t)256 * max_ldt))) return rc;
-    if ((rc = dalloc(h, &h->Yt, h->yt_elems + (size_t)256 * max_ldt))) return rc;
-    HIPCHK(h, hipMemsetAsync(h->Xt, 0, (h->xt_elems + (size_t)256 * max_ldt) * sizeof(float), h->s0));
-    HIPCHK(h, hipMemsetAsync(h->Yt, 0, (h->yt_elems + (size_t)256 * max_ldt) * sizeof(half_t), h->s0));
+    if ((rc = dalloc(h, &h->Xt, h->xt_elems + (size_t)256 * x_ldt))) return rc;
+    if ((rc = dalloc(h, &h->Yt, h->yt_elems + (size_t)256 * x_ldt))) return rc;
+    HIPCHK(h, hipMemsetAsync(h->Xt, 0, (h->xt_elems + (size_t)256 * x_ldt) * sizeof(float), h->s0));
+    HIPCHK(h, hipMemsetAsync(h->Yt, 0, (h->yt_elems + (size_t)256 * x_ldt) * sizeof(half_t), h->s0));
     if (o.lookahead && o.precision != MPQR_PREC_FP32) {
-        if ((rc = dalloc(h, &h->Xt1, h->xt_elems + (size_t)256 * max_ldt))) return rc;
-        if ((rc = dalloc(h, &h->Yt1, h->yt_elems + (size_t)256 * max_ldt))) return rc;
-        HIPCHK(h, hipMemsetAsync(h->Xt1, 0, (h->xt_elems + (size_t)256 * max_ldt) * sizeof(float), h->s0));
-        HIPCHK(h, hipMemsetAsync(h->Yt1, 0, (h->yt_elems + (size_t)256 * max_ldt) * sizeof(half_t), h->s0));
+        if ((rc = dalloc(h, &h->Xt1, h->xt_elems + (size_t)256 * x_ldt))) return rc;
+        if ((rc = dalloc(h, &h->Yt1, h->yt_elems + (size_t)256 * x_ldt))) return rc;
+        HIPCHK(h, hipMemsetAsync(h->Xt1, 0, (h->xt_elems + (size_t)256 * x_ldt) * sizeof(float), h->s0));
+        HIPCHK(h, hipMemsetAsync(h->Yt1, 0, (h->yt_elems + (size_t)256 * x_ldt) * sizeof(half_t), h->s0));
         for (size_t t = 0; t < h->tops.size(); t++) {
             hipEvent_t e1, e2;
             HIPCHK(h, hipEventCreateWithFlags(&e1, hipEventDisableTiming));
@@ -1094,12 +1170,23 @@ static int plan_common(mpqr_handle_t h, int m, int n, int r, const mpqr_opts* op
     if ((rc = dalloc(h, &h->dA0, (size_t)h->m_pad * h->lda + 1024))) return rc;
     if ((rc = dalloc(h, &h->tmp1, h->tmp_elems))) return rc;
     if ((rc = dalloc(h, &h->tmp2, h->tmp_elems))) return rc;
+    {
+        static const int sh_on = []() { const char* e = getenv("MPQR_QSHADOW"); return e ? atoi(e) : 1; }();
+        if (sh_on && world == 1 && o.form_q && o.precision != MPQR_PREC_FP32) {
+            h->ldqt = h->m_pad;
+            if ((rc = dalloc(h, &h->Qt, (size_t)(h->m_pad + 256) * h->ldqt))) return rc;
+        }
+    }
+    if (q_ldt) {                                          // scratch of the pair merges (they run on the far-update stream)
+        h->s2_elems = (size_t)16 * max_ldt * max_ldt;
+        if ((rc = dalloc(h, &h->S2, h->s2_elems)) || (rc = dalloc(h, &h->tmp1b, h->tmp_elems)) || (rc = dalloc(h, &h->tmp2b, h->tmp_elems))) return rc;
+    }
     if ((rc = dalloc(h, &h->Tf, h->t_elems))) return rc;
     HIPCHK(h, hipMemsetAsync(h->Tf, 0, h->t_elems * sizeof(float), h->s0));
-    if ((rc = dalloc(h, &h->Th, h->t_elems + (size_t)256 * max_ldt))) return rc;
-    if ((rc = dalloc(h, &h->Tth, h->t_elems + (size_t)256 * max_ldt))) return rc;
-    HIPCHK(h, hipMemsetAsync(h->Th, 0, (h->t_elems + (size_t)256 * max_ldt) * sizeof(half_t), h->s0));
-    HIPCHK(h, hipMemsetAsync(h->Tth, 0, (h->t_elems + (size_t)256 * max_ldt) * sizeof(half_t), h->s0));
+    if ((rc = dalloc(h, &h->Th, h->t_elems + (size_t)256 * x_ldt))) return rc;
+    if ((rc = dalloc(h, &h->Tth, h->t_elems + (size_t)256 * x_ldt))) return rc;
+    HIPCHK(h, hipMemsetAsync(h->Th, 0, (h->t_elems + (size_t)256 * x_ldt) * sizeof(half_t), h->s0));
+    HIPCHK(h, hipMemsetAsync(h->Tth, 0, (h->t_elems + (size_t)256 * x_ldt) * sizeof(half_t), h->s0));
     HIPCHK(h, hipMemsetAsync(h->dA0, 0, (size_t)h->m_pad * h->lda * sizeof(float), h->s0));
     HIPCHK(h, hipMemsetAsync(h->dflag, 0, (size_t)h->nflag * sizeof(int), h->s0));
     HIPCHK(h, hipMemsetAsync(h->dA, 0, (size_t)h->m_pad * h->lda * sizeof(float), h->s0));
@@ -1157,6 +1244,7 @@ int mpqr_generate_matrix(mpqr_handle_t h, uint64_t seed) {
 static int run_block_loop(mpqr_handle_t h, std::vector<int>& flags) {
     int rc;
     h->far_used = 0; h->far_flops.clear(); h->chain_used = 0; h->v8_node = -1;
+    h->pairs_ready = false;
     HIPCHK(h, hipEventRecord(h->ev[0], h->s0));
     HIPCHK(h, hipMemcpyAsync(h->dA, h->dA0, (size_t)h->m_pad * h->lda * sizeof(float), hipMemcpyDeviceToDevice, h->s0));
     HIPCHK(h, hipMemsetAsync(h->dflag, 0, (size_t)h->nflag * sizeof(int), h->s0));
@@ -1225,6 +1313,7 @@ static int run_block_loop(mpqr_handle_t h, std::vector<int>& flags) {
         Range rg("mpqr:far_update");
         if (!la) {
             apply_node(h, nd, h->dA, h->lda, nd.c1, h->n, true, h->a_scale, true, 0, true);
+            if (h->opts.form_q && h->qpair[t] >= 0 && h->S2) merge_pair(h, h->qpair[t], h->s0);
             continue;
         }
         HIPCHK(h, hipEventRecord(h->ev_node[t], h->node_done_stream ? h->node_done_stream : h->s0));
@@ -1241,7 +1330,10 @@ static int run_block_loop(mpqr_handle_t h, std::vector<int>& flags) {
             HIPCHK(h, hipEventRecord(h->ev_cols2[t + 1], h->s1));
             apply_node(h, nd, h->dA, h->lda, a_end, h->n, true, h->a_scale, true, 1, true);       // ... the rest overlaps its panels
         }
+        // Q formation works on pairs of blocks: the pair's T behind this block's far update, beside the next panels
+        if (h->opts.form_q && h->qpair[t] >= 0 && h->S2) merge_pair(h, h->qpair[t], h->s1);
     }
+    h->pairs_ready = h->opts.form_q && h->S2 != nullptr;
     if (h->la_dirty) {                                      // the tall stream's work, once
         HIPCHK(h, hipEventRecord(h->ev_cold, h->sA));
         HIPCHK(h, hipStreamWaitEvent(h->s0, h->ev_cold, 0));
@@ -1541,6 +1633,7 @@ static int stage_tree_begin(mpqr_handle_t h, StageTree& st, int c0, int c1, int 
     st.saved_nodes = h->nodes; st.saved_tops = h->tops; st.saved_robust = h->leaf_robust;
     st.oTf = h->Tf; st.oTh = h->Th; st.oTth = h->Tth;
     h->nodes.clear(); h->tops.clear(); h->leaf_robust.clear();
+    h->pairs_ready = false;                               // pair nodes belong to the planned tree
     const int saved_r = h->r; h->r = r;
     st.root = build_tree(h, c0, c1);
     h->r = saved_r;
@@ -1845,7 +1938,8 @@ int mpqr_dist_begin(mpqr_handle_t h, float absmax) {
     float sc = 1.f;
     if (absmax > 0.f && std::isfinite(absmax)) { int e; frexpf(absmax * sqrtf((float)h->m), &e); sc = ldexpf(1.f, 8 - e); }
     h->a_scale = sc;
-    h->far_used = 0; h->far_flops.clear(); h->chain_used = 0; h->v8_node = -1; h->n_passes = 1; h->n_robust_leaves = 0;
+    h->far_used = 0; h->far_flops.clear(); h->chain_used = 0; h->v8_node = -1;
+    h->pairs_ready = false; h->n_passes = 1; h->n_robust_leaves = 0;
     HIPCHK(h, hipEventRecord(h->ev[0], h->s0));
     HIPCHK(h, hipMemcpyAsync(h->dA, h->dA0, (size_t)h->m_pad * h->lda * sizeof(float), hipMemcpyDeviceToDevice, h->s0));
     if (h->Xt1) {                                   // far stream starts behind the copy-in; its "done" event starts signalled

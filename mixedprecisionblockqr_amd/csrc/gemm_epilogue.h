@@ -12,7 +12,8 @@ namespace mpqr {
 // 16 / 32 registers spill in the 256-register kernels: 478 / 330 vs 575 TFLOP/s), only the stores are predicated.
 template <int NI, int NJ, typename ACC>
 __device__ __forceinline__ void epilogue_sub_f32(const ACC (&acc)[NI][NJ], float* __restrict__ C, long ldc, int M, int N,
-                                                 int col_lo, float alpha, int row_base, int col_base, int r, int h) {
+                                                 int col_lo, float alpha, int row_base, int col_base, int r, int h,
+                                                 _Float16* __restrict__ Ct = nullptr, long ldct = 0, float cts = 1.f) {
     constexpr int D = MPQR_EPI_DEPTH;                      // sub-tiles whose loads are in flight ahead of the one being stored
     float oldv[D + 1][16];
     auto tile_ptr = [&](int t) -> float* {
@@ -45,6 +46,17 @@ __device__ __forceinline__ void epilogue_sub_f32(const ACC (&acc)[NI][NJ], float
 #pragma unroll
                 for (int e = 0; e < 4; e++) p[(long)e * ldc] = oldv[t % (D + 1)][q * 4 + e] - alpha * acc[i][j][q * 4 + e];
                 p += 8 * ldc;
+            }
+            if (Ct) {                                      // transposed fp16 shadow: 4 consecutive rows = one 8-byte store
+                typedef _Float16 half4e __attribute__((ext_vector_type(4)));
+                const int m0 = min(row_base + i * 32, M - 32) + 4 * h;
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    half4e hv;
+#pragma unroll
+                    for (int e = 0; e < 4; e++) hv[e] = (_Float16)(cts * (oldv[t % (D + 1)][q * 4 + e] - alpha * acc[i][j][q * 4 + e]));
+                    *(half4e*)&Ct[(long)n * ldct + m0 + 8 * q] = hv;
+                }
             }
         }
     }

@@ -230,7 +230,7 @@ __global__ __launch_bounds__(512) void gemm8_fp8_kernel(GemmArgs g, int tilesM, 
     __builtin_amdgcn_s_barrier();
     const float alpha = g.alpha;
     if (EM == E_SUB_F32) {
-        epilogue_sub_f32<4, 2>(acc, (float*)g.C, g.ldc, g.M, g.N, g.col_lo, alpha, bm + wm, bn + wn, r, h);
+        epilogue_sub_f32<4, 2>(acc, (float*)g.C, g.ldc, g.M, g.N, g.col_lo, alpha, bm + wm, bn + wn, r, h, g.Ct, g.ldct, g.ct_scale);
         return;
     }
 #pragma unroll

@@ -179,7 +179,7 @@ __global__ __launch_bounds__(256) void gemm_f16_kernel(GemmArgs g) {
     // ---- epilogue.  D layout of 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
     const float alpha = g.alpha;
     if (EM == E_SUB_F32) {
-        epilogue_sub_f32<2, 2>(acc, (float*)g.C, g.ldc, g.M, g.N, g.col_lo, alpha, bm + wm, bn + wn, r, h);
+        epilogue_sub_f32<2, 2>(acc, (float*)g.C, g.ldc, g.M, g.N, g.col_lo, alpha, bm + wm, bn + wn, r, h, g.Ct, g.ldct, g.ct_scale);
         return;
     }
 #pragma unroll

@@ -249,7 +249,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm2_f16_kernel(GemmArgs g, int
 
     const float alpha = g.alpha;
     if (EM == E_SUB_F32) {
-        epilogue_sub_f32<4, 2>(acc, (float*)g.C, g.ldc, g.M, g.N, g.col_lo, alpha, bm + wm, bn + wn, r, h);
+        epilogue_sub_f32<4, 2>(acc, (float*)g.C, g.ldc, g.M, g.N, g.col_lo, alpha, bm + wm, bn + wn, r, h, g.Ct, g.ldct, g.ct_scale);
         return;
     }
 #pragma unroll
@@ -298,9 +298,14 @@ static void launch2(const GemmArgs& g, hipStream_t s) {
 // allocation: every matrix has 1024 floats of slack) and are never stored.
 // Only for tiles that lie completely inside [0,M) x [col_lo,N): every lane stores, so the number of outstanding
 // vector-memory operations at each wait is known at compile time.  Edge tiles take the register-staged epilogue.
-template <typename ACC>
-__device__ __forceinline__ void epilogue_sub_f32_dma(const ACC (&acc)[4][2], char* smem, float* __restrict__ C, long ldc,
-                                                     float alpha, int bm, int bn, int wave, int lane) {
+// SH: also write the transposed fp16 shadow (GemmArgs::Ct).  The new values replace the accumulators; after the last chunk
+// every wave transposes its 128 x 64 sub-tile through its own 16 KiB of the (now free) LDS ring -- 8-byte writes at
+// [column][row], XOR-swizzled 16-byte chunks -- and stores whole 256-byte column segments (16 lanes x 16 bytes; the
+// direct 8-byte stores of a first version cost the kernel 55 %).
+template <bool SH, typename ACC>
+__device__ __forceinline__ void epilogue_sub_f32_dma(ACC (&acc)[4][2], char* smem, float* __restrict__ C, long ldc,
+                                                     float alpha, int bm, int bn, int wave, int lane,
+                                                     half_t* __restrict__ Ct = nullptr, long ldct = 0, float cts = 1.f) {
     const int r = lane & 31, h = lane >> 5;
     const int wr = wave >> 2, wn = (wave & 3) * 64;
     // chunk c: tile rows 16 c .. 16 c + 15 of BOTH wave rows -> 32 rows x 1 KiB; wave w moves rows 4 w .. 4 w + 3 of it
@@ -342,9 +347,38 @@ __device__ __forceinline__ void epilogue_sub_f32_dma(const ACC (&acc)[4][2], cha
 #pragma unroll
             for (int q = 0; q < 2; q++) {
 #pragma unroll
-                for (int e = 0; e < 4; e++) p[(long)e * ldc] = oldv[j][q * 4 + e] - alpha * acc[i][j][8 * hf + q * 4 + e];
+                for (int e = 0; e < 4; e++) {
+                    const float v = oldv[j][q * 4 + e] - alpha * acc[i][j][8 * hf + q * 4 + e];
+                    p[(long)e * ldc] = v;
+                    if (SH) acc[i][j][8 * hf + q * 4 + e] = v;
+                }
                 p += 8 * ldc;
             }
+        }
+    }
+    if (SH) {
+        typedef half_t half4e __attribute__((ext_vector_type(4)));
+        __builtin_amdgcn_s_barrier();                  // every wave has read the last chunk: the ring is free
+        char* tb = smem + wave * 16384;                // [64 columns][128 rows] fp16, 256 B per column
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+#pragma unroll
+            for (int j = 0; j < 2; j++)
+#pragma unroll
+                for (int g4 = 0; g4 < 4; g4++) {
+                    half4e hv;
+#pragma unroll
+                    for (int e = 0; e < 4; e++) hv[e] = (half_t)(cts * acc[i][j][4 * g4 + e]);
+                    const int col = j * 32 + r, chunk = 4 * i + g4;          // rows 32 i + 8 g4 + 4 h + e
+                    *(half4e*)(tb + col * 256 + ((chunk ^ (col & 15)) << 4) + 8 * h) = hv;
+                }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        half_t* ct = Ct + (long)(bn + wn) * ldct + bm + wr * 128;
+#pragma unroll
+        for (int it = 0; it < 16; it++) {
+            const int col = it * 4 + (lane >> 4), ch = lane & 15;
+            const uint4 v = *(const uint4*)(tb + col * 256 + ((ch ^ (col & 15)) << 4));
+            *(uint4*)(ct + (long)col * ldct + 8 * ch) = v;
         }
     }
 }
@@ -437,8 +471,11 @@ __global__ __launch_bounds__(512) void gemm3_f16_kernel(GemmArgs g, int tilesM, 
     const float alpha = g.alpha;
     if (EM == E_SUB_F32) {
         const bool full = DMA_EPI && bm + BM <= g.M && bn + BN <= g.N && bn >= g.col_lo;      // uniform over the workgroup
-        if (full) epilogue_sub_f32_dma(acc, g2_smem, (float*)g.C, g.ldc, alpha, bm, bn, wave, lane);
-        else epilogue_sub_f32<4, 2>(acc, (float*)g.C, g.ldc, g.M, g.N, g.col_lo, alpha, bm + wm, bn + wn, r, h);
+        if (full) {
+            if (g.Ct) epilogue_sub_f32_dma<true>(acc, g2_smem, (float*)g.C, g.ldc, alpha, bm, bn, wave, lane, g.Ct, g.ldct, g.ct_scale);
+            else epilogue_sub_f32_dma<false>(acc, g2_smem, (float*)g.C, g.ldc, alpha, bm, bn, wave, lane);
+        }
+        else epilogue_sub_f32<4, 2>(acc, (float*)g.C, g.ldc, g.M, g.N, g.col_lo, alpha, bm + wm, bn + wn, r, h, g.Ct, g.ldct, g.ct_scale);
         return;
     }
 #pragma unroll
@@ -620,8 +657,11 @@ __global__ __launch_bounds__(512) void gemm6_f16_kernel(GemmArgs g, int tilesM, 
     const float alpha = g.alpha;
     if (EM == E_SUB_F32) {
         const bool full = DMA_EPI && bm + BM <= g.M && bn + BN <= g.N && bn >= g.col_lo;      // uniform over the workgroup
-        if (full) epilogue_sub_f32_dma(acc, g2_smem, (float*)g.C, g.ldc, alpha, bm, bn, wave, lane);
-        else epilogue_sub_f32<4, 2>(acc, (float*)g.C, g.ldc, g.M, g.N, g.col_lo, alpha, bm + wm, bn + wn, r, h);
+        if (full) {
+            if (g.Ct) epilogue_sub_f32_dma<true>(acc, g2_smem, (float*)g.C, g.ldc, alpha, bm, bn, wave, lane, g.Ct, g.ldct, g.ct_scale);
+            else epilogue_sub_f32_dma<false>(acc, g2_smem, (float*)g.C, g.ldc, alpha, bm, bn, wave, lane);
+        }
+        else epilogue_sub_f32<4, 2>(acc, (float*)g.C, g.ldc, g.M, g.N, g.col_lo, alpha, bm + wm, bn + wn, r, h, g.Ct, g.ldct, g.ct_scale);
 #ifdef MPQR_KTRACE
         if (kt_on) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -880,7 +920,7 @@ __global__ __launch_bounds__(512) void gemm7_f16_kernel(GemmArgs g, int tilesM, 
                 pre = has_next;
                 if (!has_next) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); }
             } else {
-                epilogue_sub_f32<4, 2>(acc, (float*)g.C, g.ldc, g.M, g.N, g.col_lo, alpha, bm + wm, bn + wn, r, h);
+                epilogue_sub_f32<4, 2>(acc, (float*)g.C, g.ldc, g.M, g.N, g.col_lo, alpha, bm + wm, bn + wn, r, h, g.Ct, g.ldct, g.ct_scale);
             }
         } else {
 #pragma unroll
@@ -1030,7 +1070,7 @@ __global__ __launch_bounds__(256, 2) void gemm4_f16_kernel(GemmArgs g, int tiles
     __builtin_amdgcn_s_barrier();
     const float alpha = g.alpha;
     if (EM == E_SUB_F32) {
-        epilogue_sub_f32<4, 2>(acc, (float*)g.C, g.ldc, g.M, g.N, g.col_lo, alpha, bm + wm, bn + wn, r, h);
+        epilogue_sub_f32<4, 2>(acc, (float*)g.C, g.ldc, g.M, g.N, g.col_lo, alpha, bm + wm, bn + wn, r, h, g.Ct, g.ldct, g.ct_scale);
         return;
     }
 #pragma unroll

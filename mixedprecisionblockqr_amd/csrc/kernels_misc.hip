@@ -43,6 +43,14 @@ void launch_set_identity(float* Q, long ldq, int rows, int cols, hipStream_t s) 
     hipLaunchKernelGGL(identity_kernel, dim3((n + 255) / 256), dim3(256), 0, s, Q, ldq, n);
 }
 
+__global__ void identity_h16_kernel(half_t* Q, long ldq, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) Q[(long)i * ldq + i] = (half_t)1.f;
+}
+void launch_set_identity_h16(half_t* Q, long ldq, int n, hipStream_t s) {
+    hipLaunchKernelGGL(identity_h16_kernel, dim3((n + 255) / 256), dim3(256), 0, s, Q, ldq, n);
+}
+
 // ------------------------------------------------------------------ boundary layout (Cuda/qr.cu:283-285)
 // internal: R on/above the diagonal, v_k[1:] below it in natural rows, v_k[0] in vdiag[k]
 // boundary: (m+1) x n, reflector k shifted one row down (v_k[j] at row k+1+j)

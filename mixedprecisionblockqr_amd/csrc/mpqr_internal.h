@@ -34,6 +34,10 @@ struct GemmArgs {
     float alpha;
     int nslab_in;        long slab_in_stride;    // A_F32: sum of nslab_in source slabs
     int nsplit;          long slab_out_stride;   // E_STORE_F32: K split over gridDim.z slabs
+    // E_SUB_F32: optional fp16 shadow of the updated values, TRANSPOSED: Ct[n * ldct + m] = fp16(ct_scale * C[m][n]).  The
+    // next X = C^T V then reads fp16 operands that are already k-contiguous (all LDS-DMA) instead of converting and
+    // transposing fp32 in registers.  nullptr: none.
+    half_t* Ct;          long ldct;   float ct_scale;
 };
 void launch_gemm_f16(AMode am, EMode em, const GemmArgs& g, hipStream_t s);
 // 256 x 256 x 64 variant for large shapes (no split-K; operands readable up to the next multiple of 256 rows)
@@ -129,6 +133,7 @@ void launch_t_assemble(float* T, half_t* Th, half_t* Tth, int ldt, int A0,
 void launch_generate(float* A, long lda, int m, int n, uint64_t seed, int nglob, int block, int world, int rank,
                      hipStream_t s);
 void launch_set_identity(float* Q, long ldq, int rows, int cols, hipStream_t s);
+void launch_set_identity_h16(half_t* Q, long ldq, int n, hipStream_t s);   // diagonal of a zeroed fp16 matrix
 void launch_pack_factor(const float* A, long lda, const float* vdiag, float* out, int m, int n, hipStream_t s);
 void launch_unpack_factor(const float* in, int m, int n, int c0, int c1, float* A, long lda, float* vdiag,
                           half_t* Vh, long ldvh, half_t* Vt, long ldvt, hipStream_t s);

@@ -1,0 +1,26 @@
+#!/usr/bin/env python3
+"""Q-formation phase of the last factorisation in a rocprofv3 kernel trace: per-kernel time after the last panel solve.
+usage: trace_qphase.py <kernel_trace.csv>"""
+import csv, sys, re, collections
+rows = list(csv.DictReader(open(sys.argv[1])))
+for r in rows:
+    r['s'] = int(r['Start_Timestamp']); r['e'] = int(r['End_Timestamp'])
+rows.sort(key=lambda r: r['s'])
+gen = [i for i, r in enumerate(rows) if 'generate_kernel' in r['Kernel_Name']]
+lo = gen[-1]
+hi = next((i for i in range(lo, len(rows)) if 'lower_norm' in rows[i]['Kernel_Name'] or 'strip_r' in rows[i]['Kernel_Name']), len(rows))
+run = rows[lo + 1:hi]
+last = max(i for i, r in enumerate(run) if 'gh_solve' in r['Kernel_Name'] or 'leaf_wg' in r['Kernel_Name'])
+ident = next(i for i in range(last, len(run)) if 'identity' in run[i]['Kernel_Name'])
+q = run[ident:]
+t0, t1 = q[0]['s'], max(r['e'] for r in q)
+print("Q phase %.2f ms, %d dispatches" % ((t1 - t0) / 1e6, len(q)))
+d = collections.Counter(); c = collections.Counter()
+for r in q:
+    n = re.sub(r'^void ', '', r['Kernel_Name']).replace('mpqr::', '')[:60]
+    d[n] += r['e'] - r['s']; c[n] += 1
+for k, v in d.most_common():
+    print("  %-60s %4d %8.3f ms" % (k, c[k], v / 1e6))
+for r in q:
+    if (r['e'] - r['s']) > 2e5:
+        print("   %+9.1f us %8.1f us  %s" % ((r['s'] - t0) / 1e3, (r['e'] - r['s']) / 1e3, re.sub(r'^void ', '', r['Kernel_Name'])[:50]))
