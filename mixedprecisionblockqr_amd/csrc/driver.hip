@@ -408,6 +408,7 @@ void apply_node(mpqr_handle_t h, const Node& nd, float* C, long ldc, int clo, in
     g2.C = Yt; g2.ldc = Kr;
     g2.M = M1; g2.N = Kr; g2.K = Kr;
     g2.in_scale = 1.f; g2.alpha = 1.f; g2.nsplit = 1;
+    g2.tri = trans_t ? 2 : 1;                              // T is upper triangular: T^T rows end at the diagonal, T rows start there
     gemm_dispatch(A_F32, E_STORE_H16, g2, st);
     // op3: C2 -= (1/in_scale) V Yt^T
     GemmArgs g3{};

@@ -68,7 +68,9 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm2_f16_kernel(GemmArgs g, int
     const int ktiles_all = g.K / BK;
     const int z = blockIdx.y;
     const int per = (ktiles_all + g.nsplit - 1) / g.nsplit;
-    const int kt0 = z * per, kt1 = min(ktiles_all, kt0 + per);
+    int kt0 = z * per, kt1 = min(ktiles_all, kt0 + per);
+    if (g.tri == 1) kt0 = max(kt0, bn / BK);                           // Bt[n][k] = 0 for k < n
+    else if (g.tri == 2) kt1 = min(kt1, (bn + BN + BK - 1) / BK);      // Bt[n][k] = 0 for k > n
     char* const As0 = g2_smem;
     char* const Bs0 = g2_smem + A_BYTES;
 

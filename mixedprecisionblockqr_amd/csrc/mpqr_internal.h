@@ -38,6 +38,9 @@ struct GemmArgs {
     // next X = C^T V then reads fp16 operands that are already k-contiguous (all LDS-DMA) instead of converting and
     // transposing fp32 in registers.  nullptr: none.
     half_t* Ct;          long ldct;   float ct_scale;
+    // Bt is triangular (the compact-WY T as the second operand): 1: Bt[n][k] = 0 for k < n, 2: Bt[n][k] = 0 for k > n.
+    // The 256-wide kernel skips the K tiles that are entirely zero for its output columns; other kernels ignore it.
+    int tri;
 };
 void launch_gemm_f16(AMode am, EMode em, const GemmArgs& g, hipStream_t s);
 // 256 x 256 x 64 variant for large shapes (no split-K; operands readable up to the next multiple of 256 rows)
