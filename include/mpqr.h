@@ -85,7 +85,11 @@ typedef struct mpqr_timings {
     float ms_chain_wait;  /* ms_factor - ms_panel: the chain stream waiting for far updates of its columns      */
     int   n_passes;       /* block-loop passes of the last mpqr_factor (> 1: flagged leaves were redone)          */
     int   n_robust_leaves;/* tall leaves factored on the column-by-column (robust) kernels in the last pass       */
-    int   reserved[5];
+    float ms_q_tn;        /* Q formation: sum over its  X = Q2^T V   launches                                      */
+    float ms_q_nn;        /* Q formation: sum over its  Q2 -= V Y^T  launches (same kernel as the far update)        */
+    int   n_q_launches;   /* number of Q-formation applies (blocks or pairs of blocks)                               */
+    float tflop_q;        /* flops (in units of 1e12) executed by the tn launches of Q formation (= by the nn ones)  */
+    int   reserved[1];
 } mpqr_timings;
 
 typedef struct mpqr_handle_s* mpqr_handle_t;

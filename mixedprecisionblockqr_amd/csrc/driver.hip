@@ -135,6 +135,7 @@ struct mpqr_handle_s {
     // in the background, T_LR = -T_L (V_L^T V_R) T_R, on the far-update stream with its own scratch)
     std::vector<int> qpair;       // per top index t: id of the pair node whose RIGHT child is top t, else -1
     bool pairs_ready = false;     // the pair T's of the current factorisation are (enqueued to be) complete
+    size_t q_first = (size_t)-1;  // first far_ev slot used by Q formation (its applies are timed like the far updates)
     float* S2 = nullptr; size_t s2_elems = 0; float* tmp1b = nullptr; float* tmp2b = nullptr;
     // transposed fp16 shadow of Q, Qt[column][row], kept up to date by the epilogue of Q -= V Y^T: the next X = Q2^T V
     // reads it with LDS-DMA like any fp16 operand (the fp32 operand path converts and transposes in registers: 620 TFLOP/s)
@@ -899,15 +900,17 @@ int form_q(mpqr_handle_t h) {
         launch_set_identity_h16(h->Qt, h->ldqt, h->m, h->s0);
         h->shadow = h->Qt; h->ldshadow = h->ldqt;
     }
+    const bool rec = h->world == 1 && h->factored;        // timed like the far updates (mpqr_get_timings: ms_q_*)
+    h->q_first = rec ? h->far_used : (size_t)-1;
     for (int t = (int)h->tops.size() - 1; t >= 0; t--) {
         if (h->pairs_ready && t < (int)h->qpair.size() && h->qpair[t] >= 0) {      // two blocks at once, K = 2 outer_block
             const Node& pr = h->nodes[h->qpair[t]];
-            apply_node(h, pr, h->dQ, h->ldq, pr.c0, h->m, false, 1.f, false);
+            apply_node(h, pr, h->dQ, h->ldq, pr.c0, h->m, false, 1.f, rec);
             t--;
             continue;
         }
         const Node& nd = h->nodes[h->tops[t]];
-        apply_node(h, nd, h->dQ, h->ldq, nd.c0, h->m, false, 1.f, false);
+        apply_node(h, nd, h->dQ, h->ldq, nd.c0, h->m, false, 1.f, rec);
     }
     h->shadow = nullptr;
     h->q_formed = true;
@@ -1166,7 +1169,7 @@ static int plan_common(mpqr_handle_t h, int m, int n, int r, const mpqr_opts* op
     HIPCHK(h, hipMemsetAsync(h->rbTh, 0, (h->rb_elems + (size_t)256 * 256) * sizeof(half_t), h->s0));
     HIPCHK(h, hipMemsetAsync(h->rbTth, 0, (h->rb_elems + (size_t)256 * 256) * sizeof(half_t), h->s0));
     // event pools (nothing is created inside the timed region): 2 recorded far updates per block, 2 chain events per block
-    for (size_t i = 0; i < 8 * h->tops.size() + 8; i++) { hipEvent_t e; HIPCHK(h, hipEventCreate(&e)); h->far_ev.push_back(e); }
+    for (size_t i = 0; i < 12 * h->tops.size() + 8; i++) { hipEvent_t e; HIPCHK(h, hipEventCreate(&e)); h->far_ev.push_back(e); }   // + 1 per block for Q formation
     for (size_t i = 0; i < 2 * h->tops.size() + 2; i++) { hipEvent_t e; HIPCHK(h, hipEventCreate(&e)); h->chain_ev.push_back(e); }
     if ((rc = dalloc(h, &h->dA0, (size_t)h->m_pad * h->lda + 1024))) return rc;
     if ((rc = dalloc(h, &h->tmp1, h->tmp_elems))) return rc;
@@ -1245,7 +1248,7 @@ int mpqr_generate_matrix(mpqr_handle_t h, uint64_t seed) {
 static int run_block_loop(mpqr_handle_t h, std::vector<int>& flags) {
     int rc;
     h->far_used = 0; h->far_flops.clear(); h->chain_used = 0; h->v8_node = -1;
-    h->pairs_ready = false;
+    h->pairs_ready = false; h->q_first = (size_t)-1;
     HIPCHK(h, hipEventRecord(h->ev[0], h->s0));
     HIPCHK(h, hipMemcpyAsync(h->dA, h->dA0, (size_t)h->m_pad * h->lda * sizeof(float), hipMemcpyDeviceToDevice, h->s0));
     HIPCHK(h, hipMemsetAsync(h->dflag, 0, (size_t)h->nflag * sizeof(int), h->s0));
@@ -1405,15 +1408,22 @@ int mpqr_get_timings(mpqr_handle_t h, mpqr_timings* t) {
     t->ms_total = t->ms_factor + t->ms_form_q;
     double f = 0;
     float tr = 0;
+    double fq = 0;
     for (size_t i = 0; i + 3 < h->far_used; i += 4) {
         float a = 0, b = 0, x = 0;
         HIPCHK(h, hipEventElapsedTime(&a, h->far_ev[i], h->far_ev[i + 1]));
         HIPCHK(h, hipEventElapsedTime(&b, h->far_ev[i + 2], h->far_ev[i + 3]));
         HIPCHK(h, hipEventElapsedTime(&x, h->far_ev[i], h->far_ev[i + 3]));     // whole far update (op1..op3)
+        if (i >= h->q_first) {                                                    // Q formation's applies
+            t->ms_q_tn += a; t->ms_q_nn += b; t->n_q_launches++;
+            fq += h->far_flops[i / 4];
+            continue;
+        }
         t->ms_far_tn += a; t->ms_far_nn += b; tr += x;
         f += h->far_flops[i / 4];
+        t->n_far_launches++;
     }
-    t->n_far_launches = (int)(h->far_used / 4);
+    t->tflop_q = (float)(fq * 1e-12);
     t->flops_far_tn = f; t->flops_far_nn = f;
     t->ms_trailing = tr;
     // the panel chain timed on its own stream: leaves, in-block updates, T merges of every top-level block (with
