@@ -141,6 +141,7 @@ struct mpqr_handle_s {
     // reads it with LDS-DMA like any fp16 operand (the fp32 operand path converts and transposes in registers: 620 TFLOP/s)
     half_t* Qt = nullptr; long ldqt = 0;
     half_t* shadow = nullptr; long ldshadow = 0;      // set by form_q around its applies (apply_node, lane 0)
+    bool shadow_write = true;                         // false: this apply still reads the shadow but does not update it
     // 1-D block-cyclic column distribution (world == 1: everything local)
     int world = 1, rank = 0;
     int nloc = 0;        // local columns of A
@@ -287,7 +288,8 @@ int choose_split(int M, int N, int K, size_t cap_elems, long slab) {
         const long t256 = (long)((M + 255) / 256) * ((N + 255) / 256);
         if (t256 < 192) ns = (int)std::min<long>(ktiles / 16, (256 + t256 - 1) / t256);
     }
-    ns = std::min(ns, 64);   // slabs are summed by launch_slab_reduce right after the producer
+    static const int cap = []() { const char* e = getenv("MPQR_SPLIT_CAP"); return e ? std::max(1, atoi(e)) : 32; }();   // tuning hook (64: 49.5, 32: 48.6, 16: 49.0 ms at 16384^2)
+    ns = std::min(ns, cap);  // slabs are summed by launch_slab_reduce right after the producer
     while (ns > 1 && (size_t)ns * (size_t)slab > cap_elems) ns--;
     return std::max(ns, 1);
 }
@@ -375,6 +377,9 @@ void apply_node(mpqr_handle_t h, const Node& nd, float* C, long ldc, int clo, in
     // MPQR_PREC_FP8: the two large GEMMs of a FAR update take e4m3 operands (kernels_fp8.hip); shapes the fp8 kernel does
     // not cover (K not a multiple of 128) stay on the fp16 path
     const bool f8 = far && h->V8n && (Kr % 128) == 0 && (Kw % 128) == 0 && (rlo % 16) == 0 && nd.a0 == nd.c0;
+    // one leaf (128 reflectors) onto a few columns: slab sum and Y = X T' in one small kernel (leaf_xt_kernel)
+    static const int fuse_env = []() { const char* e = getenv("MPQR_FUSE_XT"); return e ? atoi(e) : 1; }();
+    const bool fuse_xt = fuse_env && !f8 && !far && lane == 0 && Kr == 128 && M1 <= 4096 && !(h->shadow && lane == 0);
     if (f8) {
         if (h->v8_node != nd.id) {                          // the block's reflectors, once per block: 2^8 V in both layouts
             launch_quant_h16_fp8(h->Vh + (long)rlo * h->ldvh + nd.a0, h->ldvh, h->V8n, h->ld8k, Kw, Kr, 256.f, st);
@@ -397,7 +402,7 @@ void apply_node(mpqr_handle_t h, const Node& nd, float* C, long ldc, int clo, in
         gemm_dispatch(A_H16, E_STORE_F32, g1, st1);
     } else
     gemm_dispatch(A_F32T, E_STORE_F32, g1, st1);
-    if (g1.nsplit > 1) launch_slab_reduce(Xt, g1.nsplit, slab, slab, Xt, st1);
+    if (g1.nsplit > 1 && !fuse_xt) launch_slab_reduce(Xt, g1.nsplit, slab, slab, Xt, st1);
     }
     if (st1 != st) { (void)hipEventRecord(h->ev_x, st1); (void)hipStreamWaitEvent(st, h->ev_x, 0); }
     if (record) (void)hipEventRecord(e1, st);
@@ -410,6 +415,8 @@ void apply_node(mpqr_handle_t h, const Node& nd, float* C, long ldc, int clo, in
     g2.M = M1; g2.N = Kr; g2.K = Kr;
     g2.in_scale = 1.f; g2.alpha = 1.f; g2.nsplit = 1;
     g2.tri = trans_t ? 2 : 1;                              // T is upper triangular: T^T rows end at the diagonal, T rows start there
+    if (fuse_xt) launch_leaf_xt(Xt, g1.nsplit, slab, M1, g2.Bt, g2.ldb, g2.tri, Yt, Kr, st);
+    else
     gemm_dispatch(A_F32, E_STORE_H16, g2, st);
     // op3: C2 -= (1/in_scale) V Yt^T
     GemmArgs g3{};
@@ -418,7 +425,7 @@ void apply_node(mpqr_handle_t h, const Node& nd, float* C, long ldc, int clo, in
     g3.C = C + (long)rlo * ldc + clo_al; g3.ldc = ldc;
     g3.M = Kw; g3.N = M1; g3.K = Kr;
     g3.col_lo = clo - clo_al; g3.alpha = 1.0f / in_scale; g3.in_scale = 1.f; g3.nsplit = 1;
-    if (h->shadow && lane == 0 && !far) { g3.Ct = h->shadow + (long)clo_al * h->ldshadow + rlo; g3.ldct = h->ldshadow; g3.ct_scale = in_scale; }
+    if (h->shadow && h->shadow_write && lane == 0 && !far) { g3.Ct = h->shadow + (long)clo_al * h->ldshadow + rlo; g3.ldct = h->ldshadow; g3.ct_scale = in_scale; }
     if (record) (void)hipEventRecord(e2, st);
     if (f8) {
         launch_quant_h16_fp8(Yt, Kr, h->Y8, h->ld8k, M1, Kr, 0.25f, st);                       // 2^-2 Y
@@ -905,11 +912,13 @@ int form_q(mpqr_handle_t h) {
     for (int t = (int)h->tops.size() - 1; t >= 0; t--) {
         if (h->pairs_ready && t < (int)h->qpair.size() && h->qpair[t] >= 0) {      // two blocks at once, K = 2 outer_block
             const Node& pr = h->nodes[h->qpair[t]];
+            h->shadow_write = t - 1 > 0;                    // nobody reads the shadow after the last apply
             apply_node(h, pr, h->dQ, h->ldq, pr.c0, h->m, false, 1.f, rec);
             t--;
             continue;
         }
         const Node& nd = h->nodes[h->tops[t]];
+        h->shadow_write = t > 0;
         apply_node(h, nd, h->dQ, h->ldq, nd.c0, h->m, false, 1.f, rec);
     }
     h->shadow = nullptr;

@@ -114,6 +114,9 @@ struct GlueArgs {
 };
 void launch_gh_glue(const GlueArgs& g, hipStream_t s);
 void launch_gh_save_top(const float* A, long lda, int c0, float* Bs, hipStream_t s);
+// Y[M1 x 128] (fp16, ld ldy) = fp16(sum of nslab X slabs, M1 x 128 fp32) * T', Bt[n][k] = T'[k][n] (fp16, ld ldb), tri as GemmArgs::tri
+void launch_leaf_xt(const float* X, int nslab, long slab_stride, int M1, const half_t* Bt, long ldb, int tri, half_t* Y, long ldy,
+                    hipStream_t s);
 void launch_gh_reduce_f32(const float* Sp, int nslab, float* S, hipStream_t s);
 
 // T of a leaf (<= 128 reflectors) from its Gram slabs S (row stride lds_, aligned range starting at a0)
