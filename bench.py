@@ -194,7 +194,7 @@ def main():
         "error": {"backward_error": mt["backward_error"], "q_error_fro": mt["q_error_fro"],
                   "q_error_max_signed": mt["q_error_max_signed"]},
         "breakdown_ms": {k: tm[k] for k in ("ms_total", "ms_factor", "ms_form_q", "ms_trailing", "ms_panel", "ms_chain_wait",
-                                            "ms_far_tn", "ms_far_nn", "ms_q_tn", "ms_q_nn", "n_passes", "n_robust_leaves")},
+                                            "ms_far_tn", "ms_far_nn", "ms_q_tn", "ms_q_nn", "ms_host_enqueue", "n_passes", "n_robust_leaves")},
         "gflops_with_q_flops": (fl["geqrf"] + fl["form_q"]) / dt / 1e9,
         "gflops_reference_formula": (4.0 * m * m * n - m * n * n + n ** 3 / 3.0) / dt / 1e9,
         "roofline": roof,

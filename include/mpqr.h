@@ -89,7 +89,7 @@ typedef struct mpqr_timings {
     float ms_q_nn;        /* Q formation: sum over its  Q2 -= V Y^T  launches (same kernel as the far update)        */
     int   n_q_launches;   /* number of Q-formation applies (blocks or pairs of blocks)                               */
     float tflop_q;        /* flops (in units of 1e12) executed by the tn launches of Q formation (= by the nn ones)  */
-    int   reserved[1];
+    float ms_host_enqueue;/* host time to enqueue the factorisation's launches (before its one synchronisation)    */
 } mpqr_timings;
 
 typedef struct mpqr_handle_s* mpqr_handle_t;

@@ -22,6 +22,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <chrono>
 #include <mutex>
 
 #include <rocprofiler-sdk-roctx/roctx.h>
@@ -135,6 +136,7 @@ struct mpqr_handle_s {
     // in the background, T_LR = -T_L (V_L^T V_R) T_R, on the far-update stream with its own scratch)
     std::vector<int> qpair;       // per top index t: id of the pair node whose RIGHT child is top t, else -1
     bool pairs_ready = false;     // the pair T's of the current factorisation are (enqueued to be) complete
+    float host_enqueue_ms = 0.f;  // host time the last block loop took to enqueue (everything before its one synchronisation)
     size_t q_first = (size_t)-1;  // first far_ev slot used by Q formation (its applies are timed like the far updates)
     float* S2 = nullptr; size_t s2_elems = 0; float* tmp1b = nullptr; float* tmp2b = nullptr;
     // transposed fp16 shadow of Q, Qt[column][row], kept up to date by the epilogue of Q -= V Y^T: the next X = Q2^T V
@@ -142,6 +144,9 @@ struct mpqr_handle_s {
     half_t* Qt = nullptr; long ldqt = 0;
     half_t* shadow = nullptr; long ldshadow = 0;      // set by form_q around its applies (apply_node, lane 0)
     bool shadow_write = true;                         // false: this apply still reads the shadow but does not update it
+    // the same for the trailing matrix: At[column][row] = fp16(a_scale * A), written by every far update's epilogue, read by
+    // the NEXT far update's X = A2^T V (far update 0 reads the fp32 matrix: nothing has written the shadow yet)
+    half_t* At = nullptr; long ldat = 0; bool at_read = false;
     // 1-D block-cyclic column distribution (world == 1: everything local)
     int world = 1, rank = 0;
     int nloc = 0;        // local columns of A
@@ -196,9 +201,9 @@ void free_plan(mpqr_handle_t h) {
     void* ptrs[] = {h->dA, h->dA0, h->dQ, h->Vh, h->Vt, h->vdiag, h->Xt, h->Yt, h->S, h->P, h->tmp1, h->tmp2,
                     h->Tf, h->Th, h->Tth, h->dstage, h->Gp, h->Gs, h->Cv, h->dflag, h->Vf, h->Yf, h->Xt1, h->Yt1, h->Sp,
                     h->rbTf, h->rbTh, h->rbTth, h->Sleaf, h->Wk, h->V8n, h->V8t, h->A8t, h->Y8,
-                    h->GsN[0], h->GsN[1], h->Gp2, h->G2, h->Bsv[0], h->Bsv[1], h->Cv2[1], h->Yg, h->S2, h->tmp1b, h->tmp2b, h->Qt};
+                    h->GsN[0], h->GsN[1], h->Gp2, h->G2, h->Bsv[0], h->Bsv[1], h->Cv2[1], h->Yg, h->S2, h->tmp1b, h->tmp2b, h->Qt, h->At};
     for (void* p : ptrs) if (p) (void)hipFree(p);
-    h->S2 = h->tmp1b = h->tmp2b = nullptr; h->s2_elems = 0; h->Qt = nullptr; h->shadow = nullptr; h->qpair.clear(); h->pairs_ready = false;
+    h->S2 = h->tmp1b = h->tmp2b = nullptr; h->s2_elems = 0; h->Qt = nullptr; h->shadow = nullptr; h->At = nullptr; h->at_read = false; h->qpair.clear(); h->pairs_ready = false;
     h->GsN[0] = h->GsN[1] = nullptr; h->Gp2 = h->G2 = nullptr; h->Bsv[0] = h->Bsv[1] = nullptr; h->Cv2[0] = h->Cv2[1] = nullptr; h->Yg = nullptr;
     h->dA = h->dA0 = h->dQ = nullptr; h->Vh = h->Vt = nullptr; h->vdiag = nullptr; h->Xt = nullptr; h->Yt = nullptr;
     h->S = nullptr; h->P = nullptr; h->tmp1 = h->tmp2 = nullptr; h->Tf = nullptr; h->Th = h->Tth = nullptr;
@@ -377,6 +382,7 @@ void apply_node(mpqr_handle_t h, const Node& nd, float* C, long ldc, int clo, in
     // MPQR_PREC_FP8: the two large GEMMs of a FAR update take e4m3 operands (kernels_fp8.hip); shapes the fp8 kernel does
     // not cover (K not a multiple of 128) stay on the fp16 path
     const bool f8 = far && h->V8n && (Kr % 128) == 0 && (Kw % 128) == 0 && (rlo % 16) == 0 && nd.a0 == nd.c0;
+    const bool a_shadow = h->At && lane == 1 && far && !f8 && C == h->dA;   // fp16 shadow of the trailing matrix (far updates)
     // one leaf (128 reflectors) onto a few columns: slab sum and Y = X T' in one small kernel (leaf_xt_kernel)
     static const int fuse_env = []() { const char* e = getenv("MPQR_FUSE_XT"); return e ? atoi(e) : 1; }();
     const bool fuse_xt = fuse_env && !f8 && !far && lane == 0 && Kr == 128 && M1 <= 4096 && !(h->shadow && lane == 0);
@@ -396,6 +402,11 @@ void apply_node(mpqr_handle_t h, const Node& nd, float* C, long ldc, int clo, in
         launch_gemm_fp8(E_STORE_F32, f1, st);
         if (f1.nsplit > 1) launch_slab_reduce(Xt, f1.nsplit, slab, slab, Xt, st);
     } else {
+    if (a_shadow && h->at_read) {                          // trailing matrix: the previous far update left fp16(s A2)^T
+        g1.A = h->At + (long)clo_al * h->ldat + rlo; g1.lda = h->ldat;
+        g1.in_scale = 1.f;
+        gemm_dispatch(A_H16, E_STORE_F32, g1, st1);
+    } else
     if (h->shadow && lane == 0 && !far) {                  // fp16 operand, already [column][row]: C2^T = shadow rows
         g1.A = h->shadow + (long)clo_al * h->ldshadow + rlo; g1.lda = h->ldshadow;
         g1.in_scale = 1.f;
@@ -425,6 +436,7 @@ void apply_node(mpqr_handle_t h, const Node& nd, float* C, long ldc, int clo, in
     g3.C = C + (long)rlo * ldc + clo_al; g3.ldc = ldc;
     g3.M = Kw; g3.N = M1; g3.K = Kr;
     g3.col_lo = clo - clo_al; g3.alpha = 1.0f / in_scale; g3.in_scale = 1.f; g3.nsplit = 1;
+    if (a_shadow) { g3.Ct = h->At + (long)clo_al * h->ldat + rlo; g3.ldct = h->ldat; g3.ct_scale = in_scale; }
     if (h->shadow && h->shadow_write && lane == 0 && !far) { g3.Ct = h->shadow + (long)clo_al * h->ldshadow + rlo; g3.ldct = h->ldshadow; g3.ct_scale = in_scale; }
     if (record) (void)hipEventRecord(e2, st);
     if (f8) {
@@ -674,7 +686,8 @@ int factor_block_flat(mpqr_handle_t h, int top, const std::vector<int>& leaves) 
         prev = lf; prev_o = o;
         if (!tq) { t_column_block(prev, prev_o); prev_o = -1; }          // single stream: nothing to defer
     }
-    if (prev_o >= 0) {                                     // the last leaf's column block needs its T (chain stream)
+    static const int dbg_skip_last = []() { const char* e = getenv("MPQR_DBG_SKIP_LAST_TCOL"); return e ? atoi(e) : 0; }();   // timing experiment
+    if (prev_o >= 0 && !dbg_skip_last) {                   // the last leaf's column block needs its T (chain stream)
         if (tq) t_stream_follows_chain(h);
         t_column_block(prev, prev_o);
     }
@@ -1190,6 +1203,17 @@ static int plan_common(mpqr_handle_t h, int m, int n, int r, const mpqr_opts* op
             if ((rc = dalloc(h, &h->Qt, (size_t)(h->m_pad + 256) * h->ldqt))) return rc;
         }
     }
+    {
+        // opt-in (MPQR_ASHADOW=1): measured at 16384^2 the far X = A2^T V gains less (6.3 -> 5.2 ms; N = 1024 gives only four
+        // column tiles per row panel) than the shadow stores cost the far A2 -= V Y^T (4.6 -> 5.4 ms), and the chain beside
+        // them does not get faster: 49.4 vs 49.3 ms on the same box.  Q formation (K = 2048) is where the shadow pays.
+        static const int as_on = []() { const char* e = getenv("MPQR_ASHADOW"); return e ? atoi(e) : 0; }();
+        if (as_on && world == 1 && o.lookahead && o.precision == MPQR_PREC_FP16) {
+            h->ldat = h->m_pad;
+            if ((rc = dalloc(h, &h->At, (size_t)(h->n_pad + 256) * h->ldat))) return rc;
+            HIPCHK(h, hipMemsetAsync(h->At, 0, (size_t)(h->n_pad + 256) * h->ldat * sizeof(half_t), h->s0));
+        }
+    }
     if (q_ldt) {                                          // scratch of the pair merges (they run on the far-update stream)
         h->s2_elems = (size_t)16 * max_ldt * max_ldt;
         if ((rc = dalloc(h, &h->S2, h->s2_elems)) || (rc = dalloc(h, &h->tmp1b, h->tmp_elems)) || (rc = dalloc(h, &h->tmp2b, h->tmp_elems))) return rc;
@@ -1258,6 +1282,7 @@ static int run_block_loop(mpqr_handle_t h, std::vector<int>& flags) {
     int rc;
     h->far_used = 0; h->far_flops.clear(); h->chain_used = 0; h->v8_node = -1;
     h->pairs_ready = false; h->q_first = (size_t)-1;
+    const auto host_t0 = std::chrono::steady_clock::now();  // host time to enqueue the block loop (ms_host_enqueue)
     HIPCHK(h, hipEventRecord(h->ev[0], h->s0));
     HIPCHK(h, hipMemcpyAsync(h->dA, h->dA0, (size_t)h->m_pad * h->lda * sizeof(float), hipMemcpyDeviceToDevice, h->s0));
     HIPCHK(h, hipMemsetAsync(h->dflag, 0, (size_t)h->nflag * sizeof(int), h->s0));
@@ -1313,7 +1338,8 @@ static int run_block_loop(mpqr_handle_t h, std::vector<int>& flags) {
             h->la_next_robust = h->robust || (fl < (int)h->leaf_robust.size() && h->leaf_robust[fl]) ||
                                 !flat_block_ok(h, h->tops[t + 1], lvtmp);
         }
-        const bool timed = h->chain_used + 2 <= h->chain_ev.size();
+        static const int no_chain_ev = []() { const char* e = getenv("MPQR_NO_CHAIN_EV"); return e ? atoi(e) : 0; }();   // experiment
+        const bool timed = !no_chain_ev && h->chain_used + 2 <= h->chain_ev.size();
         if (timed) HIPCHK(h, hipEventRecord(h->chain_ev[h->chain_used], h->s0));
         rc = factor_node(h, h->tops[t], true);
         h->ext_c1 = 0;
@@ -1329,6 +1355,7 @@ static int run_block_loop(mpqr_handle_t h, std::vector<int>& flags) {
             if (h->opts.form_q && h->qpair[t] >= 0 && h->S2) merge_pair(h, h->qpair[t], h->s0);
             continue;
         }
+        h->at_read = t >= 1;                                // far update t-1 wrote the shadow of every column this one reads
         HIPCHK(h, hipEventRecord(h->ev_node[t], h->node_done_stream ? h->node_done_stream : h->s0));
         HIPCHK(h, hipStreamWaitEvent(h->s1, h->ev_node[t], 0));
         if (t + 1 < nt) {
@@ -1363,6 +1390,7 @@ static int run_block_loop(mpqr_handle_t h, std::vector<int>& flags) {
     }
     HIPCHK(h, hipEventRecord(h->ev[1], h->s0));
     flags.assign(h->nodes.size(), 0);
+    h->host_enqueue_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - host_t0).count();
     HIPCHK(h, hipMemcpyAsync(flags.data(), h->dflag, flags.size() * sizeof(int), hipMemcpyDeviceToHost, h->s0));
     HIPCHK(h, hipStreamSynchronize(h->s0));
     HIPCHK(h, hipGetLastError());
@@ -1433,6 +1461,7 @@ int mpqr_get_timings(mpqr_handle_t h, mpqr_timings* t) {
         t->n_far_launches++;
     }
     t->tflop_q = (float)(fq * 1e-12);
+    t->ms_host_enqueue = h->host_enqueue_ms;
     t->flops_far_tn = f; t->flops_far_nn = f;
     t->ms_trailing = tr;
     // the panel chain timed on its own stream: leaves, in-block updates, T merges of every top-level block (with

@@ -1498,6 +1498,8 @@ void launch_gh_gram(const LeafArgs& a, double* Gp, double* G, hipStream_t s) {
 }
 void launch_gh_solve(const LeafArgs& a, const double* G, float* Cv, int* flag, hipStream_t s) {
     gh_set_attrs();
+    static const int dbg_skip = []() { const char* e = getenv("MPQR_DBG_NOSOLVE"); return e ? atoi(e) : 0; }();
+    if (dbg_skip) return;                                  // timing experiment only (results are garbage): is the chain host-bound?
     // gh_solve2 (blocked Householder reconstruction) is correct but measured SLOWER than the step-by-step kernel at w = 128
     // (162 vs 111 us: ~500 cycles per column for the fp64 in-wave Cholesky, ~300 for the LU, plus two triangular inverses
     // -- in-kernel stamps, make EXTRA=-DMPQR_KTRACE): opt-in only

@@ -665,6 +665,9 @@ OPT_IN = [
     {"MPQR_FLAT": "0"},                            # tree schedule inside a block
     {"MPQR_TSTREAM": "0"},                         # compact-WY T on the chain stream
     {"MPQR_EXT_LOOKAHEAD": "0"},                   # block boundary: first leaf of the next block through the far update
+    {"MPQR_ASHADOW": "1"},                         # fp16 shadow of the trailing matrix for the far updates' X = A2^T V
+    {"MPQR_QSHADOW": "0", "MPQR_QPAIR": "0"},      # Q formation block by block from the fp32 Q (round-1 form)
+    {"MPQR_FUSE_XT": "0", "MPQR_SPLIT_CAP": "64"}, # in-block update with a separate slab sum and small GEMM
 ]
 
 
