@@ -14,11 +14,14 @@ cd $root
 bash tools/pmc_sq.sh c4 > $out/${tag}_c4_sq_stalls.txt 2>&1 && echo "sq ok"
 bash tools/pmc_l2.sh $tag > $out/${tag}_c4_l2_hit.txt 2>&1 && echo "l2 ok"
 cp $(find $out/ks -name "c4_kernel_stats.csv" | head -1) $out/${tag}_c4_kernel_stats.csv
-python3 tools/trace_gaps.py $(find $out/ks -name "c4_kernel_trace.csv" | head -1) > $out/${tag}_c4_stream_gaps.txt
+KT=$(find $out/ks -name "c4_kernel_trace.csv" | head -1)
+python3 tools/trace_gaps.py $KT > $out/${tag}_c4_stream_gaps.txt
+python3 tools/trace_leaf.py $KT 60 61 64 > $out/${tag}_c4_leaf_timeline.txt      # steady-state panels and one beside a far update
+python3 tools/trace_qphase.py $KT > $out/${tag}_c4_q_phase.txt
 F=$(find $out/fetch -name "c4_counter_collection.csv" | head -1); W=$(find $out/write -name "c4_counter_collection.csv" | head -1)
 grep -E "Kernel_Name|gemm6_f16|gemm2_f16" $F > $out/${tag}_c4_pmc_FETCH_SIZE_gemm.csv
 grep -E "Kernel_Name|gemm6_f16|gemm2_f16" $W > $out/${tag}_c4_pmc_WRITE_SIZE_gemm.csv
-python3 tools/pmc_traffic.py $F $W "gemm6_f16_kernel<2, 1>" $out/${tag}_traffic_far_nn.json > /dev/null
+python3 tools/pmc_traffic.py $F $W "gemm6_f16_kernel<2, 1>" $out/${tag}_traffic_far_nn.json big > /dev/null   # the launches bench.py prices
 python3 tools/pmc_traffic.py $F $W "gemm2_f16_kernel<1, 0" $out/${tag}_traffic_far_tn.json > /dev/null
 cp $out/${tag}_traffic_far_nn.json profiles/${tag}_traffic_far_nn.json        # bench.py reads roofline.traffic from here
 python3 bench.py > $out/${tag}_c4_bench.json 2> $out/bench_c4.err && echo "bench c4 ok"
