@@ -365,7 +365,21 @@ __global__ __launch_bounds__(256) void gh_reduce_kernel(const double* __restrict
     const int i = e >> 7, j = e & 127;
     const bool act = (i >> 4) <= (j >> 4);                // 16 x 16 tiles below the diagonal are not produced: mirrored below
     double s = 0;
-    if (act) for (int q = wave; q < nwg; q += 4) s += Gp[(long)q * (GW * GW) + e];
+    if (act) {                                            // 16 loads in flight per lane, summed in slab order
+        int q = wave;
+        for (; q + 60 < nwg; q += 64) {
+            double v[16];
+#pragma unroll
+            for (int u = 0; u < 16; u++) v[u] = Gp[(long)(q + 4 * u) * (GW * GW) + e];
+#pragma unroll
+            for (int u = 0; u < 16; u++) s += v[u];
+        }
+        double v[16];
+#pragma unroll
+        for (int u = 0; u < 16; u++) v[u] = (q + 4 * u < nwg) ? Gp[(long)(q + 4 * u) * (GW * GW) + e] : 0.0;
+#pragma unroll
+        for (int u = 0; u < 16; u++) s += v[u];
+    }
     part[wave][lane] = s;
     __syncthreads();
     if (wave == 0 && act) {
@@ -1180,13 +1194,24 @@ __global__ __launch_bounds__(256) void gh_reduce_f32_kernel(const float* __restr
     const bool act = ((e >> 7) >> 5) <= ((e & 127) >> 5);   // the partials hold the 10 upper 32 x 32 tiles only; T reads j >= i
     float s = 0.f;
     if (act) {
-        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;       // four independent chains: more loads in flight per lane
+        // 16 loads in flight per lane (the kernel is pure memory latency, and that latency grows several times while a far
+        // update streams beside the chain), summed in a fixed order: four interleaved chains as before
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
         int q = wave;
-        for (; q + 12 < nslab; q += 16) {
-            s0 += Sp[(long)q * (GW * GW) + e]; s1 += Sp[(long)(q + 4) * (GW * GW) + e];
-            s2 += Sp[(long)(q + 8) * (GW * GW) + e]; s3 += Sp[(long)(q + 12) * (GW * GW) + e];
+        for (; q + 60 < nslab; q += 64) {
+            float v[16];
+#pragma unroll
+            for (int u = 0; u < 16; u++) v[u] = Sp[(long)(q + 4 * u) * (GW * GW) + e];
+#pragma unroll
+            for (int u = 0; u < 16; u += 4) { s0 += v[u]; s1 += v[u + 1]; s2 += v[u + 2]; s3 += v[u + 3]; }
         }
-        for (; q < nslab; q += 4) s0 += Sp[(long)q * (GW * GW) + e];
+        {
+            float v[16];
+#pragma unroll
+            for (int u = 0; u < 16; u++) v[u] = (q + 4 * u < nslab) ? Sp[(long)(q + 4 * u) * (GW * GW) + e] : 0.f;
+#pragma unroll
+            for (int u = 0; u < 16; u += 4) { s0 += v[u]; s1 += v[u + 1]; s2 += v[u + 2]; s3 += v[u + 3]; }
+        }
         s = (s0 + s1) + (s2 + s3);
     }
     part[wave][lane] = s;
