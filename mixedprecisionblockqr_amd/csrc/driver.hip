@@ -147,6 +147,7 @@ struct mpqr_handle_s {
     // the same for the trailing matrix: At[column][row] = fp16(a_scale * A), written by every far update's epilogue, read by
     // the NEXT far update's X = A2^T V (far update 0 reads the fp32 matrix: nothing has written the shadow yet)
     half_t* At = nullptr; long ldat = 0; bool at_read = false;
+    half_t* Xh = nullptr;          // fp16 X = Q2^T V of a Q-formation apply (the next GEMM rounds X to fp16 anyway)
     // 1-D block-cyclic column distribution (world == 1: everything local)
     int world = 1, rank = 0;
     int nloc = 0;        // local columns of A
@@ -201,9 +202,9 @@ void free_plan(mpqr_handle_t h) {
     void* ptrs[] = {h->dA, h->dA0, h->dQ, h->Vh, h->Vt, h->vdiag, h->Xt, h->Yt, h->S, h->P, h->tmp1, h->tmp2,
                     h->Tf, h->Th, h->Tth, h->dstage, h->Gp, h->Gs, h->Cv, h->dflag, h->Vf, h->Yf, h->Xt1, h->Yt1, h->Sp,
                     h->rbTf, h->rbTh, h->rbTth, h->Sleaf, h->Wk, h->V8n, h->V8t, h->A8t, h->Y8,
-                    h->GsN[0], h->GsN[1], h->Gp2, h->G2, h->Bsv[0], h->Bsv[1], h->Cv2[1], h->Yg, h->S2, h->tmp1b, h->tmp2b, h->Qt, h->At};
+                    h->GsN[0], h->GsN[1], h->Gp2, h->G2, h->Bsv[0], h->Bsv[1], h->Cv2[1], h->Yg, h->S2, h->tmp1b, h->tmp2b, h->Qt, h->At, h->Xh};
     for (void* p : ptrs) if (p) (void)hipFree(p);
-    h->S2 = h->tmp1b = h->tmp2b = nullptr; h->s2_elems = 0; h->Qt = nullptr; h->shadow = nullptr; h->At = nullptr; h->at_read = false; h->qpair.clear(); h->pairs_ready = false;
+    h->S2 = h->tmp1b = h->tmp2b = nullptr; h->s2_elems = 0; h->Qt = nullptr; h->shadow = nullptr; h->At = nullptr; h->at_read = false; h->Xh = nullptr; h->qpair.clear(); h->pairs_ready = false;
     h->GsN[0] = h->GsN[1] = nullptr; h->Gp2 = h->G2 = nullptr; h->Bsv[0] = h->Bsv[1] = nullptr; h->Cv2[0] = h->Cv2[1] = nullptr; h->Yg = nullptr;
     h->dA = h->dA0 = h->dQ = nullptr; h->Vh = h->Vt = nullptr; h->vdiag = nullptr; h->Xt = nullptr; h->Yt = nullptr;
     h->S = nullptr; h->P = nullptr; h->tmp1 = h->tmp2 = nullptr; h->Tf = nullptr; h->Th = h->Tth = nullptr;
@@ -383,6 +384,8 @@ void apply_node(mpqr_handle_t h, const Node& nd, float* C, long ldc, int clo, in
     // not cover (K not a multiple of 128) stay on the fp16 path
     const bool f8 = far && h->V8n && (Kr % 128) == 0 && (Kw % 128) == 0 && (rlo % 16) == 0 && nd.a0 == nd.c0;
     const bool a_shadow = h->At && lane == 1 && far && !f8 && C == h->dA;   // fp16 shadow of the trailing matrix (far updates)
+    static const int x16_env = []() { const char* e = getenv("MPQR_X16"); return e ? atoi(e) : 1; }();
+    const bool x16 = x16_env && h->shadow && h->Xh && lane == 0 && !far && g1.nsplit == 1 && M1 >= 256 && Kr >= 256;
     // one leaf (128 reflectors) onto a few columns: slab sum and Y = X T' in one small kernel (leaf_xt_kernel)
     static const int fuse_env = []() { const char* e = getenv("MPQR_FUSE_XT"); return e ? atoi(e) : 1; }();
     const bool fuse_xt = fuse_env && !f8 && !far && lane == 0 && Kr == 128 && M1 <= 4096 && !(h->shadow && lane == 0);
@@ -410,7 +413,8 @@ void apply_node(mpqr_handle_t h, const Node& nd, float* C, long ldc, int clo, in
     if (h->shadow && lane == 0 && !far) {                  // fp16 operand, already [column][row]: C2^T = shadow rows
         g1.A = h->shadow + (long)clo_al * h->ldshadow + rlo; g1.lda = h->ldshadow;
         g1.in_scale = 1.f;
-        gemm_dispatch(A_H16, E_STORE_F32, g1, st1);
+        if (x16) { g1.C = h->Xh; gemm_dispatch(A_H16, E_STORE_H16, g1, st1); }   // X leaves in fp16: Y = X T' reads it as is
+        else gemm_dispatch(A_H16, E_STORE_F32, g1, st1);
     } else
     gemm_dispatch(A_F32T, E_STORE_F32, g1, st1);
     if (g1.nsplit > 1 && !fuse_xt) launch_slab_reduce(Xt, g1.nsplit, slab, slab, Xt, st1);
@@ -427,6 +431,7 @@ void apply_node(mpqr_handle_t h, const Node& nd, float* C, long ldc, int clo, in
     g2.in_scale = 1.f; g2.alpha = 1.f; g2.nsplit = 1;
     g2.tri = trans_t ? 2 : 1;                              // T is upper triangular: T^T rows end at the diagonal, T rows start there
     if (fuse_xt) launch_leaf_xt(Xt, g1.nsplit, slab, M1, g2.Bt, g2.ldb, g2.tri, Yt, Kr, st);
+    else if (x16) { g2.A = h->Xh; gemm_dispatch(A_H16, E_STORE_H16, g2, st); }
     else
     gemm_dispatch(A_F32, E_STORE_H16, g2, st);
     // op3: C2 -= (1/in_scale) V Yt^T
@@ -1201,6 +1206,8 @@ static int plan_common(mpqr_handle_t h, int m, int n, int r, const mpqr_opts* op
         if (sh_on && world == 1 && o.form_q && o.precision != MPQR_PREC_FP32) {
             h->ldqt = h->m_pad;
             if ((rc = dalloc(h, &h->Qt, (size_t)(h->m_pad + 256) * h->ldqt))) return rc;
+            if ((rc = dalloc(h, &h->Xh, h->yt_elems + (size_t)256 * x_ldt))) return rc;
+            HIPCHK(h, hipMemsetAsync(h->Xh, 0, (h->yt_elems + (size_t)256 * x_ldt) * sizeof(half_t), h->s0));
         }
     }
     {

@@ -215,6 +215,7 @@ void launch_gemm_f16(AMode am, EMode em, const GemmArgs& g, hipStream_t s) {
     MPQR_CASE(A_F32, E_STORE_H16)
     MPQR_CASE(A_H16, E_SUB_F32)
     MPQR_CASE(A_H16, E_STORE_F32)
+    MPQR_CASE(A_H16, E_STORE_H16)
 #undef MPQR_CASE
 }
 

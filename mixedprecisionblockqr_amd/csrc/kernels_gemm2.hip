@@ -529,8 +529,12 @@ __global__ __launch_bounds__(512) void gemm6_f16_kernel(GemmArgs g, int tilesM, 
     const int tn = (grp % groupsN) * 8 + within % 8;
     if (tm >= tilesM || tn >= tilesN) return;
     const int bm = tm * BM, bn = tn * BN;
-    const int ktiles = g.K / BK;
-    const half_t* const A = (const half_t*)g.A;
+    // triangular second operand (GemmArgs::tri): only the K tiles where Bt can be non-zero for this tile's columns
+    const int kt_lo = g.tri == 1 ? bn / BK : 0;
+    const int kt_hi = g.tri == 2 ? min(g.K / BK, (bn + BN + BK - 1) / BK) : g.K / BK;
+    const int ktiles = kt_hi - kt_lo;
+    const half_t* const A = (const half_t*)g.A + (long)kt_lo * BK;
+    const half_t* const Bt = g.Bt + (long)kt_lo * BK;
     const int wr = wave >> 2, wc = wave & 3;
     const int wm = wr * 128, wn = wc * 64;
 
@@ -553,7 +557,7 @@ __global__ __launch_bounds__(512) void gemm6_f16_kernel(GemmArgs g, int tilesM, 
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(A + (long)(bm + rr) * g.lda + k + c * 8),
                                                  (__attribute__((address_space(3))) void*)(buf + row0 * ROWB), 16, 0, 0);
             else
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g.Bt + (long)(bn + rr) * g.ldb + k + c * 8),
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(Bt + (long)(bn + rr) * g.ldb + k + c * 8),
                                                  (__attribute__((address_space(3))) void*)(buf + A_BYTES + row0 * ROWB), 16, 0, 0);
         }
     };
@@ -683,7 +687,10 @@ __global__ __launch_bounds__(512) void gemm6_f16_kernel(GemmArgs g, int tilesM, 
 #pragma unroll
             for (int e = 0; e < 16; e++) {
                 const int m = bm + wm + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-                if (m < g.M && n < g.N) ((float*)g.C)[(long)m * g.ldc + n] = alpha * acc[i][j][e];
+                if (m < g.M && n < g.N) {
+                    if (EM == E_STORE_H16) ((half_t*)g.C)[(long)m * g.ldc + n] = (half_t)(alpha * acc[i][j][e]);
+                    else ((float*)g.C)[(long)m * g.ldc + n] = alpha * acc[i][j][e];
+                }
             }
         }
 }
@@ -1130,6 +1137,7 @@ bool launch_gemm2_f16(AMode am, EMode em, const GemmArgs& g, hipStream_t s, int 
         if (use6 && (g.K % 64) == 0) {
             if (em == E_SUB_F32) { if (dma_epi) launch6<E_SUB_F32, 1>(g, s); else launch6<E_SUB_F32, 0>(g, s); return true; }
             if (em == E_STORE_F32) { launch6<E_STORE_F32, 0>(g, s); return true; }
+            if (em == E_STORE_H16) { launch6<E_STORE_H16, 0>(g, s); return true; }
         }
         if (em == E_SUB_F32 && dma_epi) { launch3<E_SUB_F32, 1>(g, s); return true; }
         if (em == E_SUB_F32) { launch3<E_SUB_F32>(g, s); return true; }
