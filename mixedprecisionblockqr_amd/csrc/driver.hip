@@ -23,6 +23,7 @@
 
 #include <algorithm>
 #include <chrono>
+#include <functional>
 #include <mutex>
 
 #include <rocprofiler-sdk-roctx/roctx.h>
@@ -137,6 +138,12 @@ struct mpqr_handle_s {
     std::vector<int> qpair;       // per top index t: id of the pair node whose RIGHT child is top t, else -1
     bool pairs_ready = false;     // the pair T's of the current factorisation are (enqueued to be) complete
     float host_enqueue_ms = 0.f;  // host time the last block loop took to enqueue (everything before its one synchronisation)
+    // tall matrices (m >= 3 n): Q = I - (V T) V^T in ONE product over all reflectors instead of the backward accumulation
+    // (2 m^2 n + m n^2 flops instead of ~4 m^2 n, and no read-modify-write): needs the T of ALL reflectors, merged up a
+    // binary tree over the top-level blocks in the background (same merge as the pairs)
+    int qroot = -1;                               // node id of the root of that tree (-1: backward accumulation)
+    std::vector<std::vector<int>> qmerge_after;   // per top index t: tree nodes that can be merged once block t is factored
+    half_t* Wh = nullptr;                         // W = V T, fp16 [row][reflector]
     size_t q_first = (size_t)-1;  // first far_ev slot used by Q formation (its applies are timed like the far updates)
     float* S2 = nullptr; size_t s2_elems = 0; float* tmp1b = nullptr; float* tmp2b = nullptr;
     // transposed fp16 shadow of Q, Qt[column][row], kept up to date by the epilogue of Q -= V Y^T: the next X = Q2^T V
@@ -202,9 +209,9 @@ void free_plan(mpqr_handle_t h) {
     void* ptrs[] = {h->dA, h->dA0, h->dQ, h->Vh, h->Vt, h->vdiag, h->Xt, h->Yt, h->S, h->P, h->tmp1, h->tmp2,
                     h->Tf, h->Th, h->Tth, h->dstage, h->Gp, h->Gs, h->Cv, h->dflag, h->Vf, h->Yf, h->Xt1, h->Yt1, h->Sp,
                     h->rbTf, h->rbTh, h->rbTth, h->Sleaf, h->Wk, h->V8n, h->V8t, h->A8t, h->Y8,
-                    h->GsN[0], h->GsN[1], h->Gp2, h->G2, h->Bsv[0], h->Bsv[1], h->Cv2[1], h->Yg, h->S2, h->tmp1b, h->tmp2b, h->Qt, h->At, h->Xh};
+                    h->GsN[0], h->GsN[1], h->Gp2, h->G2, h->Bsv[0], h->Bsv[1], h->Cv2[1], h->Yg, h->S2, h->tmp1b, h->tmp2b, h->Qt, h->At, h->Xh, h->Wh};
     for (void* p : ptrs) if (p) (void)hipFree(p);
-    h->S2 = h->tmp1b = h->tmp2b = nullptr; h->s2_elems = 0; h->Qt = nullptr; h->shadow = nullptr; h->At = nullptr; h->at_read = false; h->Xh = nullptr; h->qpair.clear(); h->pairs_ready = false;
+    h->S2 = h->tmp1b = h->tmp2b = nullptr; h->s2_elems = 0; h->Qt = nullptr; h->shadow = nullptr; h->At = nullptr; h->at_read = false; h->Xh = nullptr; h->Wh = nullptr; h->qroot = -1; h->qmerge_after.clear(); h->qpair.clear(); h->pairs_ready = false;
     h->GsN[0] = h->GsN[1] = nullptr; h->Gp2 = h->G2 = nullptr; h->Bsv[0] = h->Bsv[1] = nullptr; h->Cv2[0] = h->Cv2[1] = nullptr; h->Yg = nullptr;
     h->dA = h->dA0 = h->dQ = nullptr; h->Vh = h->Vt = nullptr; h->vdiag = nullptr; h->Xt = nullptr; h->Yt = nullptr;
     h->S = nullptr; h->P = nullptr; h->tmp1 = h->tmp2 = nullptr; h->Tf = nullptr; h->Th = h->Tth = nullptr;
@@ -916,8 +923,40 @@ static void merge_pair(mpqr_handle_t h, int pid, hipStream_t st) {
     if (h->tq_on && nd.id < (int)h->ev_T.size()) (void)hipEventRecord(h->ev_T[nd.id], st);
 }
 
+// Q = I - (V T) V^T over all reflectors at once (tall matrices; the tree of merged T's is complete: pairs_ready)
+static int form_q_one_shot(mpqr_handle_t h) {
+    const Node rt = h->nodes[h->qroot];
+    const int Kr = rt.ldt, rlo = rdown(rt.c0, 64);
+    if (h->tq_on && rt.id < (int)h->ev_T.size()) (void)hipStreamWaitEvent(h->s0, h->ev_T[rt.id], 0);
+    hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr, e3 = nullptr;
+    const bool rec = h->factored && h->far_used + 4 <= h->far_ev.size();
+    if (rec) {
+        e0 = h->far_ev[h->far_used]; e1 = h->far_ev[h->far_used + 1]; e2 = h->far_ev[h->far_used + 2]; e3 = h->far_ev[h->far_used + 3];
+        h->q_first = h->far_used; h->far_used += 4;
+        h->far_flops.push_back(2.0 * (double)h->m * (double)h->m * Kr);
+    }
+    GemmArgs w{};                                         // W[m x Kr] = V T   (T upper triangular: k <= n)
+    w.A = h->Vh + (long)rlo * h->ldvh + rt.a0; w.lda = h->ldvh;
+    w.Bt = h->Tth + rt.toff; w.ldb = rt.tld;
+    w.C = h->Wh; w.ldc = h->n_pad;
+    w.M = h->m_pad - rlo; w.N = Kr; w.K = Kr; w.alpha = 1.f; w.in_scale = 1.f; w.nsplit = 1; w.tri = 2;
+    if (rec) (void)hipEventRecord(e0, h->s0);
+    gemm_dispatch(A_H16, E_STORE_H16, w, h->s0);
+    if (rec) { (void)hipEventRecord(e1, h->s0); (void)hipEventRecord(e2, h->s0); }
+    GemmArgs q{};                                         // Q[m x m] = I - W V^T   (V[j][k] = 0 for k > j)
+    q.A = h->Wh; q.lda = h->n_pad;
+    q.Bt = h->Vh + (long)rlo * h->ldvh + rt.a0; q.ldb = h->ldvh;
+    q.C = h->dQ + (long)rlo * h->ldq + rlo; q.ldc = h->ldq;
+    q.M = h->m - rlo; q.N = h->m - rlo; q.K = Kr; q.alpha = 1.f; q.in_scale = 1.f; q.nsplit = 1; q.tri = 2; q.eye_minus = 1;
+    gemm_dispatch(A_H16, E_STORE_F32, q, h->s0);
+    if (rec) (void)hipEventRecord(e3, h->s0);
+    h->q_formed = true;
+    return MPQR_OK;
+}
+
 int form_q(mpqr_handle_t h) {
     Range rg("mpqr:form_q");
+    if (h->qroot >= 0 && h->pairs_ready && h->world == 1) return form_q_one_shot(h);
     HIPCHK(h, hipMemsetAsync(h->dQ, 0, (size_t)h->m_pad * h->ldq * sizeof(float), h->s0));
     launch_set_identity(h->dQ, h->ldq, h->m, h->m, h->s0);
     if (h->Qt && h->world == 1) {
@@ -1108,8 +1147,37 @@ static int plan_common(mpqr_handle_t h, int m, int n, int r, const mpqr_opts* op
     // pair nodes for Q formation (single GPU, fp16 / fp8 operands, both blocks 64-aligned): appended after the tree
     h->qpair.assign(h->tops.size(), -1);
     int q_ldt = 0;
+    size_t q_half = 0;                                    // largest L.ldt x R.ldt of a tree merge (scratch of merge_pair)
+    h->qroot = -1;
     {
         static const int qp_on = []() { const char* e = getenv("MPQR_QPAIR"); return e ? atoi(e) : 1; }();
+        static const int one_on = []() { const char* e = getenv("MPQR_QONESHOT"); return e ? atoi(e) : 1; }();
+        bool aligned = h->tops.size() >= 2;
+        for (size_t p = 0; p + 1 < h->tops.size() && aligned; p++) {
+            const Node& L = h->nodes[h->tops[p]]; const Node& R = h->nodes[h->tops[p + 1]];
+            aligned = L.a0 == L.c0 && R.a0 == R.c0 && L.a1 == R.a0;
+        }
+        h->qmerge_after.assign(h->tops.size(), std::vector<int>());
+        const char* g6 = getenv("MPQR_GEMM6");             // the I - W V^T epilogue lives in the ping-pong kernel only
+        if (one_on && aligned && world == 1 && o.form_q && o.precision != MPQR_PREC_FP32 && (long)m >= 3L * n && m >= 2048 &&
+            !(g6 && atoi(g6) == 0)) {
+            // binary tree over the tops [a, b): split in the middle; a node is merged when its last block is done
+            std::function<int(int, int)> build = [&](int a, int b) -> int {
+                if (b - a == 1) return h->tops[a];
+                const int mid = a + (b - a + 1) / 2;
+                const int l = build(a, mid), r2 = build(mid, b);
+                const Node L = h->nodes[l], R = h->nodes[r2];
+                Node pr;
+                pr.c0 = L.c0; pr.c1 = R.c1; pr.a0 = L.a0; pr.a1 = R.a1; pr.ldt = pr.a1 - pr.a0;
+                pr.left = l; pr.right = r2; pr.toff = toff; pr.tld = pr.ldt; pr.id = (int)h->nodes.size();
+                toff += (size_t)pr.ldt * pr.ldt;
+                q_half = std::max(q_half, (size_t)L.ldt * (size_t)R.ldt);
+                h->nodes.push_back(pr);
+                h->qmerge_after[b - 1].push_back(pr.id);
+                return pr.id;
+            };
+            h->qroot = build(0, (int)h->tops.size());
+        } else
         if (qp_on && world == 1 && o.form_q && o.precision != MPQR_PREC_FP32) {
             for (size_t p = 0; p + 1 < h->tops.size(); p += 2) {
                 const Node L = h->nodes[h->tops[p]], R = h->nodes[h->tops[p + 1]];
@@ -1127,6 +1195,7 @@ static int plan_common(mpqr_handle_t h, int m, int n, int r, const mpqr_opts* op
     h->t_elems = toff;
     const size_t maxdim = (size_t)std::max(h->m_pad, h->n_pad);
     const int x_ldt = std::max(max_ldt, q_ldt);
+    const int t_ldt = h->qroot >= 0 ? std::max(x_ldt, h->nodes[h->qroot].ldt) : x_ldt;   // slack rows of the T arenas
     h->xt_elems = std::max(maxdim * (size_t)x_ldt, (size_t)64 * max_ldt * max_ldt);
     h->yt_elems = maxdim * (size_t)x_ldt;
     h->s_elems = (size_t)64 * max_ldt * max_ldt;
@@ -1203,7 +1272,7 @@ static int plan_common(mpqr_handle_t h, int m, int n, int r, const mpqr_opts* op
     if ((rc = dalloc(h, &h->tmp2, h->tmp_elems))) return rc;
     {
         static const int sh_on = []() { const char* e = getenv("MPQR_QSHADOW"); return e ? atoi(e) : 1; }();
-        if (sh_on && world == 1 && o.form_q && o.precision != MPQR_PREC_FP32) {
+        if (sh_on && world == 1 && o.form_q && o.precision != MPQR_PREC_FP32 && h->qroot < 0) {
             h->ldqt = h->m_pad;
             if ((rc = dalloc(h, &h->Qt, (size_t)(h->m_pad + 256) * h->ldqt))) return rc;
             if ((rc = dalloc(h, &h->Xh, h->yt_elems + (size_t)256 * x_ldt))) return rc;
@@ -1221,16 +1290,21 @@ static int plan_common(mpqr_handle_t h, int m, int n, int r, const mpqr_opts* op
             HIPCHK(h, hipMemsetAsync(h->At, 0, (size_t)(h->n_pad + 256) * h->ldat * sizeof(half_t), h->s0));
         }
     }
-    if (q_ldt) {                                          // scratch of the pair merges (they run on the far-update stream)
-        h->s2_elems = (size_t)16 * max_ldt * max_ldt;
-        if ((rc = dalloc(h, &h->S2, h->s2_elems)) || (rc = dalloc(h, &h->tmp1b, h->tmp_elems)) || (rc = dalloc(h, &h->tmp2b, h->tmp_elems))) return rc;
+    if (q_ldt || h->qroot >= 0) {                         // scratch of the pair / tree merges (they run on the far-update stream)
+        const size_t half = std::max(q_half, (size_t)max_ldt * max_ldt);
+        h->s2_elems = std::max((size_t)16 * max_ldt * max_ldt, 2 * half);
+        if ((rc = dalloc(h, &h->S2, h->s2_elems)) || (rc = dalloc(h, &h->tmp1b, half)) || (rc = dalloc(h, &h->tmp2b, half))) return rc;
+    }
+    if (h->qroot >= 0) {
+        if ((rc = dalloc(h, &h->Wh, (size_t)(h->m_pad + 256) * h->n_pad))) return rc;
+        HIPCHK(h, hipMemsetAsync(h->Wh, 0, (size_t)(h->m_pad + 256) * h->n_pad * sizeof(half_t), h->s0));
     }
     if ((rc = dalloc(h, &h->Tf, h->t_elems))) return rc;
     HIPCHK(h, hipMemsetAsync(h->Tf, 0, h->t_elems * sizeof(float), h->s0));
-    if ((rc = dalloc(h, &h->Th, h->t_elems + (size_t)256 * x_ldt))) return rc;
-    if ((rc = dalloc(h, &h->Tth, h->t_elems + (size_t)256 * x_ldt))) return rc;
-    HIPCHK(h, hipMemsetAsync(h->Th, 0, (h->t_elems + (size_t)256 * x_ldt) * sizeof(half_t), h->s0));
-    HIPCHK(h, hipMemsetAsync(h->Tth, 0, (h->t_elems + (size_t)256 * x_ldt) * sizeof(half_t), h->s0));
+    if ((rc = dalloc(h, &h->Th, h->t_elems + (size_t)256 * t_ldt))) return rc;
+    if ((rc = dalloc(h, &h->Tth, h->t_elems + (size_t)256 * t_ldt))) return rc;
+    HIPCHK(h, hipMemsetAsync(h->Th, 0, (h->t_elems + (size_t)256 * t_ldt) * sizeof(half_t), h->s0));
+    HIPCHK(h, hipMemsetAsync(h->Tth, 0, (h->t_elems + (size_t)256 * t_ldt) * sizeof(half_t), h->s0));
     HIPCHK(h, hipMemsetAsync(h->dA0, 0, (size_t)h->m_pad * h->lda * sizeof(float), h->s0));
     HIPCHK(h, hipMemsetAsync(h->dflag, 0, (size_t)h->nflag * sizeof(int), h->s0));
     HIPCHK(h, hipMemsetAsync(h->dA, 0, (size_t)h->m_pad * h->lda * sizeof(float), h->s0));
@@ -1360,6 +1434,7 @@ static int run_block_loop(mpqr_handle_t h, std::vector<int>& flags) {
         if (!la) {
             apply_node(h, nd, h->dA, h->lda, nd.c1, h->n, true, h->a_scale, true, 0, true);
             if (h->opts.form_q && h->qpair[t] >= 0 && h->S2) merge_pair(h, h->qpair[t], h->s0);
+            if (h->opts.form_q && h->qroot >= 0) for (int id : h->qmerge_after[t]) merge_pair(h, id, h->s0);
             continue;
         }
         h->at_read = t >= 1;                                // far update t-1 wrote the shadow of every column this one reads
@@ -1379,8 +1454,9 @@ static int run_block_loop(mpqr_handle_t h, std::vector<int>& flags) {
         }
         // Q formation works on pairs of blocks: the pair's T behind this block's far update, beside the next panels
         if (h->opts.form_q && h->qpair[t] >= 0 && h->S2) merge_pair(h, h->qpair[t], h->s1);
+        if (h->opts.form_q && h->qroot >= 0) for (int id : h->qmerge_after[t]) merge_pair(h, id, h->s1);   // ... or up the whole tree
     }
-    h->pairs_ready = h->opts.form_q && h->S2 != nullptr;
+    h->pairs_ready = h->opts.form_q && h->S2 != nullptr;     // (pairs or the whole tree)
     if (h->la_dirty) {                                      // the tall stream's work, once
         HIPCHK(h, hipEventRecord(h->ev_cold, h->sA));
         HIPCHK(h, hipStreamWaitEvent(h->s0, h->ev_cold, 0));

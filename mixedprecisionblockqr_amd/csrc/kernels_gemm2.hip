@@ -689,6 +689,7 @@ __global__ __launch_bounds__(512) void gemm6_f16_kernel(GemmArgs g, int tilesM, 
                 const int m = bm + wm + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
                 if (m < g.M && n < g.N) {
                     if (EM == E_STORE_H16) ((half_t*)g.C)[(long)m * g.ldc + n] = (half_t)(alpha * acc[i][j][e]);
+                    else if (g.eye_minus) ((float*)g.C)[(long)m * g.ldc + n] = (m == n ? 1.f : 0.f) - alpha * acc[i][j][e];
                     else ((float*)g.C)[(long)m * g.ldc + n] = alpha * acc[i][j][e];
                 }
             }

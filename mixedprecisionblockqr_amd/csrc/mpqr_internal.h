@@ -41,6 +41,7 @@ struct GemmArgs {
     // Bt is triangular (the compact-WY T as the second operand): 1: Bt[n][k] = 0 for k < n, 2: Bt[n][k] = 0 for k > n.
     // The 256-wide kernel skips the K tiles that are entirely zero for its output columns; other kernels ignore it.
     int tri;
+    int eye_minus;       // E_STORE_F32 (256-wide kernel): store (m == n ? 1 : 0) - alpha*acc  (Q = I - W V^T in one product)
 };
 void launch_gemm_f16(AMode am, EMode em, const GemmArgs& g, hipStream_t s);
 // 256 x 256 x 64 variant for large shapes (no split-K; operands readable up to the next multiple of 256 rows)

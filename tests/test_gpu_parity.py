@@ -668,7 +668,29 @@ OPT_IN = [
     {"MPQR_ASHADOW": "1"},                         # fp16 shadow of the trailing matrix for the far updates' X = A2^T V
     {"MPQR_QSHADOW": "0", "MPQR_QPAIR": "0"},      # Q formation block by block from the fp32 Q (round-1 form)
     {"MPQR_FUSE_XT": "0", "MPQR_SPLIT_CAP": "64"}, # in-block update with a separate slab sum and small GEMM
+    {"MPQR_X16": "0"},                             # Q formation with an fp32 X between its two GEMMs
 ]
+
+
+@pytest.mark.gpu
+def test_tall_matrix_one_shot_q_formation():
+    """m >= 3 n: Q = I - (V T) V^T in one product over all reflectors (T merged up a tree over the top-level blocks) must
+    give the same factorisation as the backward accumulation (MPQR_QONESHOT=0), within the fp16-level tolerances."""
+    import json, os, subprocess, sys
+    child = os.path.join(os.path.dirname(os.path.abspath(__file__)), "optin_child.py")
+    outs = []
+    for extra in ({}, {"MPQR_QONESHOT": "0"}):
+        env = dict(os.environ); env.update(extra)
+        p = subprocess.run([sys.executable, child, "6400", "2000", "128"], env=env, capture_output=True, text=True, timeout=600)
+        assert p.returncode == 0, (extra, p.stderr[-2000:])
+        outs.append(json.loads(p.stdout.strip().splitlines()[-1]))
+    for o in outs:
+        assert o["backward_error"] <= 1e-3, o["backward_error"]                       # north_star tolerance
+        assert o["orth_max"] <= 2e-3, o["orth_max"]
+    a, b = np.array(outs[0]["absdiag"]), np.array(outs[1]["absdiag"])
+    assert np.array_equal(a, b)                       # R does not depend on how Q is formed
+    assert abs(outs[0]["backward_error"] - outs[1]["backward_error"]) <= 2e-4
+
 
 
 @pytest.mark.gpu
