@@ -139,10 +139,10 @@ struct mpqr_handle_s {
     bool pairs_ready = false;     // the pair T's of the current factorisation are (enqueued to be) complete
     float host_enqueue_ms = 0.f;  // host time the last block loop took to enqueue (everything before its one synchronisation)
     // tall matrices (m >= 3 n): Q = I - (V T) V^T in ONE product over all reflectors instead of the backward accumulation
-    // (2 m^2 n + m n^2 flops instead of ~4 m^2 n, and no read-modify-write): needs the T of ALL reflectors, merged up a
-    // binary tree over the top-level blocks in the background (same merge as the pairs)
-    int qroot = -1;                               // node id of the root of that tree (-1: backward accumulation)
-    std::vector<std::vector<int>> qmerge_after;   // per top index t: tree nodes that can be merged once block t is factored
+    // (2 m^2 n + m n^2 flops instead of ~4 m^2 n, and no read-modify-write): needs the T of ALL reflectors, built block
+    // column by block column in the background (merge_prefix)
+    int qroot = -1;                               // node id of the full-width T (-1: backward accumulation)
+    std::vector<std::vector<int>> qmerge_after;   // per top index t: prefix nodes that can be completed once block t is factored
     half_t* Wh = nullptr;                         // W = V T, fp16 [row][reflector]
     size_t q_first = (size_t)-1;  // first far_ev slot used by Q formation (its applies are timed like the far updates)
     float* S2 = nullptr; size_t s2_elems = 0; float* tmp1b = nullptr; float* tmp2b = nullptr;
@@ -923,6 +923,39 @@ static void merge_pair(mpqr_handle_t h, int pid, hipStream_t st) {
     if (h->tq_on && nd.id < (int)h->ev_T.size()) (void)hipEventRecord(h->ev_T[nd.id], st);
 }
 
+// prefix step: T of blocks 0..k from T of blocks 0..k-1 (in place, leading block of the same arena) and T of block k
+static void merge_prefix(mpqr_handle_t h, int pid, hipStream_t st) {
+    Range rg("mpqr:wy_T_prefix");
+    const Node nd = h->nodes[pid];
+    const Node L = h->nodes[nd.left], R = h->nodes[nd.right];
+    const int ld = nd.tld, o = L.ldt, w = R.ldt;
+    float* const Tr = h->Tf + nd.toff; half_t* const Thr = h->Th + nd.toff; half_t* const Tthr = h->Tth + nd.toff;
+    if (h->tq_on) {
+        (void)hipStreamWaitEvent(st, h->ev_T[L.id], 0);
+        (void)hipStreamWaitEvent(st, h->ev_T[R.id], 0);
+    }
+    if (L.tld != ld) {                                    // first step: block 0's own T becomes the leading block
+        (void)hipMemcpy2DAsync(Tr, (size_t)ld * 4, h->Tf + L.toff, (size_t)L.tld * 4, (size_t)o * 4, o, hipMemcpyDeviceToDevice, st);
+        launch_t_colblock_h16(Tr, Thr, Tthr, ld, o, 0, o, st);
+    }
+    int nslab; long slab;
+    gram(h, L, R, &nslab, &slab, st, h->S2, h->s2_elems);  // S = V_P^T V_k  (o x w)
+    SgemmArgs s1{};                                        // tmp1 = S T_k
+    s1.A = h->S2; s1.lda = w; s1.transA = 0; s1.nslab_a = nslab; s1.slab_a = slab;
+    s1.B = h->Tf + R.toff; s1.ldb = R.tld; s1.transB = 0;
+    s1.C = h->tmp1b; s1.ldc = w; s1.M = o; s1.N = w; s1.K = w; s1.alpha = 1.f; s1.beta = 0.f; s1.upperB = 1;
+    launch_sgemm(s1, st);
+    SgemmArgs s2{};                                        // T[0:o, o:o+w] = -T_P tmp1
+    s2.A = Tr; s2.lda = ld; s2.transA = 0; s2.nslab_a = 1;
+    s2.B = h->tmp1b; s2.ldb = w; s2.transB = 0;
+    s2.C = Tr + o; s2.ldc = ld; s2.M = o; s2.N = w; s2.K = o; s2.alpha = -1.f; s2.beta = 0.f; s2.upperA = 1;
+    launch_sgemm(s2, st);
+    (void)hipMemcpy2DAsync(Tr + (size_t)o * ld + o, (size_t)ld * 4, h->Tf + R.toff, (size_t)R.tld * 4, (size_t)w * 4, w,
+                           hipMemcpyDeviceToDevice, st);  // diagonal block = T_k
+    launch_t_colblock_h16(Tr, Thr, Tthr, ld, o + w, o, w, st);   // fp16 T and T^T of the new column block (diagonal block included)
+    if (h->tq_on && nd.id < (int)h->ev_T.size()) (void)hipEventRecord(h->ev_T[nd.id], st);
+}
+
 // Q = I - (V T) V^T over all reflectors at once (tall matrices; the tree of merged T's is complete: pairs_ready)
 static int form_q_one_shot(mpqr_handle_t h) {
     const Node rt = h->nodes[h->qroot];
@@ -1161,22 +1194,27 @@ static int plan_common(mpqr_handle_t h, int m, int n, int r, const mpqr_opts* op
         const char* g6 = getenv("MPQR_GEMM6");             // the I - W V^T epilogue lives in the ping-pong kernel only
         if (one_on && aligned && world == 1 && o.form_q && o.precision != MPQR_PREC_FP32 && (long)m >= 3L * n && m >= 2048 &&
             !(g6 && atoi(g6) == 0)) {
-            // binary tree over the tops [a, b): split in the middle; a node is merged when its last block is done
-            std::function<int(int, int)> build = [&](int a, int b) -> int {
-                if (b - a == 1) return h->tops[a];
-                const int mid = a + (b - a + 1) / 2;
-                const int l = build(a, mid), r2 = build(mid, b);
-                const Node L = h->nodes[l], R = h->nodes[r2];
+            // prefix nodes P_k = blocks 0..k, all in ONE arena of the full width (P_k's T is the leading principal block of
+            // the root's): step k adds the column block  T[0:o, o:o+w] = -T_{P_{k-1}} (V_P^T V_k) T_k  (LAPACK larft order, as
+            // the flat block schedule does for the leaves of a block).  One arena instead of a tree of them; measured the same
+            // step time as a balanced binary tree of merges (111 ms at 65536 x 8192: the tree leaves a 7 ms merge behind
+            // the chain's end, the prefix steps cost the chain as much through contention while they run beside it)
+            const Node first = h->nodes[h->tops[0]], last = h->nodes[h->tops.back()];
+            const int root_ldt = last.a1 - first.a0;
+            const size_t root_toff = toff;
+            toff += (size_t)root_ldt * root_ldt;
+            int prev = h->tops[0];
+            for (size_t k = 1; k < h->tops.size(); k++) {
+                const Node L = h->nodes[prev], R = h->nodes[h->tops[k]];
                 Node pr;
-                pr.c0 = L.c0; pr.c1 = R.c1; pr.a0 = L.a0; pr.a1 = R.a1; pr.ldt = pr.a1 - pr.a0;
-                pr.left = l; pr.right = r2; pr.toff = toff; pr.tld = pr.ldt; pr.id = (int)h->nodes.size();
-                toff += (size_t)pr.ldt * pr.ldt;
+                pr.c0 = first.c0; pr.c1 = R.c1; pr.a0 = first.a0; pr.a1 = R.a1; pr.ldt = pr.a1 - pr.a0;
+                pr.left = prev; pr.right = h->tops[k]; pr.toff = root_toff; pr.tld = root_ldt; pr.id = (int)h->nodes.size();
                 q_half = std::max(q_half, (size_t)L.ldt * (size_t)R.ldt);
                 h->nodes.push_back(pr);
-                h->qmerge_after[b - 1].push_back(pr.id);
-                return pr.id;
-            };
-            h->qroot = build(0, (int)h->tops.size());
+                h->qmerge_after[k].push_back(pr.id);
+                prev = pr.id;
+            }
+            h->qroot = prev;
         } else
         if (qp_on && world == 1 && o.form_q && o.precision != MPQR_PREC_FP32) {
             for (size_t p = 0; p + 1 < h->tops.size(); p += 2) {
@@ -1434,7 +1472,7 @@ static int run_block_loop(mpqr_handle_t h, std::vector<int>& flags) {
         if (!la) {
             apply_node(h, nd, h->dA, h->lda, nd.c1, h->n, true, h->a_scale, true, 0, true);
             if (h->opts.form_q && h->qpair[t] >= 0 && h->S2) merge_pair(h, h->qpair[t], h->s0);
-            if (h->opts.form_q && h->qroot >= 0) for (int id : h->qmerge_after[t]) merge_pair(h, id, h->s0);
+            if (h->opts.form_q && h->qroot >= 0) for (int id : h->qmerge_after[t]) merge_prefix(h, id, h->s0);
             continue;
         }
         h->at_read = t >= 1;                                // far update t-1 wrote the shadow of every column this one reads
@@ -1454,7 +1492,7 @@ static int run_block_loop(mpqr_handle_t h, std::vector<int>& flags) {
         }
         // Q formation works on pairs of blocks: the pair's T behind this block's far update, beside the next panels
         if (h->opts.form_q && h->qpair[t] >= 0 && h->S2) merge_pair(h, h->qpair[t], h->s1);
-        if (h->opts.form_q && h->qroot >= 0) for (int id : h->qmerge_after[t]) merge_pair(h, id, h->s1);   // ... or up the whole tree
+        if (h->opts.form_q && h->qroot >= 0) for (int id : h->qmerge_after[t]) merge_prefix(h, id, h->s1);   // ... or the T of all blocks so far
     }
     h->pairs_ready = h->opts.form_q && h->S2 != nullptr;     // (pairs or the whole tree)
     if (h->la_dirty) {                                      // the tall stream's work, once
