@@ -96,6 +96,8 @@ typedef struct mpqr_handle_s* mpqr_handle_t;
 
 /* ---------------- lifecycle ---------------- */
 const char* mpqr_version(void);
+/* sizeof(mpqr_opts), sizeof(mpqr_metrics), sizeof(mpqr_timings) as compiled into the library (bindings check their layout) */
+void        mpqr_abi_sizes(int out[3]);
 void        mpqr_default_opts(mpqr_opts* o);
 int         mpqr_create(mpqr_handle_t* h, int device);          /* one handle per GPU; owns its streams */
 int         mpqr_destroy(mpqr_handle_t h);

@@ -50,6 +50,7 @@ _H = C.c_void_p
 # name -> (restype, argtypes); mirrors include/mpqr.h one to one
 SIGNATURES = {
     "mpqr_version": (_s, []),
+    "mpqr_abi_sizes": (None, [C.POINTER(C.c_int)]),
     "mpqr_default_opts": (None, [C.POINTER(MpqrOpts)]),
     "mpqr_create": (_i, [C.POINTER(_H), _i]),
     "mpqr_destroy": (_i, [_H]),

@@ -1050,6 +1050,11 @@ extern "C" {
 
 const char* mpqr_version(void) { return "mpqr 0.1 (gfx950)"; }
 
+void mpqr_abi_sizes(int out[3]) {
+    if (!out) return;
+    out[0] = (int)sizeof(mpqr_opts); out[1] = (int)sizeof(mpqr_metrics); out[2] = (int)sizeof(mpqr_timings);
+}
+
 void mpqr_default_opts(mpqr_opts* o) {
     if (!o) return;
     memset(o, 0, sizeof *o);

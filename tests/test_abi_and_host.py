@@ -78,3 +78,19 @@ def test_block_cyclic_partition():
         assert [L.mpqr_part_local_index(c, b, G) for c in cols] == list(range(k))
         seen += cols
     assert sorted(seen) == list(range(n))
+
+
+def test_struct_layouts_match_the_header():
+    """The ctypes mirrors of mpqr_opts / mpqr_metrics / mpqr_timings: same size as compiled into the library and the same
+    field names, in order, as include/mpqr.h declares."""
+    import ctypes as C, os, re
+    from mixedprecisionblockqr_amd import _lib as L
+    out = (C.c_int * 3)()
+    L.lib().mpqr_abi_sizes(out)
+    assert list(out) == [C.sizeof(L.MpqrOpts), C.sizeof(L.MpqrMetrics), C.sizeof(L.MpqrTimings)]
+    hdr = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "mpqr.h")).read()
+    for name, cls in (("mpqr_opts", L.MpqrOpts), ("mpqr_metrics", L.MpqrMetrics), ("mpqr_timings", L.MpqrTimings)):
+        body = re.search(r"typedef struct %s \{(.*?)\} %s;" % (name, name), hdr, re.S).group(1)
+        body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+        fields = [re.sub(r"\[.*", "", d.split()[-1]) for d in body.split(";") if d.strip()]
+        assert fields == [f for f, _ in cls._fields_], (name, fields)
