@@ -304,10 +304,11 @@ constexpr int GW = 128;          // window width
 constexpr int GH_TS = 132;       // LDS row stride (floats) of a staged 128-column tile
 constexpr int GH_ROWS = 128;     // rows per workgroup in gh_gram
 
-constexpr int GH_TD = 130;       // LDS row stride (doubles) of the staged tile
+constexpr int GH_TD = 144;       // LDS row stride (doubles) of the staged tile: rows k, k+1 of one MFMA operand read land on disjoint bank halves
 __global__ __launch_bounds__(256) void gh_gram_kernel(LeafArgs a, double* __restrict__ Gp) {
     double* tile = (double*)gh_smem;                      // [GH_ROWS][GH_TD] doubles: converted once while staging
     const int tid = threadIdx.x;
+    KT_DECL; KT();
     const int row0 = a.c0 + (blockIdx.x >> 1) * GH_ROWS;   // ALL leaf rows, top block included: G = Gram of the remaining rows at k = c0
     const int hb = blockIdx.x & 1;                        // which half of G's rows this workgroup produces
 #pragma unroll
@@ -320,6 +321,7 @@ __global__ __launch_bounds__(256) void gh_gram_kernel(LeafArgs a, double* __rest
         *(double2*)(d + 2) = make_double2((double)v.z, (double)v.w);
     }
     __syncthreads();
+    KT();
     // G = T^T T on v_mfma_f64_16x16x4_f64 (A[i][k] from lane i + 16k, B[k][j] from lane j + 16k, D[i][j] in lane j + 16 (i%4),
     // element i/4 -- probed, tools/probe_mfma_f64.hip).  G is symmetric: only the 36 upper 16 x 16 tiles are computed,
     // tile t = hb + 2 wave + 8 s  (s < 5) by this wave; gh_reduce mirrors the sum.
@@ -338,12 +340,23 @@ __global__ __launch_bounds__(256) void gh_gram_kernel(LeafArgs a, double* __rest
         }
         acc[s] = double4g{0, 0, 0, 0};
     }
-    for (int k0 = 0; k0 < GH_ROWS; k0 += 4) {
-        const double* tr = &tile[(k0 + lk) * GH_TD + li];
+    // two K steps per iteration, all 20 operand reads in flight before the 10 MFMAs (the loop was LDS-latency bound: 10 of
+    // the kernel's 16 us); slots without a tile recompute tile 0 (never stored) so that the loop has no branches
+    int ca[5], cb[5];
 #pragma unroll
-        for (int s = 0; s < 5; s++)
-            if (tti[s] >= 0) acc[s] = __builtin_amdgcn_mfma_f64_16x16x4f64(tr[16 * tti[s]], tr[16 * ttj[s]], acc[s], 0, 0, 0);
+    for (int s = 0; s < 5; s++) { ca[s] = tti[s] >= 0 ? 16 * tti[s] : 0; cb[s] = tti[s] >= 0 ? 16 * ttj[s] : 0; }
+    for (int k0 = 0; k0 < GH_ROWS; k0 += 8) {
+        const double* tr0 = &tile[(k0 + lk) * GH_TD + li];
+        const double* tr1 = tr0 + 4 * GH_TD;
+        double a0[5], b0[5], a1[5], b1[5];
+#pragma unroll
+        for (int s = 0; s < 5; s++) { a0[s] = tr0[ca[s]]; b0[s] = tr0[cb[s]]; a1[s] = tr1[ca[s]]; b1[s] = tr1[cb[s]]; }
+#pragma unroll
+        for (int s = 0; s < 5; s++) acc[s] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[s], b0[s], acc[s], 0, 0, 0);
+#pragma unroll
+        for (int s = 0; s < 5; s++) acc[s] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[s], b1[s], acc[s], 0, 0, 0);
     }
+    KT();
     double* out = Gp + (long)(blockIdx.x >> 1) * (GW * GW);
 #pragma unroll
     for (int s = 0; s < 5; s++)
@@ -354,6 +367,7 @@ __global__ __launch_bounds__(256) void gh_gram_kernel(LeafArgs a, double* __rest
                 out[i * GW + j] = acc[s][v];                 // upper tiles only: gh_reduce mirrors
             }
         }
+    KT(); KT_DUMP(3, "gh_gram load|mfma|store");
 }
 
 // G = sum of the partials in slab order.  256 workgroups: workgroup b owns 64 consecutive entries, its 4 waves
