@@ -340,6 +340,8 @@ int gram(mpqr_handle_t h, const Node& L, const Node& R, int* nslab, long* slab, 
 void apply_node(mpqr_handle_t h, const Node& nd, float* C, long ldc, int clo, int chi, bool trans_t, float in_scale,
                 bool record, int lane = 0, bool far = false) {
     if (chi <= clo) return;
+    static const int dbg_nofar = []() { const char* e = getenv("MPQR_DBG_NOFAR"); return e ? atoi(e) : 0; }();
+    if (dbg_nofar && lane == 1) return;                     // timing experiment only (results are garbage): the chain without far updates beside it
     hipStream_t st = lane ? h->s1 : (h->inblock_stream ? h->inblock_stream : h->s0);   // lane 1: far-update stream with its own scratch
     float* const Xt = lane ? h->Xt1 : h->Xt;
     half_t* const Yt = lane ? h->Yt1 : h->Yt;
@@ -1447,6 +1449,11 @@ static int run_block_loop(mpqr_handle_t h, std::vector<int>& flags) {
         h->la_warm = false; h->la_pg_issued = false; h->la_dirty = false; h->la_idx = 0;
         if (h->la_on) HIPCHK(h, hipStreamWaitEvent(h->sA, h->ev[3], 0));     // sA sees the copy-in / clears as s1 does
     }
+    // far updates beyond the next two blocks are taken pairwise (K = 2 outer blocks: the GEMMs run ~25 % faster and there
+    // are half as many), with the pair T that Q formation needs anyway (MPQR_FAR_PAIR=0: every block on its own)
+    static const int fp_env = []() { const char* e = getenv("MPQR_FAR_PAIR"); return e ? atoi(e) : 1; }();
+    const bool far_pair = la && fp_env && h->opts.precision == MPQR_PREC_FP16 && h->opts.form_q && h->S2 && h->qroot < 0;
+    bool deferred = false, pair_merged = false;
     for (size_t t = 0; t < nt; t++) {
         const Node nd = h->nodes[h->tops[t]];
         if (la && t > 0) {
@@ -1493,10 +1500,24 @@ static int run_block_loop(mpqr_handle_t h, std::vector<int>& flags) {
             }
             apply_node(h, nd, h->dA, h->lda, cf1, a_end, true, h->a_scale, true, 1, true);        // ... then what its first apply touches ...
             HIPCHK(h, hipEventRecord(h->ev_cols2[t + 1], h->s1));
+            if (far_pair && (t % 2) == 0 && h->qpair[t + 1] >= 0) {
+                // even block of a pair: only the columns the NEXT block's part (a) will need get this block's update now
+                // (K = outer block); everything beyond waits for the pair's T and takes both blocks at K = 2 outer blocks
+                const int e_next = (t + 2 < nt) ? (ext[t + 2] ? cfirst[t + 3] : h->nodes[h->tops[t + 2]].c1) : h->n;
+                apply_node(h, nd, h->dA, h->lda, a_end, std::min(e_next, h->n), true, h->a_scale, true, 1, true);
+                deferred = e_next < h->n;
+            } else if (deferred) {
+                // odd block: the pair (t-1, t) onto everything neither of them has reached yet
+                merge_pair(h, h->qpair[t], h->s1); pair_merged = true;
+                h->at_read = t >= 3;                        // the first pair's columns have not been written by a far update yet
+                apply_node(h, h->nodes[h->qpair[t]], h->dA, h->lda, a_end, h->n, true, h->a_scale, true, 1, true);
+                deferred = false;
+            } else
             apply_node(h, nd, h->dA, h->lda, a_end, h->n, true, h->a_scale, true, 1, true);       // ... the rest overlaps its panels
         }
         // Q formation works on pairs of blocks: the pair's T behind this block's far update, beside the next panels
-        if (h->opts.form_q && h->qpair[t] >= 0 && h->S2) merge_pair(h, h->qpair[t], h->s1);
+        if (h->opts.form_q && h->qpair[t] >= 0 && h->S2 && !pair_merged) merge_pair(h, h->qpair[t], h->s1);
+        pair_merged = false;
         if (h->opts.form_q && h->qroot >= 0) for (int id : h->qmerge_after[t]) merge_prefix(h, id, h->s1);   // ... or the T of all blocks so far
     }
     h->pairs_ready = h->opts.form_q && h->S2 != nullptr;     // (pairs or the whole tree)
