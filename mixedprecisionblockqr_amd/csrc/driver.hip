@@ -700,8 +700,7 @@ int factor_block_flat(mpqr_handle_t h, int top, const std::vector<int>& leaves) 
         prev = lf; prev_o = o;
         if (!tq) { t_column_block(prev, prev_o); prev_o = -1; }          // single stream: nothing to defer
     }
-    static const int dbg_skip_last = []() { const char* e = getenv("MPQR_DBG_SKIP_LAST_TCOL"); return e ? atoi(e) : 0; }();   // timing experiment
-    if (prev_o >= 0 && !dbg_skip_last) {                   // the last leaf's column block needs its T (chain stream)
+    if (prev_o >= 0) {                                     // the last leaf's column block needs its T (chain stream)
         if (tq) t_stream_follows_chain(h);
         t_column_block(prev, prev_o);
     }
@@ -1469,8 +1468,7 @@ static int run_block_loop(mpqr_handle_t h, std::vector<int>& flags) {
             h->la_next_robust = h->robust || (fl < (int)h->leaf_robust.size() && h->leaf_robust[fl]) ||
                                 !flat_block_ok(h, h->tops[t + 1], lvtmp);
         }
-        static const int no_chain_ev = []() { const char* e = getenv("MPQR_NO_CHAIN_EV"); return e ? atoi(e) : 0; }();   // experiment
-        const bool timed = !no_chain_ev && h->chain_used + 2 <= h->chain_ev.size();
+        const bool timed = h->chain_used + 2 <= h->chain_ev.size();
         if (timed) HIPCHK(h, hipEventRecord(h->chain_ev[h->chain_used], h->s0));
         rc = factor_node(h, h->tops[t], true);
         h->ext_c1 = 0;
