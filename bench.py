@@ -161,7 +161,7 @@ def main():
         peak = PEAK_FP8_TFLOPS if prec_name == "fp8" else PEAK_FP16_TFLOPS
         kname = ("gemm8_fp8_kernel<E_SUB_F32> (far A2 -= V*Y^T, e4m3 x e4m3 -> fp32 on v_mfma_scale_f32_32x32x64_f8f6f4, K = outer block)"
                  if prec_name == "fp8" else
-                 "gemm6_f16_kernel<E_SUB_F32> (C -= V*Y^T, fp16 x fp16 -> fp32: far trailing update, K = outer block, and Q formation, K = 2 outer blocks)")
+                 "gemm6_f16_kernel<E_SUB_F32> (C -= V*Y^T, fp16 x fp16 -> fp32: far trailing updates, K = 2 outer blocks beyond the next two blocks, and Q formation, K = 2 outer blocks)")
         roof = {"bound": "mfma", "kernel": kname,
                 "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
                 "traffic": _pmc_traffic(), "launches": tm["n_far_launches"] + (tm.get("n_q_launches", 0) if q_nn else 0),
@@ -169,33 +169,16 @@ def main():
                 "far_update_achieved": ach_far, "q_formation_achieved": q_nn,
                 "q_formation_tn_achieved": (tm["tflop_q"] / (tm["ms_q_tn"] * 1e-3)) if q_nn and tm["ms_q_tn"] > 0 else None,
                 "tn_achieved": (tm["flops_far_tn"] / (tm["ms_far_tn"] * 1e-3) / 1e12) if tm["ms_far_tn"] > 0 else None}
-        # The same launches against the HBM roof: algorithmic bytes = fp32 C read + write (8 M N) + both fp16 operands once
-        # (2 K (M + N)), summed over the schedule's far updates (block t updates the next block, then the rest).
-        K = args.outer_block or 1024
-        nblk = (n + K - 1) // K
-        alg = 0.0
-        for t in range(nblk - 1):
-            W = m - t * K
-            for N in (min(K, n - (t + 1) * K), n - (t + 2) * K):
-                if N > 0:
-                    alg += 8.0 * W * N + 2.0 * K * (W + N)
+        # The far launches against the HBM roof: algorithmic bytes = fp32 C read + write (8 M N) + both fp16 operands once
+        # (2 K (M + N)), summed by the library over the far updates it launched (pairs of blocks beyond the next two).
+        alg = tm["gbytes_far_nn"] * 1e9
         roof["hbm_view"] = {"set": "far updates", "algorithmic_bytes": alg, "achieved": alg / nn_t / 1e9, "peak": PEAK_HBM_GBPS, "unit": "GB/s",
                             "frac": alg / nn_t / 1e9 / PEAK_HBM_GBPS, "flop_per_byte": tm["flops_far_nn"] / alg,
                             "ridge_flop_per_byte": peak * 1e3 / PEAK_HBM_GBPS}
-        # algorithmic bytes per launch over the SAME launches `traffic` is averaged over (far updates + Q formation on
-        # pairs of blocks: fp32 C read + write, the fp16 shadow write, both fp16 operands once)
-        alg_q, nq = 0.0, 0
-        if q_nn:
-            Kq = 2 * K
-            t = nblk - 1
-            while t >= 0:
-                if t >= 1 and (t % 2) == 1:
-                    W = m - (t - 1) * K
-                    alg_q += 10.0 * W * W + 2.0 * Kq * (W + W); nq += 1; t -= 2
-                else:
-                    W = m - t * K
-                    alg_q += 10.0 * W * W + 2.0 * K * (W + W); nq += 1; t -= 1
-        roof["algorithmic_bytes_per_launch"] = (alg + alg_q) / (tm["n_far_launches"] + nq) if (tm["n_far_launches"] + nq) else None
+        # algorithmic bytes per launch over the SAME launches `traffic` is averaged over (the library sums, per launch, fp32 C
+        # read + write, the fp16 shadow where it is written, both fp16 operands once)
+        nl = tm["n_far_launches"] + (tm.get("n_q_launches", 0) if q_nn else 0)
+        roof["algorithmic_bytes_per_launch"] = ((tm["gbytes_far_nn"] + (tm["gbytes_q_nn"] if q_nn else 0.0)) * 1e9 / nl) if nl else None
     out = {
         "metric": "GFLOP/s block QR (%s MFMA trailing)" % prec_name, "value": fl["geqrf"] / dt / 1e9, "unit": "GFLOP/s",
         "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt * 1e3,

@@ -90,6 +90,8 @@ typedef struct mpqr_timings {
     int   n_q_launches;   /* number of Q-formation applies (blocks or pairs of blocks)                               */
     float tflop_q;        /* flops (in units of 1e12) executed by the tn launches of Q formation (= by the nn ones)  */
     float ms_host_enqueue;/* host time to enqueue the factorisation's launches (before its one synchronisation)    */
+    double gbytes_far_nn; /* algorithmic HBM bytes (1e9) of the far A2 -= V Y^T launches: fp32 C read + write, fp16 operands once */
+    double gbytes_q_nn;   /* the same for Q formation's Q2 -= V Y^T launches (+ the fp16 shadow they write)          */
 } mpqr_timings;
 
 typedef struct mpqr_handle_s* mpqr_handle_t;

@@ -32,7 +32,7 @@ class MpqrTimings(C.Structure):
                 ("ms_far_nn", C.c_float), ("n_far_launches", C.c_int), ("flops_far_tn", C.c_double),
                 ("flops_far_nn", C.c_double), ("ms_chain_wait", C.c_float), ("n_passes", C.c_int),
                 ("n_robust_leaves", C.c_int), ("ms_q_tn", C.c_float), ("ms_q_nn", C.c_float), ("n_q_launches", C.c_int),
-                ("tflop_q", C.c_float), ("ms_host_enqueue", C.c_float)]
+                ("tflop_q", C.c_float), ("ms_host_enqueue", C.c_float), ("gbytes_far_nn", C.c_double), ("gbytes_q_nn", C.c_double)]
 
 
 def build(force=False):

@@ -168,6 +168,7 @@ struct mpqr_handle_s {
     std::vector<hipEvent_t> far_ev;   // pool, 4 per recorded far update: around op1 / op3
     size_t far_used = 0;
     std::vector<double> far_flops;
+    std::vector<double> far_bytes;     // algorithmic HBM bytes of the same launches' C -= V Y^T
     std::vector<hipEvent_t> chain_ev; // pool, 2 per top-level block: around factor_node on the chain stream
     size_t chain_used = 0;
     mpqr_timings last_t;
@@ -464,6 +465,7 @@ void apply_node(mpqr_handle_t h, const Node& nd, float* C, long ldc, int clo, in
     if (record) {
         (void)hipEventRecord(e3, st);
         h->far_flops.push_back(2.0 * M1 * (double)Kr * Kw);
+        h->far_bytes.push_back((g3.Ct ? 10.0 : 8.0) * M1 * (double)Kw + 2.0 * Kr * ((double)M1 + Kw));
     }
 }
 
@@ -968,6 +970,7 @@ static int form_q_one_shot(mpqr_handle_t h) {
         e0 = h->far_ev[h->far_used]; e1 = h->far_ev[h->far_used + 1]; e2 = h->far_ev[h->far_used + 2]; e3 = h->far_ev[h->far_used + 3];
         h->q_first = h->far_used; h->far_used += 4;
         h->far_flops.push_back(2.0 * (double)h->m * (double)h->m * Kr);
+        h->far_bytes.push_back(4.0 * (double)h->m * h->m + 2.0 * Kr * (2.0 * h->m));
     }
     GemmArgs w{};                                         // W[m x Kr] = V T   (T upper triangular: k <= n)
     w.A = h->Vh + (long)rlo * h->ldvh + rt.a0; w.lda = h->ldvh;
@@ -1405,7 +1408,7 @@ int mpqr_generate_matrix(mpqr_handle_t h, uint64_t seed) {
 // enqueue copy-in + the whole block loop; flags[id] != 0: the Gram-Householder leaf `id` was too ill-conditioned
 static int run_block_loop(mpqr_handle_t h, std::vector<int>& flags) {
     int rc;
-    h->far_used = 0; h->far_flops.clear(); h->chain_used = 0; h->v8_node = -1;
+    h->far_used = 0; h->far_flops.clear(); h->far_bytes.clear(); h->chain_used = 0; h->v8_node = -1;
     h->pairs_ready = false; h->q_first = (size_t)-1;
     const auto host_t0 = std::chrono::steady_clock::now();  // host time to enqueue the block loop (ms_host_enqueue)
     HIPCHK(h, hipEventRecord(h->ev[0], h->s0));
@@ -1599,8 +1602,10 @@ int mpqr_get_timings(mpqr_handle_t h, mpqr_timings* t) {
         if (i >= h->q_first) {                                                    // Q formation's applies
             t->ms_q_tn += a; t->ms_q_nn += b; t->n_q_launches++;
             fq += h->far_flops[i / 4];
+            if (i / 4 < h->far_bytes.size()) t->gbytes_q_nn += h->far_bytes[i / 4] * 1e-9;
             continue;
         }
+        if (i / 4 < h->far_bytes.size()) t->gbytes_far_nn += h->far_bytes[i / 4] * 1e-9;
         t->ms_far_tn += a; t->ms_far_nn += b; tr += x;
         f += h->far_flops[i / 4];
         t->n_far_launches++;
@@ -2132,7 +2137,7 @@ int mpqr_dist_begin(mpqr_handle_t h, float absmax) {
     float sc = 1.f;
     if (absmax > 0.f && std::isfinite(absmax)) { int e; frexpf(absmax * sqrtf((float)h->m), &e); sc = ldexpf(1.f, 8 - e); }
     h->a_scale = sc;
-    h->far_used = 0; h->far_flops.clear(); h->chain_used = 0; h->v8_node = -1;
+    h->far_used = 0; h->far_flops.clear(); h->far_bytes.clear(); h->chain_used = 0; h->v8_node = -1;
     h->pairs_ready = false; h->n_passes = 1; h->n_robust_leaves = 0;
     HIPCHK(h, hipEventRecord(h->ev[0], h->s0));
     HIPCHK(h, hipMemcpyAsync(h->dA, h->dA0, (size_t)h->m_pad * h->lda * sizeof(float), hipMemcpyDeviceToDevice, h->s0));
