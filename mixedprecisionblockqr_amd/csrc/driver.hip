@@ -905,9 +905,9 @@ static void merge_pair(mpqr_handle_t h, int pid, hipStream_t st) {
     Range rg("mpqr:wy_T_pair");
     const Node nd = h->nodes[pid];
     const Node L = h->nodes[nd.left], R = h->nodes[nd.right];
-    if (h->tq_on) {                                       // the children's T's come from the T stream
-        (void)hipStreamWaitEvent(st, h->ev_T[L.id], 0);
-        (void)hipStreamWaitEvent(st, h->ev_T[R.id], 0);
+    if (h->tq_on) {                                       // the children's T's come from the T stream (blocks factored here)
+        if (L.id < (int)h->ev_T.size()) (void)hipStreamWaitEvent(st, h->ev_T[L.id], 0);
+        if (R.id < (int)h->ev_T.size()) (void)hipStreamWaitEvent(st, h->ev_T[R.id], 0);
     }
     int nslab; long slab;
     gram(h, L, R, &nslab, &slab, st, h->S2, h->s2_elems);
@@ -997,7 +997,7 @@ int form_q(mpqr_handle_t h) {
     HIPCHK(h, hipMemsetAsync(h->dQ, 0, (size_t)h->m_pad * h->ldq * sizeof(float), h->s0));
     launch_set_identity(h->dQ, h->ldq, h->m, h->m, h->s0);
     if (h->Qt && h->world == 1) {
-        HIPCHK(h, hipMemsetAsync(h->Qt, 0, (size_t)(h->m_pad + 256) * h->ldqt * sizeof(half_t), h->s0));
+        HIPCHK(h, hipMemsetAsync(h->Qt, 0, (size_t)(h->ldq + 256) * h->ldqt * sizeof(half_t), h->s0));
         launch_set_identity_h16(h->Qt, h->ldqt, h->m, h->s0);
         h->shadow = h->Qt; h->ldshadow = h->ldqt;
     }
@@ -1225,7 +1225,7 @@ static int plan_common(mpqr_handle_t h, int m, int n, int r, const mpqr_opts* op
             }
             h->qroot = prev;
         } else
-        if (qp_on && world == 1 && o.form_q && o.precision != MPQR_PREC_FP32) {
+        if (qp_on && o.form_q && o.precision != MPQR_PREC_FP32) {             // (every rank of a distributed plan builds the same pairs)
             for (size_t p = 0; p + 1 < h->tops.size(); p += 2) {
                 const Node L = h->nodes[h->tops[p]], R = h->nodes[h->tops[p + 1]];
                 if (L.a0 != L.c0 || R.a0 != R.c0 || L.a1 != R.a0 || L.ldt < 256 || R.ldt < 256) continue;
@@ -1319,9 +1319,9 @@ static int plan_common(mpqr_handle_t h, int m, int n, int r, const mpqr_opts* op
     if ((rc = dalloc(h, &h->tmp2, h->tmp_elems))) return rc;
     {
         static const int sh_on = []() { const char* e = getenv("MPQR_QSHADOW"); return e ? atoi(e) : 1; }();
-        if (sh_on && world == 1 && o.form_q && o.precision != MPQR_PREC_FP32 && h->qroot < 0) {
-            h->ldqt = h->m_pad;
-            if ((rc = dalloc(h, &h->Qt, (size_t)(h->m_pad + 256) * h->ldqt))) return rc;
+        if (sh_on && o.form_q && o.precision != MPQR_PREC_FP32 && h->qroot < 0) {
+            h->ldqt = h->m_pad;                             // one row per LOCAL column of Q (all of them on a single GPU)
+            if ((rc = dalloc(h, &h->Qt, (size_t)(h->ldq + 256) * h->ldqt))) return rc;
             if ((rc = dalloc(h, &h->Xh, h->yt_elems + (size_t)256 * x_ldt))) return rc;
             HIPCHK(h, hipMemsetAsync(h->Xh, 0, (h->yt_elems + (size_t)256 * x_ldt) * sizeof(half_t), h->s0));
         }
@@ -2194,7 +2194,7 @@ long mpqr_dist_block_bytes(mpqr_handle_t h, int s) {
     if (!h || !h->planned || s < 0 || s >= (int)h->tops.size()) return -1;
     const Node& nd = h->nodes[h->tops[s]];
     const long Kr = nd.ldt, Wc = h->m_pad - rdown(nd.c0, 64);
-    return (Kr * Wc + 2 * Kr * Kr) * (long)sizeof(half_t);
+    return (Kr * Wc + 2 * Kr * Kr) * (long)sizeof(half_t) + Kr * Kr * (long)sizeof(float);   // V^T | T | T^T (fp16) | T (fp32: pair merges)
 }
 
 int mpqr_dist_pack_block(mpqr_handle_t h, int s, void* dbuf) {
@@ -2207,6 +2207,7 @@ int mpqr_dist_pack_block(mpqr_handle_t h, int s, void* dbuf) {
                                Wc * sizeof(half_t), Kr, hipMemcpyDeviceToDevice, h->s0));
     HIPCHK(h, hipMemcpyAsync(out + Kr * Wc, h->Th + nd.toff, Kr * Kr * sizeof(half_t), hipMemcpyDeviceToDevice, h->s0));
     HIPCHK(h, hipMemcpyAsync(out + Kr * Wc + Kr * Kr, h->Tth + nd.toff, Kr * Kr * sizeof(half_t), hipMemcpyDeviceToDevice, h->s0));
+    HIPCHK(h, hipMemcpyAsync(out + Kr * Wc + 2 * Kr * Kr, h->Tf + nd.toff, Kr * Kr * sizeof(float), hipMemcpyDeviceToDevice, h->s0));
     HIPCHK(h, hipStreamSynchronize(h->s0));
     return MPQR_OK;
 }
@@ -2222,6 +2223,7 @@ int mpqr_dist_unpack_block(mpqr_handle_t h, int s, const void* dbuf) {
                                Wc * sizeof(half_t), Kr, hipMemcpyDeviceToDevice, h->s0));
     HIPCHK(h, hipMemcpyAsync(h->Th + nd.toff, in + Kr * Wc, Kr * Kr * sizeof(half_t), hipMemcpyDeviceToDevice, h->s0));
     HIPCHK(h, hipMemcpyAsync(h->Tth + nd.toff, in + Kr * Wc + Kr * Kr, Kr * Kr * sizeof(half_t), hipMemcpyDeviceToDevice, h->s0));
+    HIPCHK(h, hipMemcpyAsync(h->Tf + nd.toff, in + Kr * Wc + 2 * Kr * Kr, Kr * Kr * sizeof(float), hipMemcpyDeviceToDevice, h->s0));
     // Vh[rlo + c][a0 + k] = Vt[a0 + k][rlo + c]
     launch_transpose_h16(in, Wc, h->Vh + (size_t)rlo * h->ldvh + nd.a0, h->ldvh, (int)Kr, (int)Wc, h->s0);
     HIPCHK(h, hipStreamSynchronize(h->s0));              // the caller may refill the buffer (double-buffered broadcasts)
@@ -2257,7 +2259,17 @@ int mpqr_dist_update_part(mpqr_handle_t h, int s, int part) {
         apply_node(h, nd, h->dA, h->lda, lc1, h->nloc, true, h->a_scale, true, 1, true);
         (void)hipEventRecord(h->ev_dist_far, h->s1);
     }
+    if (part != 0 && h->opts.form_q && h->S2 && s < (int)h->qpair.size() && h->qpair[s] >= 0) {
+        // Q formation works on pairs of blocks: T of the pair (s-1, s), behind this rank's update with block s
+        hipStream_t ms = (part == 1 && two_streams) ? h->s1 : h->s0;
+        if (ms == h->s1) {                                 // V, T of block s are on the chain stream (factor / unpack)
+            (void)hipEventRecord(h->ev_dist_chain, h->s0); (void)hipStreamWaitEvent(h->s1, h->ev_dist_chain, 0);
+        }
+        merge_pair(h, h->qpair[s], ms);
+        if (ms == h->s1) (void)hipEventRecord(h->ev_dist_far, h->s1);
+    }
     if (last && part != 0) {
+        h->pairs_ready = h->opts.form_q && h->S2 != nullptr;
         if (two_streams) (void)hipStreamWaitEvent(h->s0, h->ev_dist_far, 0);
         HIPCHK(h, hipEventRecord(h->ev[1], h->s0)); h->factored = true;
     }
@@ -2272,11 +2284,21 @@ int mpqr_dist_form_q(mpqr_handle_t h) {
     if (h->Xt1) (void)hipStreamWaitEvent(h->s0, h->ev_dist_far, 0);
     HIPCHK(h, hipMemsetAsync(h->dQ, 0, (size_t)h->m_pad * h->ldq * sizeof(float), h->s0));
     launch_identity_cyclic(h->dQ, h->ldq, h->m, h->qloc, h->Ko, h->world, h->rank, h->s0);
-    for (int t = (int)h->tops.size() - 1; t >= 0; t--) {
-        const Node& nd = h->nodes[h->tops[t]];
-        const int lq = mpqr_part_local_cols(std::min(h->m, nd.c0), h->Ko, h->world, h->rank);
-        apply_node(h, nd, h->dQ, h->ldq, lq, h->qloc, false, 1.f, false);
+    if (h->Qt) {                                           // transposed fp16 shadow of the local columns (as in form_q)
+        HIPCHK(h, hipMemsetAsync(h->Qt, 0, (size_t)(h->ldq + 256) * h->ldqt * sizeof(half_t), h->s0));
+        launch_identity_cyclic_h16(h->Qt, h->ldqt, h->m, h->qloc, h->Ko, h->world, h->rank, h->s0);
+        h->shadow = h->Qt; h->ldshadow = h->ldqt;
     }
+    const bool pairs = h->pairs_ready && h->qpair.size() == h->tops.size();
+    for (int t = (int)h->tops.size() - 1; t >= 0; t--) {
+        const bool pr = pairs && h->qpair[t] >= 0;          // two blocks at once, K = 2 outer blocks
+        const Node& nd = pr ? h->nodes[h->qpair[t]] : h->nodes[h->tops[t]];
+        const int lq = mpqr_part_local_cols(std::min(h->m, nd.c0), h->Ko, h->world, h->rank);
+        h->shadow_write = (pr ? t - 1 : t) > 0;
+        apply_node(h, nd, h->dQ, h->ldq, lq, h->qloc, false, 1.f, false);
+        if (pr) t--;
+    }
+    h->shadow = nullptr; h->shadow_write = true;
     h->q_formed = true;
     HIPCHK(h, hipEventRecord(h->ev[2], h->s0));
     HIPCHK(h, hipGetLastError());

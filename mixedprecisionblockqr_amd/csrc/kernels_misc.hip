@@ -115,6 +115,17 @@ void launch_identity_cyclic(float* Q, long ldq, int m, int qloc, int block, int 
     if (qloc <= 0) return;
     hipLaunchKernelGGL(identity_cyclic_kernel, dim3((qloc + 255) / 256), dim3(256), 0, s, Q, ldq, m, qloc, block, world, rank);
 }
+// the same diagonal in the transposed fp16 shadow Qt[local column][row]
+__global__ void identity_cyclic_h16_kernel(half_t* Qt, long ldqt, int m, int qloc, int block, int world, int rank) {
+    const int lc = blockIdx.x * blockDim.x + threadIdx.x;
+    if (lc >= qloc) return;
+    const int gc = cyc_global(lc, block, world, rank);
+    if (gc < m) Qt[(long)lc * ldqt + gc] = (half_t)1.f;
+}
+void launch_identity_cyclic_h16(half_t* Qt, long ldqt, int m, int qloc, int block, int world, int rank, hipStream_t s) {
+    if (qloc <= 0) return;
+    hipLaunchKernelGGL(identity_cyclic_h16_kernel, dim3((qloc + 255) / 256), dim3(256), 0, s, Qt, ldqt, m, qloc, block, world, rank);
+}
 // boundary layout ((m+1) x nloc, shifted reflectors) of this rank's columns
 __global__ void pack_factor_cyclic_kernel(const float* A, long lda, const float* vdiag, float* out, int m, int nloc,
                                           int block, int world, int rank) {
