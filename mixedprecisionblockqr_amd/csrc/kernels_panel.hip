@@ -446,22 +446,60 @@ __device__ __forceinline__ void lds_store32(float* C, int ldc, const floatx16p& 
 // product overwrites X_LR in Ss, so the lower triangle of Ts stays zero.  Needs >= 4 waves; ends with a barrier.
 __device__ __forceinline__ void tri_inverse_128(float* Ss, const float* tdiag, float* Ts, int nblk, int tid) {
     const int wave = tid >> 6, lane = tid & 63;
+#ifdef MPQR_KTRACE
+    long ti_[8]; int tn_ = 0;
+    if (tid == 0 && blockIdx.x == 0) ti_[tn_++] = clock64();
+#endif
+    // diagonal 16 x 16 blocks: row a of the inverse depends on row a only -- lane a runs the column recurrence in registers
+    // (eight blocks: two per wave, one per half of the first 32 lanes ... of waves 0-3)
     if (wave < nblk && lane < 32) {
-        const int base = 32 * wave;
-        float tr[32];
+        const int base = 32 * wave + 16 * (lane >> 4), a = lane & 15;
+        float tr[16];
 #pragma unroll
-        for (int i = 0; i < 32; i++) {
+        for (int i = 0; i < 16; i++) {
             const float tii = tdiag[base + i];
             float ps[4] = {0.f, 0.f, 0.f, 0.f};            // four partial sums: a quarter of the dependent chain
 #pragma unroll
             for (int q = 0; q < i; q++) ps[q & 3] += tr[q] * Ss[(base + q) * TPS + base + i];
             const float sum = (ps[0] + ps[1]) + (ps[2] + ps[3]);
-            tr[i] = (lane < i) ? -tii * sum : (lane == i ? tii : 0.f);
+            tr[i] = (a < i) ? -tii * sum : (a == i ? tii : 0.f);
         }
 #pragma unroll
-        for (int i = 0; i < 32; i++) Ts[(base + lane) * TPS + base + i] = tr[i];
+        for (int i = 0; i < 16; i++) Ts[(base + a) * TPS + base + i] = tr[i];
     }
     __syncthreads();
+    // 16 -> 32 inside every 32-block (one wave each): with L / R the two halves, T_LR = -T_L (S_LR T_R).  On 32 x 32 tiles:
+    // rows < 16 of  S_blk[:, 16:32] T_blk[16:32, :]  (k range 16..32) are S_LR T_R in the columns >= 16; it replaces S_LR,
+    // then rows < 16 of  T_blk[:, 0:16] (that)[0:16, :]  (k range 0..16) are T_L (S_LR T_R).
+    {
+        const bool has = wave < nblk;
+        const int base = 32 * wave, r = lane & 31, kk = lane >> 5;
+        floatx16p acc;
+        if (has) acc = lds_mm32(&Ss[base * TPS + base], TPS, &Ts[base * TPS + base], TPS, 16, 32, lane);
+        __syncthreads();
+        if (has && r >= 16) {
+#pragma unroll
+            for (int e = 0; e < 16; e++) {
+                const int i = (e & 3) + 8 * (e >> 2) + 4 * kk;
+                if (i < 16) Ss[(base + i) * TPS + base + r] = acc[e];
+            }
+        }
+        __syncthreads();
+        if (has) {
+            acc = lds_mm32(&Ts[base * TPS + base], TPS, &Ss[base * TPS + base], TPS, 0, 16, lane);
+            if (r >= 16) {
+#pragma unroll
+                for (int e = 0; e < 16; e++) {
+                    const int i = (e & 3) + 8 * (e >> 2) + 4 * kk;
+                    if (i < 16) Ts[(base + i) * TPS + base + r] = -acc[e];
+                }
+            }
+        }
+        __syncthreads();
+    }
+#ifdef MPQR_KTRACE
+    if (tid == 0 && blockIdx.x == 0) ti_[tn_++] = clock64();
+#endif
     for (int half = 32; half < 32 * nblk; half *= 2) {
         const int ts = half / 32, npair = TP / (2 * half);
         const bool has = wave < npair * ts * ts;
@@ -477,7 +515,17 @@ __device__ __forceinline__ void tri_inverse_128(float* Ss, const float* tdiag, f
             lds_store32(&Ts[(L0 + 32 * bi) * TPS + R0 + 32 * bj], TPS, acc, -1.f, lane);
         }
         __syncthreads();
+#ifdef MPQR_KTRACE
+        if (tid == 0 && blockIdx.x == 0 && tn_ < 8) ti_[tn_++] = clock64();
+#endif
     }
+#ifdef MPQR_KTRACE
+    if (tid == 0 && blockIdx.x == 0 && atomicSub(&g_ktrace_left[4], 1) > 0) {
+        printf("ktrace tri_inverse diag|merge32|merge64:");
+        for (int q = 1; q < tn_; q++) printf(" %ld", ti_[q] - ti_[q - 1]);
+        printf("\n");
+    }
+#endif
 }
 
 // 768 threads.  Waves 0-7 ("update", a 16 x 32 grid): thread (ti,tj) keeps the CYCLIC entries {ti + 16x} x {tj + 32y},
