@@ -1731,6 +1731,26 @@ __global__ __launch_bounds__(1024) void t_panel_kernel(const float* __restrict__
     KT();
     // the ldt x ldt aligned range is written (zeros outside the leaf) into a matrix of leading dimension ld (>= ldt:
     // the node's own T, or its diagonal block inside the T of the enclosing top-level block)
+    if (ldt == TP && off == 0 && (ld & 3) == 0) {
+        // the usual case (a full 128-column leaf): four consecutive entries per thread, 16- and 8-byte stores
+        typedef half_t half4t __attribute__((ext_vector_type(4)));
+#pragma unroll
+        for (int q = 0; q < TP * TP / 4 / 1024; q++) {
+            const int e4 = tid + 1024 * q, i = e4 >> 5, j = (e4 & 31) * 4;
+            float4 v; half4t hv, ht;
+            float t[4], u[4];
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+                t[c] = (i < w && j + c >= i && j + c < w) ? Ts[i * TPS + j + c] : 0.f;          // T[i][j+c]
+                u[c] = (j + c < w && i >= j + c && i < w) ? Ts[(j + c) * TPS + i] : 0.f;        // T^T[i][j+c] = T[j+c][i]
+                hv[c] = (half_t)t[c]; ht[c] = (half_t)u[c];
+            }
+            v.x = t[0]; v.y = t[1]; v.z = t[2]; v.w = t[3];
+            *(float4*)&T[(long)i * ld + j] = v;
+            *(half4t*)&Th[(long)i * ld + j] = hv;
+            *(half4t*)&Tth[(long)i * ld + j] = ht;
+        }
+    } else {
     for (int e = tid; e < ldt * ldt; e += 1024) {
         const int i = e / ldt, j = e % ldt;
         const int li = i - off, lj = j - off;
@@ -1745,6 +1765,7 @@ __global__ __launch_bounds__(1024) void t_panel_kernel(const float* __restrict__
         float v = 0.f;
         if (li >= 0 && li < w && lj >= li && lj < w) v = Ts[li * TPS + lj];
         Tth[(long)j * ld + i] = (half_t)v;
+    }
     }
     KT(); KT_DUMP(1, "t_panel load|inverse|store");
 }
