@@ -569,6 +569,7 @@ __global__ __launch_bounds__(GH_SOLVE_THREADS) void gh_solve_kernel(LeafArgs a, 
     __shared__ GhPreB preB[2];
     __shared__ int lflag, cmask[GW];
     const int tid = threadIdx.x;
+    KT_DECL; KT();
     const bool upd = tid < GH_UPD_THREADS;
     const int role = upd ? 0 : (tid < GH_UPD_THREADS + GW ? 1 : 2);   // 0 update, 1 Cholesky chain, 2 Householder chain
     const int ti = (tid >> 5) & 15, tj = tid & 31;
@@ -607,6 +608,7 @@ __global__ __launch_bounds__(GH_SOLVE_THREADS) void gh_solve_kernel(LeafArgs a, 
     // the scalar chains are the critical path: their waves issue first
     if (!upd) __builtin_amdgcn_s_setprio(3);
     __syncthreads();
+    KT();
     for (int it = 0; it <= w; it++) {
         if (role == 1) {
             // ---- Cholesky step a = it (one ahead of the Householder chain)
@@ -716,6 +718,7 @@ __global__ __launch_bounds__(GH_SOLVE_THREADS) void gh_solve_kernel(LeafArgs a, 
         __syncthreads();
     }
     if (!upd) __builtin_amdgcn_s_setprio(0);
+    KT();
     // R and the top block of V go out first (from the LDS columns): the stores drain while the inverse below runs.
     // Ts[k][i] = |R[i][k]| for i <= k (sign -sgn[i]), v_top of column k for i > k.
     if ((w & 7) == 0 && (a.c0 & 7) == 0) {                 // usual case: 16-byte stores (8 fp16 / 4 fp32 per thread)
@@ -777,11 +780,14 @@ __global__ __launch_bounds__(GH_SOLVE_THREADS) void gh_solve_kernel(LeafArgs a, 
     for (int e = tid; e < TP * TPS; e += GH_SOLVE_THREADS) Ts[e] = 0.f;
     __syncthreads();
     // C = (D^-1 + W)^-1, columns of flagged reflectors zeroed
+    KT();
     tri_inverse_128(Ws, tdiag, Ts, (w + 31) / 32, tid);
+    KT();
     for (int e = tid; e < GW * GW; e += GH_SOLVE_THREADS) {          // window coordinates (leaf index + off), zero elsewhere
         const int i = (e >> 7) - off, k = (e & 127) - off;
         Cv[e] = (i >= 0 && i <= k && k < w && cmask[k]) ? Ts[i * TPS + k] : 0.f;
     }
+    KT(); KT_DUMP(5, "gh_solve load|loop|out|inverse|cstore");
 }
 
 // ------------------------------------------------------------------ gh_solve2: blocked form of gh_solve
