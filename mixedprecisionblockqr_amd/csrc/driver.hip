@@ -440,7 +440,8 @@ void apply_node(mpqr_handle_t h, const Node& nd, float* C, long ldc, int clo, in
     g2.M = M1; g2.N = Kr; g2.K = Kr;
     g2.in_scale = 1.f; g2.alpha = 1.f; g2.nsplit = 1;
     g2.tri = trans_t ? 2 : 1;                              // T is upper triangular: T^T rows end at the diagonal, T rows start there
-    if (fuse_xt) launch_leaf_xt(Xt, g1.nsplit, slab, M1, g2.Bt, g2.ldb, g2.tri, Yt, Kr, st);
+    g2.cscale = h->Tf + nd.toff; g2.cscale_ld = (long)nd.tld + 1;   // tau_n: the fp16 T's have a unit diagonal
+    if (fuse_xt) launch_leaf_xt(Xt, g1.nsplit, slab, M1, g2.Bt, g2.ldb, g2.tri, Yt, Kr, g2.cscale, g2.cscale_ld, st);
     else if (x16) { g2.A = h->Xh; gemm_dispatch(A_H16, E_STORE_H16, g2, st); }
     else
     gemm_dispatch(A_F32, E_STORE_H16, g2, st);
@@ -977,6 +978,7 @@ static int form_q_one_shot(mpqr_handle_t h) {
     w.Bt = h->Tth + rt.toff; w.ldb = rt.tld;
     w.C = h->Wh; w.ldc = h->n_pad;
     w.M = h->m_pad - rlo; w.N = Kr; w.K = Kr; w.alpha = 1.f; w.in_scale = 1.f; w.nsplit = 1; w.tri = 2;
+    w.cscale = h->Tf + rt.toff; w.cscale_ld = (long)rt.tld + 1;
     if (rec) (void)hipEventRecord(e0, h->s0);
     gemm_dispatch(A_H16, E_STORE_H16, w, h->s0);
     if (rec) { (void)hipEventRecord(e1, h->s0); (void)hipEventRecord(e2, h->s0); }

@@ -193,7 +193,7 @@ __global__ __launch_bounds__(256) void gemm_f16_kernel(GemmArgs g) {
                 if (m < g.M && n < g.N) {
                     const float v = alpha * acc[i][j][e];
                     if (EM == E_STORE_F32) ((float*)g.C)[(long)z * g.slab_out_stride + (long)m * g.ldc + n] = v;
-                    else ((half_t*)g.C)[(long)m * g.ldc + n] = (half_t)v;
+                    else ((half_t*)g.C)[(long)m * g.ldc + n] = (half_t)(g.cscale ? v * g.cscale[(long)n * g.cscale_ld] : v);
                 }
             }
         }

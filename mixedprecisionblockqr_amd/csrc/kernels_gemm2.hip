@@ -265,7 +265,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm2_f16_kernel(GemmArgs g, int
                 if (m < g.M && n < g.N) {
                     const float v = alpha * acc[i][j][e];
                     if (EM == E_STORE_F32) ((float*)g.C)[(long)z * g.slab_out_stride + (long)m * g.ldc + n] = v;
-                    else ((half_t*)g.C)[(long)m * g.ldc + n] = (half_t)v;
+                    else ((half_t*)g.C)[(long)m * g.ldc + n] = (half_t)(g.cscale ? v * g.cscale[(long)n * g.cscale_ld] : v);
                 }
             }
         }
@@ -688,7 +688,7 @@ __global__ __launch_bounds__(512) void gemm6_f16_kernel(GemmArgs g, int tilesM, 
             for (int e = 0; e < 16; e++) {
                 const int m = bm + wm + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
                 if (m < g.M && n < g.N) {
-                    if (EM == E_STORE_H16) ((half_t*)g.C)[(long)m * g.ldc + n] = (half_t)(alpha * acc[i][j][e]);
+                    if (EM == E_STORE_H16) ((half_t*)g.C)[(long)m * g.ldc + n] = (half_t)(g.cscale ? alpha * acc[i][j][e] * g.cscale[(long)n * g.cscale_ld] : alpha * acc[i][j][e]);
                     else if (g.eye_minus) ((float*)g.C)[(long)m * g.ldc + n] = (m == n ? 1.f : 0.f) - alpha * acc[i][j][e];
                     else ((float*)g.C)[(long)m * g.ldc + n] = alpha * acc[i][j][e];
                 }

@@ -1650,7 +1650,7 @@ typedef half_t half4x __attribute__((ext_vector_type(4)));
 typedef float float4x __attribute__((ext_vector_type(4)));
 __global__ __launch_bounds__(256) void leaf_xt_kernel(const float* __restrict__ X, int nslab, long slab_stride, int M1,
                                                       const half_t* __restrict__ Bt, long ldb, int tri,
-                                                      half_t* __restrict__ Y, long ldy) {
+                                                      half_t* __restrict__ Y, long ldy, const float* __restrict__ cscale, long cs_ld) {
     __shared__ __attribute__((aligned(16))) half_t Xs[16][136];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int row0 = blockIdx.x * 16;
@@ -1689,16 +1689,18 @@ __global__ __launch_bounds__(256) void leaf_xt_kernel(const float* __restrict__ 
             const half4x bv = *(const half4x*)&Bt[(long)(n0 + li) * ldb + k0 + 4 * lg];
             acc = __builtin_amdgcn_mfma_f32_16x16x16f16(av, bv, acc, 0, 0, 0);
         }
+        const float sc = cscale ? cscale[(long)(n0 + li) * cs_ld] : 1.f;      // tau_n (the fp16 T has a unit diagonal)
 #pragma unroll
         for (int e = 0; e < 4; e++) {
             const int row = row0 + 4 * lg + e;
-            if (row < M1) Y[(long)row * ldy + n0 + li] = (half_t)acc[e];
+            if (row < M1) Y[(long)row * ldy + n0 + li] = (half_t)(sc * acc[e]);
         }
     }
 }
 void launch_leaf_xt(const float* X, int nslab, long slab_stride, int M1, const half_t* Bt, long ldb, int tri, half_t* Y, long ldy,
-                    hipStream_t s) {
-    hipLaunchKernelGGL(leaf_xt_kernel, dim3((M1 + 15) / 16), dim3(256), 0, s, X, nslab, slab_stride, M1, Bt, ldb, tri, Y, ldy);
+                    const float* cscale, long cscale_ld, hipStream_t s) {
+    hipLaunchKernelGGL(leaf_xt_kernel, dim3((M1 + 15) / 16), dim3(256), 0, s, X, nslab, slab_stride, M1, Bt, ldb, tri, Y, ldy,
+                       cscale, cscale_ld);
 }
 
 // ------------------------------------------------------------------ T of a leaf (up to 128 reflectors)
@@ -1745,11 +1747,13 @@ __global__ __launch_bounds__(1024) void t_panel_kernel(const float* __restrict__
             const int e4 = tid + 1024 * q, i = e4 >> 5, j = (e4 & 31) * 4;
             float4 v; half4t hv, ht;
             float t[4], u[4];
+            const float tii = i < w ? Ts[i * TPS + i] : 0.f;
+            const float rti = tii != 0.f ? 1.0f / tii : 0.f;
 #pragma unroll
             for (int c = 0; c < 4; c++) {
                 t[c] = (i < w && j + c >= i && j + c < w) ? Ts[i * TPS + j + c] : 0.f;          // T[i][j+c]
                 u[c] = (j + c < w && i >= j + c && i < w) ? Ts[(j + c) * TPS + i] : 0.f;        // T^T[i][j+c] = T[j+c][i]
-                hv[c] = (half_t)t[c]; ht[c] = (half_t)u[c];
+                hv[c] = (half_t)(t[c] * rti); ht[c] = (half_t)(u[c] * rti);                    // fp16 copies: row i / tau_i
             }
             v.x = t[0]; v.y = t[1]; v.z = t[2]; v.w = t[3];
             *(float4*)&T[(long)i * ld + j] = v;
@@ -1763,14 +1767,16 @@ __global__ __launch_bounds__(1024) void t_panel_kernel(const float* __restrict__
         float v = 0.f;
         if (li >= 0 && li < w && lj >= li && lj < w) v = Ts[li * TPS + lj];
         T[(long)i * ld + j] = v;
-        Th[(long)i * ld + j] = (half_t)v;
+        const float tii = (li >= 0 && li < w) ? Ts[li * TPS + li] : 0.f;
+        Th[(long)i * ld + j] = (half_t)(tii != 0.f ? v / tii : 0.f);       // fp16 copies carry T[n][k] / tau_n (unit diagonal)
     }
     for (int e = tid; e < ldt * ldt; e += 1024) {          // T^T: consecutive lanes walk a column of T (odd LDS stride)
         const int j = e / ldt, i = e % ldt;
         const int li = i - off, lj = j - off;
         float v = 0.f;
         if (li >= 0 && li < w && lj >= li && lj < w) v = Ts[li * TPS + lj];
-        Tth[(long)j * ld + i] = (half_t)v;
+        const float tjj = (lj >= 0 && lj < w) ? Ts[lj * TPS + lj] : 0.f;
+        Tth[(long)j * ld + i] = (half_t)(tjj != 0.f ? v / tjj : 0.f);
     }
     }
     KT(); KT_DUMP(1, "t_panel load|inverse|store");
@@ -1893,14 +1899,21 @@ __global__ __launch_bounds__(256) void t_colblock_h16_kernel(const float* __rest
     for (int q = 0; q < 4; q++) {
         const int i = i0 + ty + 8 * q, j = j0 + tx;
         float v = 0.f;
-        if (i < rows && j < w) { v = T[(long)i * ld + c + j]; Th[(long)i * ld + c + j] = (half_t)v; }
+        if (i < rows && j < w) {
+            v = T[(long)i * ld + c + j];
+            const float tii = T[(long)i * ld + i];                      // tau_i: the fp16 copies carry row n / tau_n
+            Th[(long)i * ld + c + j] = (half_t)(tii != 0.f ? v / tii : 0.f);
+        }
         tile[ty + 8 * q][tx] = v;
     }
     __syncthreads();
 #pragma unroll
     for (int q = 0; q < 4; q++) {
         const int j = j0 + ty + 8 * q, i = i0 + tx;
-        if (i < rows && j < w) Tth[(long)(c + j) * ld + i] = (half_t)tile[tx][ty + 8 * q];
+        if (i < rows && j < w) {
+            const float tjj = T[(long)(c + j) * ld + c + j];
+            Tth[(long)(c + j) * ld + i] = (half_t)(tjj != 0.f ? tile[tx][ty + 8 * q] / tjj : 0.f);
+        }
     }
 }
 void launch_t_colblock_h16(const float* T, half_t* Th, half_t* Tth, int ld, int rows, int c, int w, hipStream_t s) {
@@ -1925,7 +1938,11 @@ __global__ __launch_bounds__(256) void t_assemble_kernel(float* __restrict__ T, 
     else if (iR && jR) v = TR[(long)(gi - aR0) * ldr + (gj - aR0)];
     else if (iL && jR) v = TLR[(long)(gi - aL0) * ldlr + (gj - aR0)];
     T[(long)i * ldt + j] = v;
-    Th[(long)i * ldt + j] = (half_t)v;
+    float dii = 0.f;                                      // tau_i = T[i][i]: both fp16 copies carry their row i divided by it
+    if (gi >= c0 && gi < cm) dii = TL[(long)(gi - aL0) * ldl + (gi - aL0)];
+    else if (gi >= cm && gi < c1) dii = TR[(long)(gi - aR0) * ldr + (gi - aR0)];
+    const float rdi = dii != 0.f ? 1.0f / dii : 0.f;
+    Th[(long)i * ldt + j] = (half_t)(v * rdi);
     {   // T^T entry (i, j) = T[j][i]: the same thread index walks T^T row-major, so this store is coalesced too
         const int gj2 = A0 + i, gi2 = A0 + j;             // T row gi2, column gj2
         float u = 0.f;
@@ -1934,7 +1951,7 @@ __global__ __launch_bounds__(256) void t_assemble_kernel(float* __restrict__ T, 
         if (iL2 && jL2) u = TL[(long)(gi2 - aL0) * ldl + (gj2 - aL0)];
         else if (iR2 && jR2) u = TR[(long)(gi2 - aR0) * ldr + (gj2 - aR0)];
         else if (iL2 && jR2) u = TLR[(long)(gi2 - aL0) * ldlr + (gj2 - aR0)];
-        Tth[(long)i * ldt + j] = (half_t)u;
+        Tth[(long)i * ldt + j] = (half_t)(u * rdi);
     }
 }
 

@@ -41,6 +41,12 @@ struct GemmArgs {
     // Bt is triangular (the compact-WY T as the second operand): 1: Bt[n][k] = 0 for k < n, 2: Bt[n][k] = 0 for k > n.
     // The 256-wide kernel skips the K tiles that are entirely zero for its output columns; other kernels ignore it.
     int tri;
+    // E_STORE_H16: column n of the result is multiplied by cscale[n * cscale_ld] (fp32) before it is rounded.  The fp16
+    // copies of a compact-WY T carry T[n][k] / T[n][n] (unit diagonal, exactly representable): the diagonal tau_n stays in
+    // fp32 (the diagonal of the fp32 T) and is applied here.  Rounding tau_n ~ 2 to fp16 would put a coherent relative error
+    // of up to 2^-11 on a whole reflector's contribution; with a dominant reflector (non-centred data) that alone moved the
+    // backward error of random instances between 6e-4 and 1.2e-3.
+    const float* cscale; long cscale_ld;
     int eye_minus;       // E_STORE_F32 (256-wide kernel): store (m == n ? 1 : 0) - alpha*acc  (Q = I - W V^T in one product)
 };
 void launch_gemm_f16(AMode am, EMode em, const GemmArgs& g, hipStream_t s);
@@ -117,7 +123,7 @@ void launch_gh_glue(const GlueArgs& g, hipStream_t s);
 void launch_gh_save_top(const float* A, long lda, int c0, float* Bs, hipStream_t s);
 // Y[M1 x 128] (fp16, ld ldy) = fp16(sum of nslab X slabs, M1 x 128 fp32) * T', Bt[n][k] = T'[k][n] (fp16, ld ldb), tri as GemmArgs::tri
 void launch_leaf_xt(const float* X, int nslab, long slab_stride, int M1, const half_t* Bt, long ldb, int tri, half_t* Y, long ldy,
-                    hipStream_t s);
+                    const float* cscale, long cscale_ld, hipStream_t s);
 void launch_gh_reduce_f32(const float* Sp, int nslab, float* S, hipStream_t s);
 
 // T of a leaf (<= 128 reflectors) from its Gram slabs S (row stride lds_, aligned range starting at a0)

@@ -523,13 +523,15 @@ def test_fp8_trailing_update_matches_e4m3_emulation(mp, h, po):
     # --- emulation
     V = po.extract_V(Ac, m, n, go, pw).astype(np.float64)                 # (m-go) x pw, unit-norm reflectors
     Vh = po.round_fp16(V)
-    T = po.round_fp16(po.compact_T(Ac, m, n, go, pw, round_v_fp16=True))
+    T32 = po.compact_T(Ac, m, n, go, pw, round_v_fp16=True).astype(np.float32)
+    tau = np.diag(T32).copy()                                              # the fp16 T has a unit diagonal: T[k][n] / tau_n ...
+    T = po.round_fp16(T32 / tau[None, :])
     A2 = Ac[go:m, go + pw:].astype(np.float64)
     mx = float(np.abs(Ac[:m]).max())
     s = 2.0 ** (8 - np.frexp(np.float32(mx) * np.sqrt(np.float32(m)))[1])     # the library's power-of-two scale
     V8 = po.round_e4m3(256.0 * Vh).astype(np.float64)
     X = (po.round_e4m3(s * A2).astype(np.float64).T @ V8) / 256.0
-    Y = po.round_fp16(X.astype(np.float32) @ T.astype(np.float32)).astype(np.float64)      # Q_panel^T = I - V T^T V^T: Y^T = T^T X^T
+    Y = po.round_fp16((X.astype(np.float32) @ T.astype(np.float32)) * tau[None, :]).astype(np.float64)   # ... tau_n in fp32 in the epilogue
     Y8 = po.round_e4m3(0.25 * Y).astype(np.float64)
     want = A2 - (V8 @ Y8.T) / (64.0 * s)
     exact = A2 - V @ (po.compact_T(Ac, m, n, go, pw).astype(np.float64).T @ (V.T @ A2))
