@@ -154,7 +154,8 @@ struct mpqr_handle_s {
     // the same for the trailing matrix: At[column][row] = fp16(a_scale * A), written by every far update's epilogue, read by
     // the NEXT far update's X = A2^T V (far update 0 reads the fp32 matrix: nothing has written the shadow yet)
     half_t* At = nullptr; long ldat = 0; bool at_read = false;
-    half_t* Xh = nullptr;          // fp16 X = Q2^T V of a Q-formation apply (the next GEMM rounds X to fp16 anyway)
+    // X = C2^T V leaves its GEMM as fp16 hi + lo parts (per stream lane) and Y = X T' takes both on the ping-pong kernel
+    half_t* Xh = nullptr; half_t* Xl = nullptr; half_t* Xh1 = nullptr; half_t* Xl1 = nullptr;
     // 1-D block-cyclic column distribution (world == 1: everything local)
     int world = 1, rank = 0;
     int nloc = 0;        // local columns of A
@@ -210,9 +211,9 @@ void free_plan(mpqr_handle_t h) {
     void* ptrs[] = {h->dA, h->dA0, h->dQ, h->Vh, h->Vt, h->vdiag, h->Xt, h->Yt, h->S, h->P, h->tmp1, h->tmp2,
                     h->Tf, h->Th, h->Tth, h->dstage, h->Gp, h->Gs, h->Cv, h->dflag, h->Vf, h->Yf, h->Xt1, h->Yt1, h->Sp,
                     h->rbTf, h->rbTh, h->rbTth, h->Sleaf, h->Wk, h->V8n, h->V8t, h->A8t, h->Y8,
-                    h->GsN[0], h->GsN[1], h->Gp2, h->G2, h->Bsv[0], h->Bsv[1], h->Cv2[1], h->Yg, h->S2, h->tmp1b, h->tmp2b, h->Qt, h->At, h->Xh, h->Wh};
+                    h->GsN[0], h->GsN[1], h->Gp2, h->G2, h->Bsv[0], h->Bsv[1], h->Cv2[1], h->Yg, h->S2, h->tmp1b, h->tmp2b, h->Qt, h->At, h->Xh, h->Wh, h->Xl, h->Xh1, h->Xl1};
     for (void* p : ptrs) if (p) (void)hipFree(p);
-    h->S2 = h->tmp1b = h->tmp2b = nullptr; h->s2_elems = 0; h->Qt = nullptr; h->shadow = nullptr; h->At = nullptr; h->at_read = false; h->Xh = nullptr; h->Wh = nullptr; h->qroot = -1; h->qmerge_after.clear(); h->qpair.clear(); h->pairs_ready = false;
+    h->S2 = h->tmp1b = h->tmp2b = nullptr; h->s2_elems = 0; h->Qt = nullptr; h->shadow = nullptr; h->At = nullptr; h->at_read = false; h->Xh = nullptr; h->Xl = h->Xh1 = h->Xl1 = nullptr; h->Wh = nullptr; h->qroot = -1; h->qmerge_after.clear(); h->qpair.clear(); h->pairs_ready = false;
     h->GsN[0] = h->GsN[1] = nullptr; h->Gp2 = h->G2 = nullptr; h->Bsv[0] = h->Bsv[1] = nullptr; h->Cv2[0] = h->Cv2[1] = nullptr; h->Yg = nullptr;
     h->dA = h->dA0 = h->dQ = nullptr; h->Vh = h->Vt = nullptr; h->vdiag = nullptr; h->Xt = nullptr; h->Yt = nullptr;
     h->S = nullptr; h->P = nullptr; h->tmp1 = h->tmp2 = nullptr; h->Tf = nullptr; h->Th = h->Tth = nullptr;
@@ -394,8 +395,19 @@ void apply_node(mpqr_handle_t h, const Node& nd, float* C, long ldc, int clo, in
     // not cover (K not a multiple of 128) stay on the fp16 path
     const bool f8 = far && h->V8n && (Kr % 128) == 0 && (Kw % 128) == 0 && (rlo % 16) == 0 && nd.a0 == nd.c0;
     const bool a_shadow = h->At && lane == 1 && far && !f8 && C == h->dA;   // fp16 shadow of the trailing matrix (far updates)
+    // X keeps ~22 bits through Y = X T' (fp16 hi + lo parts, MPQR_XSPLIT=0: one fp16 rounding as in round 1); the fp16-X
+    // shortcut of Q formation (MPQR_X16=1) is the opposite trade
+    static const int xsplit = []() { const char* e = getenv("MPQR_XSPLIT"); return e ? atoi(e) : 1; }();
     static const int x16_env = []() { const char* e = getenv("MPQR_X16"); return e ? atoi(e) : 1; }();
-    const bool x16 = x16_env && h->shadow && h->Xh && lane == 0 && !far && g1.nsplit == 1 && M1 >= 256 && Kr >= 256;
+    // big unsplit updates: X goes from its GEMM to the next one as fp16 (hi, and lo when xsplit) instead of fp32
+    half_t* const Xhi = lane ? h->Xh1 : h->Xh;
+    // (Q formation: Q has no dominant component, the lo part buys 1.5 % of backward error and 7 % of ||Q^T Q - I|| for
+    // 0.7 ms at 16384^2 -- MPQR_QSPLIT=1 turns it on there as well)
+    static const int qsplit = []() { const char* e = getenv("MPQR_QSPLIT"); return e ? atoi(e) : 0; }();
+    const bool q_apply = h->shadow && lane == 0 && !far;
+    half_t* const Xlo = (xsplit && (!q_apply || qsplit)) ? (lane ? h->Xl1 : h->Xl) : nullptr;
+    const bool x16 = x16_env && Xhi && (!xsplit || Xlo || q_apply) && !f8 && g1.nsplit == 1 && M1 >= 256 && Kr >= 256 && (Kr % 64) == 0 &&
+                     (long)(M1 / 256) * (Kr / 256) >= 48 && h->opts.precision != MPQR_PREC_FP32;
     // one leaf (128 reflectors) onto a few columns: slab sum and Y = X T' in one small kernel (leaf_xt_kernel)
     static const int fuse_env = []() { const char* e = getenv("MPQR_FUSE_XT"); return e ? atoi(e) : 1; }();
     const bool fuse_xt = fuse_env && !f8 && !far && lane == 0 && Kr == 128 && M1 <= 4096 && !(h->shadow && lane == 0);
@@ -418,13 +430,17 @@ void apply_node(mpqr_handle_t h, const Node& nd, float* C, long ldc, int clo, in
     if (a_shadow && h->at_read) {                          // trailing matrix: the previous far update left fp16(s A2)^T
         g1.A = h->At + (long)clo_al * h->ldat + rlo; g1.lda = h->ldat;
         g1.in_scale = 1.f;
-        gemm_dispatch(A_H16, E_STORE_F32, g1, st1);
+        if (x16) { g1.C = Xhi; g1.C2 = Xlo; gemm_dispatch(A_H16, E_STORE_H16, g1, st1); }
+        else gemm_dispatch(A_H16, E_STORE_F32, g1, st1);
     } else
     if (h->shadow && lane == 0 && !far) {                  // fp16 operand, already [column][row]: C2^T = shadow rows
         g1.A = h->shadow + (long)clo_al * h->ldshadow + rlo; g1.lda = h->ldshadow;
         g1.in_scale = 1.f;
-        if (x16) { g1.C = h->Xh; gemm_dispatch(A_H16, E_STORE_H16, g1, st1); }   // X leaves in fp16: Y = X T' reads it as is
+        if (x16) { g1.C = Xhi; g1.C2 = Xlo; gemm_dispatch(A_H16, E_STORE_H16, g1, st1); }   // X leaves as fp16 hi (+ lo)
         else gemm_dispatch(A_H16, E_STORE_F32, g1, st1);
+    } else if (x16) {
+        g1.C = Xhi; g1.C2 = Xlo;
+        gemm_dispatch(A_F32T, E_STORE_H16, g1, st1);
     } else
     gemm_dispatch(A_F32T, E_STORE_F32, g1, st1);
     if (g1.nsplit > 1 && !fuse_xt) launch_slab_reduce(Xt, g1.nsplit, slab, slab, Xt, st1);
@@ -442,9 +458,9 @@ void apply_node(mpqr_handle_t h, const Node& nd, float* C, long ldc, int clo, in
     g2.tri = trans_t ? 2 : 1;                              // T is upper triangular: T^T rows end at the diagonal, T rows start there
     g2.cscale = h->Tf + nd.toff; g2.cscale_ld = (long)nd.tld + 1;   // tau_n: the fp16 T's have a unit diagonal
     if (fuse_xt) launch_leaf_xt(Xt, g1.nsplit, slab, M1, g2.Bt, g2.ldb, g2.tri, Yt, Kr, g2.cscale, g2.cscale_ld, st);
-    else if (x16) { g2.A = h->Xh; gemm_dispatch(A_H16, E_STORE_H16, g2, st); }
+    else if (x16) { g2.A = Xhi; g2.A2 = Xlo; gemm_dispatch(A_H16, E_STORE_H16, g2, st); }
     else
-    gemm_dispatch(A_F32, E_STORE_H16, g2, st);
+    gemm_dispatch(xsplit ? A_F32S : A_F32, E_STORE_H16, g2, st);
     // op3: C2 -= (1/in_scale) V Yt^T
     GemmArgs g3{};
     g3.A = h->Vh + (long)rlo * h->ldvh + nd.a0; g3.lda = h->ldvh;
@@ -1270,6 +1286,15 @@ static int plan_common(mpqr_handle_t h, int m, int n, int r, const mpqr_opts* op
         HIPCHK(h, hipMemsetAsync(h->V8n, 0, e1, h->s0)); HIPCHK(h, hipMemsetAsync(h->V8t, 0, e2, h->s0));
         HIPCHK(h, hipMemsetAsync(h->A8t, 0, e3, h->s0)); HIPCHK(h, hipMemsetAsync(h->Y8, 0, e4, h->s0));
     }
+    if (o.precision != MPQR_PREC_FP32) {
+        const size_t xe = h->yt_elems + (size_t)256 * x_ldt;
+        if ((rc = dalloc(h, &h->Xh, xe)) || (rc = dalloc(h, &h->Xl, xe))) return rc;
+        HIPCHK(h, hipMemsetAsync(h->Xh, 0, xe * sizeof(half_t), h->s0)); HIPCHK(h, hipMemsetAsync(h->Xl, 0, xe * sizeof(half_t), h->s0));
+        if (o.lookahead) {
+            if ((rc = dalloc(h, &h->Xh1, xe)) || (rc = dalloc(h, &h->Xl1, xe))) return rc;
+            HIPCHK(h, hipMemsetAsync(h->Xh1, 0, xe * sizeof(half_t), h->s0)); HIPCHK(h, hipMemsetAsync(h->Xl1, 0, xe * sizeof(half_t), h->s0));
+        }
+    }
     if ((rc = dalloc(h, &h->Xt, h->xt_elems + (size_t)256 * x_ldt))) return rc;
     if ((rc = dalloc(h, &h->Yt, h->yt_elems + (size_t)256 * x_ldt))) return rc;
     HIPCHK(h, hipMemsetAsync(h->Xt, 0, (h->xt_elems + (size_t)256 * x_ldt) * sizeof(float), h->s0));
@@ -1324,8 +1349,7 @@ static int plan_common(mpqr_handle_t h, int m, int n, int r, const mpqr_opts* op
         if (sh_on && o.form_q && o.precision != MPQR_PREC_FP32 && h->qroot < 0) {
             h->ldqt = h->m_pad;                             // one row per LOCAL column of Q (all of them on a single GPU)
             if ((rc = dalloc(h, &h->Qt, (size_t)(h->ldq + 256) * h->ldqt))) return rc;
-            if ((rc = dalloc(h, &h->Xh, h->yt_elems + (size_t)256 * x_ldt))) return rc;
-            HIPCHK(h, hipMemsetAsync(h->Xh, 0, (h->yt_elems + (size_t)256 * x_ldt) * sizeof(half_t), h->s0));
+
         }
     }
     {

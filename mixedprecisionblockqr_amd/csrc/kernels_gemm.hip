@@ -209,6 +209,7 @@ static void launch_one(const GemmArgs& g, hipStream_t s) {
 }
 
 void launch_gemm_f16(AMode am, EMode em, const GemmArgs& g, hipStream_t s) {
+    if (am == A_F32S) am = A_F32;                          // the 128-tile kernel has no split staging (small shapes only)
     if (g.M <= 0 || g.N <= 0 || g.K <= 0) return;
 #define MPQR_CASE(A_, E_) if (am == A_ && em == E_) { launch_one<A_, E_>(g, s); return; }
     MPQR_CASE(A_F32T, E_STORE_F32)

@@ -46,7 +46,9 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm2_f16_kernel(GemmArgs g, int
     constexpr int ROWB = BK * 2;                       // bytes per LDS row
     constexpr int CPR = BK / 8;                        // 16-B chunks per row
     constexpr int RB = 256 / ROWB;                     // rows per 256-B bank row
-    constexpr int A_BYTES = BM * ROWB, B_BYTES = BN * ROWB, STAGE = A_BYTES + B_BYTES;
+    constexpr int A_BYTES = BM * ROWB, B_BYTES = BN * ROWB;
+    constexpr int A_ALL = (AM == A_F32S ? 2 : 1) * A_BYTES;      // A_F32S: hi tile, then lo tile
+    constexpr int STAGE = A_ALL + B_BYTES;
     // byte offset of logical chunk c of row r: XOR swizzle makes 16 consecutive rows hit 16 distinct 16-B bank slots
     auto swz = [](int r, int c) -> int { return r * ROWB + ((c ^ ((r / RB) & (CPR - 1))) << 4); };
 
@@ -72,13 +74,14 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm2_f16_kernel(GemmArgs g, int
     if (g.tri == 1) kt0 = max(kt0, bn / BK);                           // Bt[n][k] = 0 for k < n
     else if (g.tri == 2) kt1 = min(kt1, (bn + BN + BK - 1) / BK);      // Bt[n][k] = 0 for k > n
     char* const As0 = g2_smem;
-    char* const Bs0 = g2_smem + A_BYTES;
+    char* const Bs0 = g2_smem + A_ALL;
 
     // ---- A staging through registers
     constexpr int NA = BM * CPR / NT;                  // 16-B chunks per thread (A_H16 / A_F32)
     constexpr int NBLK = (BK / 4) * (BM / 4) / NT;     // 4 x 4 fp32 blocks per thread (A_F32T)
     typedef float F4 __attribute__((ext_vector_type(4)));   // first-class vectors: the loads land in their final registers
     U4 ra[NA];
+    U4 ral[AM == A_F32S ? NA : 1];                      // A_F32S: the lo parts
     F4 raT[2][NBLK * 4];                                 // A_F32T: two register sets, loads run two K tiles ahead
     // A_F32T: per-thread row pointers advance by BK rows per K tile (no 64-bit multiplies in the loop)
     const float* pT[NBLK];
@@ -118,6 +121,12 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm2_f16_kernel(GemmArgs g, int
                 v.x = pack2(s0.x * sc, s0.y * sc); v.y = pack2(s0.z * sc, s0.w * sc);
                 v.z = pack2(s1.x * sc, s1.y * sc); v.w = pack2(s1.z * sc, s1.w * sc);
                 ra[i] = v;
+                if (AM == A_F32S) {                           // lo = x - fp16(x), rounded to fp16 itself
+                    auto lo2 = [&](float a, float b) { return pack2(a * sc - (float)(half_t)(a * sc), b * sc - (float)(half_t)(b * sc)); };
+                    U4 l;
+                    l.x = lo2(s0.x, s0.y); l.y = lo2(s0.z, s0.w); l.z = lo2(s1.x, s1.y); l.w = lo2(s1.z, s1.w);
+                    ral[i] = l;
+                }
             }
         }
     };
@@ -154,6 +163,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm2_f16_kernel(GemmArgs g, int
             for (int i = 0; i < NA; i++) {
                 const int c = tid + NT * i, row = c / CPR, kc = c % CPR;
                 *(U4*)(As + swz(row, kc)) = ra[i];
+                if (AM == A_F32S) *(U4*)(As + A_BYTES + swz(row, kc)) = ral[i];
             }
         }
     };
@@ -200,6 +210,16 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm2_f16_kernel(GemmArgs g, int
 #pragma unroll
                 for (int j = 0; j < 2; j++)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i], b[j], acc[i][j], 0, 0, 0);
+            if (AM == A_F32S) {
+                half8 al[4];
+#pragma unroll
+                for (int i = 0; i < 4; i++) al[i] = *(const half8*)(As + A_BYTES + swz(wm + i * 32 + r, ks * 2 + h));
+#pragma unroll
+                for (int i = 0; i < 4; i++)
+#pragma unroll
+                    for (int j = 0; j < 2; j++)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], b[j], acc[i][j], 0, 0, 0);
+            }
         }
     };
     if (AM == A_F32T) {
@@ -265,7 +285,12 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm2_f16_kernel(GemmArgs g, int
                 if (m < g.M && n < g.N) {
                     const float v = alpha * acc[i][j][e];
                     if (EM == E_STORE_F32) ((float*)g.C)[(long)z * g.slab_out_stride + (long)m * g.ldc + n] = v;
-                    else ((half_t*)g.C)[(long)m * g.ldc + n] = (half_t)(g.cscale ? v * g.cscale[(long)n * g.cscale_ld] : v);
+                    else {
+                        const float vs = g.cscale ? v * g.cscale[(long)n * g.cscale_ld] : v;
+                        const half_t hv = (half_t)vs;
+                        ((half_t*)g.C)[(long)m * g.ldc + n] = hv;
+                        if (g.C2) g.C2[(long)m * g.ldc + n] = (half_t)(vs - (float)hv);
+                    }
                 }
             }
         }
@@ -274,7 +299,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm2_f16_kernel(GemmArgs g, int
 template <int AM, int EM, int WM, int WN, int BK>
 static void launch2(const GemmArgs& g, hipStream_t s) {
     constexpr int BM = 128 * WM, BN = 64 * WN, NT = 64 * WM * WN;
-    constexpr int LDS = 2 * (BM + BN) * BK * 2;
+    constexpr int LDS = 2 * ((AM == A_F32S ? 2 : 1) * BM + BN) * BK * 2;
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void*)gemm2_f16_kernel<AM, EM, WM, WN, BK>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
@@ -532,8 +557,10 @@ __global__ __launch_bounds__(512) void gemm6_f16_kernel(GemmArgs g, int tilesM, 
     // triangular second operand (GemmArgs::tri): only the K tiles where Bt can be non-zero for this tile's columns
     const int kt_lo = g.tri == 1 ? bn / BK : 0;
     const int kt_hi = g.tri == 2 ? min(g.K / BK, (bn + BN + BK - 1) / BK) : g.K / BK;
-    const int ktiles = kt_hi - kt_lo;
+    const int kth = kt_hi - kt_lo;                            // K tiles of one pass over Bt
+    const int ktiles = g.A2 ? 2 * kth : kth;                  // second pass: the lo parts of A over the same Bt
     const half_t* const A = (const half_t*)g.A + (long)kt_lo * BK;
+    const half_t* const A2 = g.A2 ? g.A2 + (long)kt_lo * BK : nullptr;
     const half_t* const Bt = g.Bt + (long)kt_lo * BK;
     const int wr = wave >> 2, wc = wave & 3;
     const int wm = wr * 128, wn = wc * 64;
@@ -541,7 +568,10 @@ __global__ __launch_bounds__(512) void gemm6_f16_kernel(GemmArgs g, int tilesM, 
     // half tile s of K tile tau -> buffer tau & 1.  s: 0 = A-S0, 1 = B-S0, 2 = B-S1, 3 = A-S1.
     // One wave-instruction = 8 rows x 128 B; lane l lands on row row0 + l/8, physical chunk l%8.
     auto issue = [&](int tau, int sidx) {
-        const int k = min(tau, ktiles - 1) * BK;              // past the end: re-fetch the last tile into a dead region
+        const int tc = min(tau, ktiles - 1);                  // past the end: re-fetch the last tile into a dead region
+        const bool second = tc >= kth;
+        const int k = (second ? tc - kth : tc) * BK;
+        const half_t* const Ab = second ? A2 : A;
         char* buf = g2_smem + (tau & 1) * BUF;
         const bool isA = (sidx == 0 || sidx == 3);
         const int sub = (sidx == 0 || sidx == 1) ? 0 : 1;
@@ -554,7 +584,7 @@ __global__ __launch_bounds__(512) void gemm6_f16_kernel(GemmArgs g, int tilesM, 
             const int rr = row0 + (lane >> 3);
             const int c = (lane & 7) ^ ((rr >> 1) & 7);
             if (isA)
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(A + (long)(bm + rr) * g.lda + k + c * 8),
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(Ab + (long)(bm + rr) * g.lda + k + c * 8),
                                                  (__attribute__((address_space(3))) void*)(buf + row0 * ROWB), 16, 0, 0);
             else
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(Bt + (long)(bn + rr) * g.ldb + k + c * 8),
@@ -688,7 +718,12 @@ __global__ __launch_bounds__(512) void gemm6_f16_kernel(GemmArgs g, int tilesM, 
             for (int e = 0; e < 16; e++) {
                 const int m = bm + wm + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
                 if (m < g.M && n < g.N) {
-                    if (EM == E_STORE_H16) ((half_t*)g.C)[(long)m * g.ldc + n] = (half_t)(g.cscale ? alpha * acc[i][j][e] * g.cscale[(long)n * g.cscale_ld] : alpha * acc[i][j][e]);
+                    if (EM == E_STORE_H16) {
+                        const float vs = g.cscale ? alpha * acc[i][j][e] * g.cscale[(long)n * g.cscale_ld] : alpha * acc[i][j][e];
+                        const half_t hv = (half_t)vs;
+                        ((half_t*)g.C)[(long)m * g.ldc + n] = hv;
+                        if (g.C2) g.C2[(long)m * g.ldc + n] = (half_t)(vs - (float)hv);
+                    }
                     else if (g.eye_minus) ((float*)g.C)[(long)m * g.ldc + n] = (m == n ? 1.f : 0.f) - alpha * acc[i][j][e];
                     else ((float*)g.C)[(long)m * g.ldc + n] = alpha * acc[i][j][e];
                 }
@@ -1151,10 +1186,12 @@ bool launch_gemm2_f16(AMode am, EMode em, const GemmArgs& g, hipStream_t s, int 
         return true;                                                        \
     }
     MPQR_CASE2(A_F32T, E_STORE_F32)
+    MPQR_CASE2(A_F32T, E_STORE_H16)
     MPQR_CASE2(A_F32, E_STORE_H16)
     MPQR_CASE2(A_H16, E_SUB_F32)
     MPQR_CASE2(A_F32, E_STORE_F32)
 #undef MPQR_CASE2
+    if (am == A_F32S && em == E_STORE_H16) { launch2<A_F32S, E_STORE_H16, 2, 4, 32>(g, s); return true; }
     return false;
 }
 

@@ -1651,7 +1651,8 @@ typedef float float4x __attribute__((ext_vector_type(4)));
 __global__ __launch_bounds__(256) void leaf_xt_kernel(const float* __restrict__ X, int nslab, long slab_stride, int M1,
                                                       const half_t* __restrict__ Bt, long ldb, int tri,
                                                       half_t* __restrict__ Y, long ldy, const float* __restrict__ cscale, long cs_ld) {
-    __shared__ __attribute__((aligned(16))) half_t Xs[16][136];
+    __shared__ __attribute__((aligned(16))) half_t Xs[16][136];       // fp16(X)
+    __shared__ __attribute__((aligned(16))) half_t Xl[16][136];       // X - fp16(X): the product keeps X to ~22 bits
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int row0 = blockIdx.x * 16;
 #pragma unroll
@@ -1675,6 +1676,9 @@ __global__ __launch_bounds__(256) void leaf_xt_kernel(const float* __restrict__ 
         }
         half4x hv; hv[0] = (half_t)a.x; hv[1] = (half_t)a.y; hv[2] = (half_t)a.z; hv[3] = (half_t)a.w;
         *(half4x*)&Xs[lr][c] = hv;
+        half4x lv; lv[0] = (half_t)(a.x - (float)hv[0]); lv[1] = (half_t)(a.y - (float)hv[1]);
+        lv[2] = (half_t)(a.z - (float)hv[2]); lv[3] = (half_t)(a.w - (float)hv[3]);
+        *(half4x*)&Xl[lr][c] = lv;
     }
     __syncthreads();
     const int li = lane & 15, lg = lane >> 4;
@@ -1686,8 +1690,10 @@ __global__ __launch_bounds__(256) void leaf_xt_kernel(const float* __restrict__ 
         const int klo = tri == 1 ? (n0 & ~15) : 0, khi = tri == 2 ? n0 + 16 : 128;
         for (int k0 = klo; k0 < khi; k0 += 16) {
             const half4x av = *(const half4x*)&Xs[li][k0 + 4 * lg];
+            const half4x al = *(const half4x*)&Xl[li][k0 + 4 * lg];
             const half4x bv = *(const half4x*)&Bt[(long)(n0 + li) * ldb + k0 + 4 * lg];
             acc = __builtin_amdgcn_mfma_f32_16x16x16f16(av, bv, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x16f16(al, bv, acc, 0, 0, 0);
         }
         const float sc = cscale ? cscale[(long)(n0 + li) * cs_ld] : 1.f;      // tau_n (the fp16 T has a unit diagonal)
 #pragma unroll

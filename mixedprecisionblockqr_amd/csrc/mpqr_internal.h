@@ -16,7 +16,9 @@ typedef _Float16 half_t;
 enum AMode {
     A_H16 = 0,   // fp16 source [M][K], k contiguous
     A_F32T = 1,  // fp32 source [K][M], m contiguous: converted (x in_scale) and transposed while staged
-    A_F32 = 2    // fp32 source [M][K], k contiguous, summed over nslab slabs while staged
+    A_F32 = 2,   // fp32 source [M][K], k contiguous, summed over nslab slabs while staged
+    A_F32S = 3   // as A_F32, staged as fp16 hi + lo parts (two MFMAs per fragment: the operand keeps ~22 bits).  Y = X T':
+                 // rounding X to fp16 before the product and Y after it rounds a dominant reflector's contribution twice
 };
 enum EMode {
     E_STORE_F32 = 0,  // C(slab z)[m][n] = alpha*acc          (fp32, split-K slabs)
@@ -47,6 +49,9 @@ struct GemmArgs {
     // of up to 2^-11 on a whole reflector's contribution; with a dominant reflector (non-centred data) that alone moved the
     // backward error of random instances between 6e-4 and 1.2e-3.
     const float* cscale; long cscale_ld;
+    // split fp16 operands (hi + lo = ~22 bits) between the two GEMMs of an update:
+    half_t* C2;          // E_STORE_H16 (256-wide kernels): also store the remainder  fp16(v - fp16(v))  here (same layout as C)
+    const half_t* A2;    // ping-pong kernel: a second A operand (the lo parts) accumulated over the same Bt: C = (A + A2) Bt^T
     int eye_minus;       // E_STORE_F32 (256-wide kernel): store (m == n ? 1 : 0) - alpha*acc  (Q = I - W V^T in one product)
 };
 void launch_gemm_f16(AMode am, EMode em, const GemmArgs& g, hipStream_t s);

@@ -670,7 +670,9 @@ OPT_IN = [
     {"MPQR_ASHADOW": "1"},                         # fp16 shadow of the trailing matrix for the far updates' X = A2^T V
     {"MPQR_QSHADOW": "0", "MPQR_QPAIR": "0"},      # Q formation block by block from the fp32 Q (round-1 form)
     {"MPQR_FUSE_XT": "0", "MPQR_SPLIT_CAP": "64"}, # in-block update with a separate slab sum and small GEMM
-    {"MPQR_X16": "0"},                             # Q formation with an fp32 X between its two GEMMs
+    {"MPQR_XSPLIT": "0"},                          # X rounded once to fp16 between the two GEMMs of an update (round 1)
+    {"MPQR_QSPLIT": "1"},                          # hi + lo parts of X in Q formation as well
+    {"MPQR_X16": "0"},                             # fp32 X through memory, split while staged (gemm2 A_F32S)
     {"MPQR_FAR_PAIR": "0"},                        # far updates block by block (K = outer block) instead of pairwise
     {"MPQR_ASHADOW": "1", "MPQR_FAR_PAIR": "1"},   # pairwise far updates reading the fp16 shadow of the trailing matrix
 ]
