@@ -1136,6 +1136,7 @@ __global__ __launch_bounds__(256) void gh_apply_kernel(LeafArgs a, const float* 
     float* Cs = (float*)gh_smem + 8256;                  // [128][GH_TS], 16-B aligned
     half_t* Ts = (half_t*)gh_smem;                       // [128][72] halves, reuses the As region after the MFMAs
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    KT_DECL; KT();
     if ((int)blockIdx.x >= nlow) {                        // top-block rows: V^T tile straight from the fp16 copy
         const int trow0 = a.c0 + ((int)blockIdx.x - nlow) * 64;
         for (int e = tid; e < GW * 64; e += 256) {
@@ -1164,6 +1165,7 @@ __global__ __launch_bounds__(256) void gh_apply_kernel(LeafArgs a, const float* 
         d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
     }
     __syncthreads();
+    KT();
     floatx16p acc0, acc1;
 #pragma unroll
     for (int e = 0; e < 16; e++) { acc0[e] = 0.f; acc1[e] = 0.f; }
@@ -1183,6 +1185,7 @@ __global__ __launch_bounds__(256) void gh_apply_kernel(LeafArgs a, const float* 
         }
     }
     __syncthreads();                                     // As is dead: reuse as the transpose buffer
+    KT();
     const int gc = a.cb + n0 + r;
     const bool in_leaf = gc >= a.c0 && gc < a.c1;
 #pragma unroll
@@ -1237,7 +1240,9 @@ __global__ __launch_bounds__(256) void gh_apply_kernel(LeafArgs a, const float* 
                 if (row < a.mrows) a.A[(long)row * a.lda + gn] -= (mt == 0 ? u0[e] : u1[e]);
             }
     }
+    KT();
     if (Sp) gh_partial_gram(Ts, Sp + (long)blockIdx.x * (GW * GW), lane, wave);
+    KT();
     // V^T rows: 128 columns x 64 rows of this workgroup, 16-B chunks along the row index
     for (int e = tid; e < GW * 8; e += 256) {
         const int c = e >> 3, ch = e & 7;
@@ -1252,6 +1257,7 @@ __global__ __launch_bounds__(256) void gh_apply_kernel(LeafArgs a, const float* 
             }
         }
     }
+    KT(); KT_DUMP(6, "gh_apply load|mfma|store+next|gram|vt");
 }
 
 // S = sum of nslab fp32 partials (128 x 128), fixed order; same scheme as gh_reduce_kernel
