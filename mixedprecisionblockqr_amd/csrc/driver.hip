@@ -688,7 +688,7 @@ int factor_block_flat(mpqr_handle_t h, int top, const std::vector<int>& leaves) 
             a.Vh = h->Vh; a.ldvh = h->ldvh; a.Vt = h->Vt; a.ldvt = h->ldvt; a.vdiag = h->vdiag;
             a.P = h->P; a.maxwg = h->maxwg; a.Wk = h->Wk;
             launch_leaf_gram_householder(a, h->Gp, h->Gs, h->Cv, h->dflag + (id < h->nflag ? id : 0), h->Sp, nullptr, h->s0);
-            if (h->wait_after_first_leaf) {              // look-ahead: the block's other columns arrive with this event
+            if (h->wait_after_first_leaf && !tq) {       // look-ahead: the block's other columns arrive with this event
                 (void)hipStreamWaitEvent(h->s0, h->wait_after_first_leaf, 0);
                 h->wait_after_first_leaf = nullptr;
             }
@@ -708,6 +708,13 @@ int factor_block_flat(mpqr_handle_t h, int top, const std::vector<int>& leaves) 
         // leaf as well (ext_c1): that leaf then needs nothing from this block's far update and the chain crosses the block
         // boundary without waiting for the block's T and a skinny far update (~350 us per boundary at 16384^2)
         const int upd_end = std::max(tp.c1, h->ext_c1);
+        if (h->wait_after_first_leaf) {
+            // The block's other columns become valid with this event (far update of the previous block).  Only X = C2^T V_j
+            // reads them first, and it runs on the side stream: that stream waits, the chain stream goes on with T_j and
+            // meets the dependency through the X event (the robust leaf path, which works on the chain stream, waits there)
+            (void)hipStreamWaitEvent(tq && !robust_leaf ? h->sT : h->s0, h->wait_after_first_leaf, 0);
+            h->wait_after_first_leaf = nullptr;
+        }
         if (lf.c1 < upd_end) {
             Range rg("mpqr:in_block_update");
             h->op1_stream = tq ? h->sT : nullptr;
