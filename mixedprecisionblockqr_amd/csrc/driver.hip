@@ -297,7 +297,8 @@ int choose_split(int M, int N, int K, size_t cap_elems, long slab) {
     const int tiles = ((M + 127) / 128) * ((N + 127) / 128);
     const int ktiles = K / 64;
     int ns = 1;
-    if (tiles < 128) ns = std::min(ktiles / 2, std::max(1, 512 / tiles));   // >= 2 k-tiles per slice, ~2 workgroups per CU
+    static const int wgs = []() { const char* e = getenv("MPQR_SPLIT_WGS"); return e ? std::max(64, atoi(e)) : 512; }();   // tuning hook
+    if (tiles < 128) ns = std::min(ktiles / 2, std::max(1, wgs / tiles));   // >= 2 k-tiles per slice, ~2 workgroups per CU
     else {
         // large-tile (256 x 256, one workgroup per CU) regime: keep every CU busy when the output has few tiles
         const long t256 = (long)((M + 255) / 256) * ((N + 255) / 256);
