@@ -151,6 +151,7 @@ struct mpqr_handle_s {
     half_t* Qt = nullptr; long ldqt = 0;
     half_t* shadow = nullptr; long ldshadow = 0;      // set by form_q around its applies (apply_node, lane 0)
     bool shadow_write = true;                         // false: this apply still reads the shadow but does not update it
+    int q_ident_cols = 0;                             // form_q: this many leading columns of the apply's range are still identity columns
     // the same for the trailing matrix: At[column][row] = fp16(a_scale * A), written by every far update's epilogue, read by
     // the NEXT far update's X = A2^T V (far update 0 reads the fp32 matrix: nothing has written the shadow yet)
     half_t* At = nullptr; long ldat = 0; bool at_read = false;
@@ -437,7 +438,22 @@ void apply_node(mpqr_handle_t h, const Node& nd, float* C, long ldc, int clo, in
     if (h->shadow && lane == 0 && !far) {                  // fp16 operand, already [column][row]: C2^T = shadow rows
         g1.A = h->shadow + (long)clo_al * h->ldshadow + rlo; g1.lda = h->ldshadow;
         g1.in_scale = 1.f;
-        if (x16) { g1.C = Xhi; g1.C2 = Xlo; gemm_dispatch(A_H16, E_STORE_H16, g1, st1); }   // X leaves as fp16 hi (+ lo)
+        if (x16) {                                          // X leaves as fp16 hi (+ lo)
+            g1.C = Xhi; g1.C2 = Xlo;
+            // backward accumulation: the node's own columns of Q are still columns of the identity, so their rows of
+            // X = Q2^T V are rows of V (exact in fp16): copied, and the GEMM starts behind them
+            const int idc = (h->q_ident_cols > 0 && clo == clo_al && nd.a0 == nd.c0 && rlo == nd.c0 && clo == nd.c0) ?
+                            std::min({h->q_ident_cols, M1 - 256, (nd.c1 - nd.c0) / 256 * 256}) : 0;
+            if (idc >= 256 && (long)((M1 - idc) / 256) * (Kr / 256) >= 48) {   // (the rest still goes to the 256-wide kernel)
+                (void)hipMemcpy2DAsync(Xhi, (size_t)Kr * sizeof(half_t), h->Vh + (long)nd.c0 * h->ldvh + nd.a0, h->ldvh * sizeof(half_t),
+                                       (size_t)Kr * sizeof(half_t), idc, hipMemcpyDeviceToDevice, st1);
+                if (Xlo) (void)hipMemsetAsync(Xlo, 0, (size_t)idc * Kr * sizeof(half_t), st1);
+                g1.A = h->shadow + (long)(clo_al + idc) * h->ldshadow + rlo;
+                g1.C = Xhi + (long)idc * Kr; if (Xlo) g1.C2 = Xlo + (long)idc * Kr;
+                g1.M = M1 - idc;
+            }
+            gemm_dispatch(A_H16, E_STORE_H16, g1, st1);
+        }
         else gemm_dispatch(A_H16, E_STORE_F32, g1, st1);
     } else if (x16) {
         g1.C = Xhi; g1.C2 = Xlo;
@@ -1033,13 +1049,17 @@ int form_q(mpqr_handle_t h) {
         if (h->pairs_ready && t < (int)h->qpair.size() && h->qpair[t] >= 0) {      // two blocks at once, K = 2 outer_block
             const Node& pr = h->nodes[h->qpair[t]];
             h->shadow_write = t - 1 > 0;                    // nobody reads the shadow after the last apply
+            h->q_ident_cols = pr.c1 - pr.c0;
             apply_node(h, pr, h->dQ, h->ldq, pr.c0, h->m, false, 1.f, rec);
+            h->q_ident_cols = 0;
             t--;
             continue;
         }
         const Node& nd = h->nodes[h->tops[t]];
         h->shadow_write = t > 0;
+        h->q_ident_cols = nd.c1 - nd.c0;
         apply_node(h, nd, h->dQ, h->ldq, nd.c0, h->m, false, 1.f, rec);
+        h->q_ident_cols = 0;
     }
     h->shadow = nullptr;
     h->q_formed = true;
