@@ -15,12 +15,12 @@
 // Reductions: 8-lane row groups -> DPP/xor shuffles across the wave64 -> LDS across the 4 waves
 // -> per-workgroup partial in HBM, summed by every workgroup of the next launch.
 #include "mpqr_internal.h"
+#include "panel_dev.h"
 
 namespace mpqr {
 
 constexpr int RPW = 256;   // rows per workgroup
 
-extern __shared__ __attribute__((aligned(16))) char gh_smem[];   // dynamic LDS of the kernels that need > 64 KiB
 
 __device__ __forceinline__ float pick(const float4& v, int c) {
     return c == 0 ? v.x : (c == 1 ? v.y : (c == 2 ? v.z : v.w));
@@ -286,21 +286,6 @@ __global__ __launch_bounds__(1024) void leaf_wg_kernel(LeafArgs a) {
 // No pass over the tall data is sequential in k.  V differs from Householder's by O(2^-24 / sqrt(rho)); a leaf
 // with rho < GH_RHO_MIN or a column that cannot be reflected raises a flag and the driver redoes the work on the
 // column-by-column kernels above.
-// optional in-kernel phase timing (make EXTRA=-DMPQR_KTRACE): thread 0 of block 0 stamps s_memtime at phase
-// boundaries and prints the deltas for the first few launches of each kernel
-#ifdef MPQR_KTRACE
-__device__ int g_ktrace_left[8] = {3, 3, 3, 3, 3, 3, 3, 3};
-#define KT_DECL long kt_[16]; int kn_ = 0; const bool kon_ = (threadIdx.x == 0 && blockIdx.x == 0)
-#define KT() do { if (kon_ && kn_ < 16) kt_[kn_++] = clock64(); } while (0)
-#define KT_DUMP(id, name) do { if (kon_ && atomicSub(&g_ktrace_left[id], 1) > 0) { printf("ktrace %s:", name); \
-    for (int q_ = 1; q_ < kn_; q_++) printf(" %ld", kt_[q_] - kt_[q_ - 1]); printf("\n"); } } while (0)
-#else
-#define KT_DECL
-#define KT() do {} while (0)
-#define KT_DUMP(id, name) do {} while (0)
-#endif
-constexpr double GH_RHO_MIN = 1e-8;
-constexpr int GW = 128;          // window width
 constexpr int GH_TS = 132;       // LDS row stride (floats) of a staged 128-column tile
 constexpr int GH_ROWS = 128;     // rows per workgroup in gh_gram
 
@@ -403,130 +388,6 @@ __global__ __launch_bounds__(256) void gh_reduce_kernel(const double* __restrict
     }
 }
 
-// 1/sqrt(x) in fp64 from an fp32 seed and two Newton steps (2^-23 -> 2^-46 -> 2^-92); x outside the fp32 range
-// takes the library path
-__device__ __forceinline__ double refine_rsqrt(double x, double y) {
-    y = y * fma(-0.5 * x, y * y, 1.5);
-    y = y * fma(-0.5 * x, y * y, 1.5);
-    return y;
-}
-__device__ __forceinline__ double fast_rsqrt(double x) {
-    if (!(x > 1e-30 && x < 1e30)) return 1.0 / sqrt(x);
-    return refine_rsqrt(x, (double)rsqrtf((float)x));
-}
-
-typedef float floatx16p __attribute__((ext_vector_type(16)));
-constexpr int TP = 128, TPS = 129;
-
-// 32 x 32 tile of A (32 x K, LDS) * B (K x 32, LDS) on the exact-f32 MFMA; odd row strides: conflict-free
-// k runs over [klo, khi), both multiples of 16 (callers skip the zero part of triangular factors)
-__device__ __forceinline__ floatx16p lds_mm32(const float* A, int lda, const float* B, int ldb, int klo, int khi, int lane) {
-    const int r = lane & 31, kk = lane >> 5;
-    floatx16p acc;
-#pragma unroll
-    for (int e = 0; e < 16; e++) acc[e] = 0.f;
-    for (int k1 = klo; k1 < khi; k1 += 16) {             // 8 steps' LDS reads in flight together
-        float av[8], bv[8];
-#pragma unroll
-        for (int u = 0; u < 8; u++) { av[u] = A[r * lda + k1 + 2 * u + kk]; bv[u] = B[(k1 + 2 * u + kk) * ldb + r]; }
-#pragma unroll
-        for (int u = 0; u < 8; u++) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u], bv[u], acc, 0, 0, 0);
-    }
-    return acc;
-}
-__device__ __forceinline__ void lds_store32(float* C, int ldc, const floatx16p& acc, float scale, int lane) {
-    const int r = lane & 31, kk = lane >> 5;
-#pragma unroll
-    for (int e = 0; e < 16; e++) C[((e & 3) + 8 * (e >> 2) + 4 * kk) * ldc + r] = scale * acc[e];
-}
-
-// Ts = X^{-1} for the upper-triangular X = striu(Ss) + diag(1 / tdiag), 128 x 128 in LDS (stride TPS), Ts zero on
-// entry.  nblk = active 32-blocks.  Diagonal blocks: row a of the inverse depends on row a only, lane a runs the
-// column recurrence in registers.  Then two merge levels X_LR -> -T_L (X_LR T_R) on the MFMA; the intermediate
-// product overwrites X_LR in Ss, so the lower triangle of Ts stays zero.  Needs >= 4 waves; ends with a barrier.
-__device__ __forceinline__ void tri_inverse_128(float* Ss, const float* tdiag, float* Ts, int nblk, int tid) {
-    const int wave = tid >> 6, lane = tid & 63;
-#ifdef MPQR_KTRACE
-    long ti_[8]; int tn_ = 0;
-    if (tid == 0 && blockIdx.x == 0) ti_[tn_++] = clock64();
-#endif
-    // diagonal 16 x 16 blocks: row a of the inverse depends on row a only -- lane a runs the column recurrence in registers
-    // (eight blocks: two per wave, one per half of the first 32 lanes ... of waves 0-3)
-    if (wave < nblk && lane < 32) {
-        const int base = 32 * wave + 16 * (lane >> 4), a = lane & 15;
-        float tr[16];
-#pragma unroll
-        for (int i = 0; i < 16; i++) {
-            const float tii = tdiag[base + i];
-            float ps[4] = {0.f, 0.f, 0.f, 0.f};            // four partial sums: a quarter of the dependent chain
-#pragma unroll
-            for (int q = 0; q < i; q++) ps[q & 3] += tr[q] * Ss[(base + q) * TPS + base + i];
-            const float sum = (ps[0] + ps[1]) + (ps[2] + ps[3]);
-            tr[i] = (a < i) ? -tii * sum : (a == i ? tii : 0.f);
-        }
-#pragma unroll
-        for (int i = 0; i < 16; i++) Ts[(base + a) * TPS + base + i] = tr[i];
-    }
-    __syncthreads();
-    // 16 -> 32 inside every 32-block (one wave each): with L / R the two halves, T_LR = -T_L (S_LR T_R).  On 32 x 32 tiles:
-    // rows < 16 of  S_blk[:, 16:32] T_blk[16:32, :]  (k range 16..32) are S_LR T_R in the columns >= 16; it replaces S_LR,
-    // then rows < 16 of  T_blk[:, 0:16] (that)[0:16, :]  (k range 0..16) are T_L (S_LR T_R).
-    {
-        const bool has = wave < nblk;
-        const int base = 32 * wave, r = lane & 31, kk = lane >> 5;
-        floatx16p acc;
-        if (has) acc = lds_mm32(&Ss[base * TPS + base], TPS, &Ts[base * TPS + base], TPS, 16, 32, lane);
-        __syncthreads();
-        if (has && r >= 16) {
-#pragma unroll
-            for (int e = 0; e < 16; e++) {
-                const int i = (e & 3) + 8 * (e >> 2) + 4 * kk;
-                if (i < 16) Ss[(base + i) * TPS + base + r] = acc[e];
-            }
-        }
-        __syncthreads();
-        if (has) {
-            acc = lds_mm32(&Ts[base * TPS + base], TPS, &Ss[base * TPS + base], TPS, 0, 16, lane);
-            if (r >= 16) {
-#pragma unroll
-                for (int e = 0; e < 16; e++) {
-                    const int i = (e & 3) + 8 * (e >> 2) + 4 * kk;
-                    if (i < 16) Ts[(base + i) * TPS + base + r] = -acc[e];
-                }
-            }
-        }
-        __syncthreads();
-    }
-#ifdef MPQR_KTRACE
-    if (tid == 0 && blockIdx.x == 0) ti_[tn_++] = clock64();
-#endif
-    for (int half = 32; half < 32 * nblk; half *= 2) {
-        const int ts = half / 32, npair = TP / (2 * half);
-        const bool has = wave < npair * ts * ts;
-        const int p = wave / (ts * ts), t = wave % (ts * ts), bi = t / ts, bj = t % ts;
-        const int L0 = p * 2 * half, R0 = L0 + half;
-        floatx16p acc;
-        if (has) acc = lds_mm32(&Ss[(L0 + 32 * bi) * TPS + R0], TPS, &Ts[R0 * TPS + R0 + 32 * bj], TPS, 0, 32 * (bj + 1), lane);   // T_R upper
-        __syncthreads();
-        if (has) lds_store32(&Ss[(L0 + 32 * bi) * TPS + R0 + 32 * bj], TPS, acc, 1.f, lane);
-        __syncthreads();
-        if (has) {
-            acc = lds_mm32(&Ts[(L0 + 32 * bi) * TPS + L0], TPS, &Ss[L0 * TPS + R0 + 32 * bj], TPS, 32 * bi, half, lane);   // T_L upper
-            lds_store32(&Ts[(L0 + 32 * bi) * TPS + R0 + 32 * bj], TPS, acc, -1.f, lane);
-        }
-        __syncthreads();
-#ifdef MPQR_KTRACE
-        if (tid == 0 && blockIdx.x == 0 && tn_ < 8) ti_[tn_++] = clock64();
-#endif
-    }
-#ifdef MPQR_KTRACE
-    if (tid == 0 && blockIdx.x == 0 && atomicSub(&g_ktrace_left[4], 1) > 0) {
-        printf("ktrace tri_inverse diag|merge32|merge64:");
-        for (int q = 1; q < tn_; q++) printf(" %ld", ti_[q] - ti_[q - 1]);
-        printf("\n");
-    }
-#endif
-}
 
 // 768 threads.  Waves 0-7 ("update", a 16 x 32 grid): thread (ti,tj) keeps the CYCLIC entries {ti + 16x} x {tj + 32y},
 // x < 8, y < 4, of B_top (fp32) and of N (fp64) in registers.  N is symmetric and only rows <= columns are ever
@@ -805,15 +666,6 @@ __global__ __launch_bounds__(GH_SOLVE_THREADS) void gh_solve_kernel(LeafArgs a, 
 // else is a small matrix product.  One workgroup of 1024 threads; LDS: the fp64 Gram matrix during step 1, two fp32
 // 128 x 129 matrices afterwards; Cc and Cc^-1 are parked in a global scratch (2 x 64 KiB, L2 resident).
 constexpr int GD = 130;                                   // LDS row stride (doubles) of the Gram matrix
-__device__ __forceinline__ double bcast_lane_d(double v, int srclane) {
-    const long b = __builtin_bit_cast(long, v);
-    const int lo = __builtin_amdgcn_readlane((int)(b & 0xffffffffL), srclane);
-    const int hi = __builtin_amdgcn_readlane((int)(b >> 32), srclane);
-    return __builtin_bit_cast(double, ((long)hi << 32) | ((long)lo & 0xffffffffL));
-}
-__device__ __forceinline__ float bcast_lane_f(float v, int srclane) {
-    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), srclane));
-}
 // 32 x 32 tile product as lds_mm32, but k runs over [0, kn) in steps of 2 (kn even, any multiple of 2)
 __device__ __forceinline__ floatx16p lds_mm32_k(const float* A, int lda, const float* B, int ldb, int kn, int lane) {
     const int r = lane & 31, kk = lane >> 5;
@@ -1602,6 +1454,10 @@ void launch_gh_solve(const LeafArgs& a, const double* G, float* Cv, int* flag, h
     // gh_solve2 (blocked Householder reconstruction) is correct but measured SLOWER than the step-by-step kernel at w = 128
     // (162 vs 111 us: ~500 cycles per column for the fp64 in-wave Cholesky, ~300 for the LU, plus two triangular inverses
     // -- in-kernel stamps, make EXTRA=-DMPQR_KTRACE): opt-in only
+    // gh_solve3 (kernels_solve.hip): the same recursion blocked by 16, chains in single waves (bit-identical outputs on the
+    // harness tools/test_solve3.hip); MPQR_SOLVE3=0 selects the step-by-step kernel below
+    static const int solve3 = []() { const char* e = getenv("MPQR_SOLVE3"); return e ? atoi(e) : 1; }();
+    if (solve3) { launch_gh_solve3(a, G, Cv, flag, s); return; }
     static const int solve2 = []() { const char* e = getenv("MPQR_SOLVE2"); return e ? atoi(e) : 0; }();
     if (solve2 && a.Wk) hipLaunchKernelGGL(gh_solve2_kernel, dim3(1), dim3(1024), GW * GD * 8, s, a, G, Cv, flag, a.Wk);
     else hipLaunchKernelGGL(gh_solve_kernel, dim3(1), dim3(GH_SOLVE_THREADS), 2 * TP * TPS * 4, s, a, G, Cv, flag);

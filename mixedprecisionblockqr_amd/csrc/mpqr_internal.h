@@ -108,6 +108,8 @@ int gh_num_partials(const LeafArgs& a);
 void launch_gh_gram(const LeafArgs& a, double* Gp, double* G, hipStream_t s);
 void launch_gh_solve(const LeafArgs& a, const double* G, float* Cv, int* flag, hipStream_t s);
 void launch_gh_apply(const LeafArgs& a, const float* Cv, float* Sp, const float* Yg /* or nullptr */, hipStream_t s);
+// blocked form of gh_solve (kernels_solve.hip): same inputs and outputs
+void launch_gh_solve3(const LeafArgs& a, const double* G, float* Cv, int* flag, hipStream_t s);
 // look-ahead inputs: rows >= r0 of the 256 columns [cx, cx+256): G2 = [A_x^T A_d | A_d^T A_d] (2 x 16384 doubles);
 // Gp2: max_wg x 32768 doubles of partials
 void launch_gh_pair_gram(const float* A, long lda, int mrows, int r0, int cx, double* Gp2, int max_wg, double* G2, hipStream_t s);
