@@ -534,9 +534,45 @@ __global__ __launch_bounds__(S3_THREADS) void gh_solve3_kernel(LeafArgs a, const
                 }
             }
         };
+        // V_top of block b (Ws[i][k], i > k; diagonal in vdl): A below the diagonal, the fp16 copies V and V^T -- one round after
+        // the Householder waves finished the block, 16-byte stores where the leaf is 8-aligned (else: after the loop, all threads)
+        const bool vec_out = (w & 7) == 0 && (a.c0 & 7) == 0;
+        auto store_v = [&](int b) {
+            typedef half_t half4v __attribute__((ext_vector_type(4)));
+            typedef half_t half8v __attribute__((ext_vector_type(8)));
+            if (!vec_out) return;
+            {
+                const int id = u * 64 + lane, i = 16 * b + (id >> 2), k = 16 * b + 4 * (id & 3);   // 4 consecutive k: a row segment of A and Vh
+                if (i < w && k < w && i >= k) {
+                    float t4[4]; half4v hv;
+#pragma unroll
+                    for (int q = 0; q < 4; q++) t4[q] = Ws[i * TPS + k + q];
+                    float* dst = &a.A[(long)(a.c0 + i) * a.lda + a.c0 + k];
+                    if (i > k + 3) *(float4*)dst = make_float4(t4[0], t4[1], t4[2], t4[3]);
+                    else {
+#pragma unroll
+                        for (int q = 0; q < 4; q++) if (i > k + q) dst[q] = t4[q];
+                    }
+                    const float vd = vdl[i];
+#pragma unroll
+                    for (int q = 0; q < 4; q++) hv[q] = i > k + q ? (half_t)t4[q] : (i == k + q ? (half_t)vd : (half_t)0.f);
+                    *(half4v*)&a.Vh[(long)(a.c0 + i) * a.ldvh + a.c0 + k] = hv;
+                }
+            }
+            if (u < 4) {
+                const int id = u * 64 + lane, k = 16 * b + (id >> 4), i = 8 * (id & 15);            // 8 consecutive i: a row segment of V^T
+                if (k < w && i < w && i + 7 >= k) {
+                    half8v hv;
+                    const float vd = vdl[k];
+#pragma unroll
+                    for (int q = 0; q < 8; q++) hv[q] = (i + q > k) ? (half_t)Ws[(i + q) * TPS + k] : (i + q == k ? (half_t)vd : (half_t)0.f);
+                    *(half8v*)&a.Vt[(long)(a.c0 + k) * a.ldvt + a.c0 + i] = hv;
+                }
+            }
+        };
         for (int r = 0; r <= nb; r++) {
             if (u == 7) S3T(3, 4 * r);
-            if (r >= 2) store_r(16 * (r - 2) + 2 * u);
+            if (r >= 2) { store_r(16 * (r - 2) + 2 * u); store_v(r - 2); }
             // ---- segment 1: the updates nobody is waiting for
 #ifndef S3_DBG_NOUPD
             if (r >= 1 && r + 1 < nb) {                    // Cholesky block r-1 onto the tiles below the next panel
@@ -598,42 +634,13 @@ __global__ __launch_bounds__(S3_THREADS) void gh_solve3_kernel(LeafArgs a, const
             s3_barrier();
         }
         store_r(16 * (nb - 1) + 2 * u);
+        store_v(nb - 1);
     }
     __builtin_amdgcn_s_setprio(0);
     KT();
     // ------------------------------------------------ outputs.  R went out row by row (Householder wave); V_top sits in the
     // lower triangle of Ws (Ws[i][k] = v_top^(k)[i], i > k), the diagonal entries in vdl.
-    if ((w & 7) == 0 && (a.c0 & 7) == 0) {                 // usual case: 16-byte stores
-        typedef half_t half4v __attribute__((ext_vector_type(4)));
-        typedef half_t half8v __attribute__((ext_vector_type(8)));
-        for (int e = tid; e < GW * (GW / 4); e += S3_THREADS) {
-            const int i = e >> 5, k = (e & 31) * 4;           // 4 consecutive k: a row segment of A and Vh
-            if (i < w && k < w && i >= k) {
-                float t4[4]; half4v hv;
-#pragma unroll
-                for (int q = 0; q < 4; q++) t4[q] = Ws[i * TPS + k + q];
-                float* dst = &a.A[(long)(a.c0 + i) * a.lda + a.c0 + k];
-                if (i > k + 3) *(float4*)dst = make_float4(t4[0], t4[1], t4[2], t4[3]);
-                else {
-#pragma unroll
-                    for (int q = 0; q < 4; q++) if (i > k + q) dst[q] = t4[q];
-                }
-                const float vd = vdl[i];
-#pragma unroll
-                for (int q = 0; q < 4; q++) hv[q] = i > k + q ? (half_t)t4[q] : (i == k + q ? (half_t)vd : (half_t)0.f);
-                *(half4v*)&a.Vh[(long)(a.c0 + i) * a.ldvh + a.c0 + k] = hv;
-            }
-        }
-        for (int e = tid; e < GW * (GW / 8); e += S3_THREADS) {
-            const int k = e >> 4, i = (e & 15) * 8;           // 8 consecutive i: a row segment of V^T
-            if (k < w && i < w && i + 7 >= k) {
-                half8v hv;
-                const float vd = vdl[k];
-#pragma unroll
-                for (int q = 0; q < 8; q++) hv[q] = (i + q > k) ? (half_t)Ws[(i + q) * TPS + k] : (i + q == k ? (half_t)vd : (half_t)0.f);
-                *(half8v*)&a.Vt[(long)(a.c0 + k) * a.ldvt + a.c0 + i] = hv;
-            }
-        }
+    if ((w & 7) == 0 && (a.c0 & 7) == 0) {                 // usual case: the update waves sent V_top out block by block
     } else {
         for (int e = tid; e < GW * GW; e += S3_THREADS) {
             const int i = e >> 7, k = e & 127;
