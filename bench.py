@@ -95,6 +95,7 @@ def main():
     ap.add_argument("--config", default="c4", choices=sorted(CONFIGS))
     ap.add_argument("--outer-block", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-dropin", action="store_true", help="skip the PCIe-inclusive timing of the drop-in call (dropin_ms)")
     ap.add_argument("--no-lookahead", action="store_true")
     ap.add_argument("--precision", default=None, choices=["fp16", "fp8", "fp32"],
                     help="operand precision of the trailing-update GEMMs (default: fp8 for c5 = BASELINE config 5, fp16 otherwise)")
@@ -144,6 +145,9 @@ def main():
     dt = (time.perf_counter() - t0) / args.steps
 
     fl = mp.flops(m, n, r)
+    # the serial core of one leaf (gh_solve: one workgroup on 1 of 256 CUs) timed alone; x the number of such leaves = the part
+    # of the panel chain no other kernel can overlap (breakdown_ms.ms_gh_solve)
+    us_solve = h.bench_leaf_solve(min(r, 128), 50) if prec_name != "fp32" else 0.0
     tm = h.timings()                      # HIP-event timings of the LAST step, on the library's own stream
     mt = h.metrics()
     # dominant kernel: the far trailing-update GEMM  A2 -= V Y^T  (fp16 MFMA, K = outer block); achieved =
@@ -179,6 +183,14 @@ def main():
         # read + write, the fp16 shadow where it is written, both fp16 operands once)
         nl = tm["n_far_launches"] + (tm.get("n_q_launches", 0) if q_nn else 0)
         roof["algorithmic_bytes_per_launch"] = ((tm["gbytes_far_nn"] + (tm["gbytes_q_nn"] if q_nn else 0.0)) * 1e9 / nl) if nl else None
+    # The panel step against the HBM roof (algorithmic bytes per panel = 2 W r 4, each panel read and written once):
+    # the critical path of the factorisation, latency bound -- the fraction says how far from a bandwidth-bound panel it is
+    pbytes = sum(2.0 * (m - lam) * min(r, n - lam) * 4 for lam in range(0, n, r))
+    if roof is not None and tm["ms_panel"] > 0:
+        roof["panel"] = {"bound": "hbm", "kernels": "gh_gram / gh_reduce / gh_solve3 / gh_apply / t_panel / leaf_xt + in-block updates (the chain stream)",
+                         "algorithmic_bytes": pbytes, "ms": tm["ms_panel"], "achieved": pbytes / (tm["ms_panel"] * 1e-3) / 1e9,
+                         "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": pbytes / (tm["ms_panel"] * 1e-3) / 1e9 / PEAK_HBM_GBPS,
+                         "us_gh_solve_per_leaf": us_solve, "n_gh_leaves": tm["n_gh_leaves"]}
     out = {
         "metric": "GFLOP/s block QR (%s MFMA trailing)" % prec_name, "value": fl["geqrf"] / dt / 1e9, "unit": "GFLOP/s",
         "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt * 1e3,
@@ -190,12 +202,26 @@ def main():
                    "outer_block": args.outer_block or 1024, "parallelism": "1 gpu"},
         "error": {"backward_error": mt["backward_error"], "q_error_fro": mt["q_error_fro"],
                   "q_error_max_signed": mt["q_error_max_signed"]},
-        "breakdown_ms": {k: tm[k] for k in ("ms_total", "ms_factor", "ms_form_q", "ms_trailing", "ms_panel", "ms_chain_wait",
-                                            "ms_far_tn", "ms_far_nn", "ms_q_tn", "ms_q_nn", "ms_host_enqueue", "n_passes", "n_robust_leaves")},
+        "breakdown_ms": dict({k: tm[k] for k in ("ms_total", "ms_factor", "ms_form_q", "ms_trailing", "ms_panel", "ms_chain_wait",
+                                                 "ms_far_tn", "ms_far_nn", "ms_q_tn", "ms_q_nn", "ms_host_enqueue", "n_passes", "n_robust_leaves")},
+                             ms_gh_solve=tm["n_gh_leaves"] * us_solve * 1e-3),
         "gflops_with_q_flops": (fl["geqrf"] + fl["form_q"]) / dt / 1e9,
         "gflops_reference_formula": (4.0 * m * m * n - m * n * n + n ** 3 / 3.0) / dt / 1e9,
         "roofline": roof,
     }
+    if not args.no_dropin and 4.0 * m * m <= 4e9:          # (config 5's 17 GB host Q is left out)
+        # the drop-in call itself (host pointers in, host Q and R out: the contract of qr.cu:1049-1226), PCIe inclusive; never `value`
+        import numpy as np
+        Ah = np.zeros((m + 1, n), np.float32)
+        Ah[:m] = np.random.default_rng(1234).random((m, n), dtype=np.float32)
+        Qh = np.zeros((m, m), np.float32)
+        A1 = Ah.copy()
+        mp.dev_mixed_precision_block_qr(A1, Qh, m, n, r, handle=h, outer_block=args.outer_block, lookahead=not args.no_lookahead)   # warm-up: pins, plans
+        A1[:] = Ah
+        t0 = time.perf_counter()
+        mp.dev_mixed_precision_block_qr(A1, Qh, m, n, r, handle=h, outer_block=args.outer_block, lookahead=not args.no_lookahead)
+        out["dropin_ms"] = (time.perf_counter() - t0) * 1e3
+        del Ah, Qh, A1
     if not args.no_cpu_baseline:
         out["cpu_baseline"], port = cpu_baseline()
         if port is not None:

@@ -92,6 +92,8 @@ typedef struct mpqr_timings {
     float ms_host_enqueue;/* host time to enqueue the factorisation's launches (before its one synchronisation)    */
     double gbytes_far_nn; /* algorithmic HBM bytes (1e9) of the far A2 -= V Y^T launches: fp32 C read + write, fp16 operands once */
     double gbytes_q_nn;   /* the same for Q formation's Q2 -= V Y^T launches (+ the fp16 shadow they write)          */
+    int   n_gh_leaves;    /* Gram-Householder leaves (gram / solve / apply launches) of the last block-loop pass     */
+    float us_gh_solve;    /* one gh_solve launch at this plan's leaf width, timed alone (mpqr_bench_leaf_solve; 0 = not measured) */
 } mpqr_timings;
 
 typedef struct mpqr_handle_s* mpqr_handle_t;
@@ -133,6 +135,10 @@ int mpqr_generate_matrix(mpqr_handle_t h, uint64_t seed);
 int mpqr_factor(mpqr_handle_t h);
 int mpqr_sync(mpqr_handle_t h);
 int mpqr_get_timings(mpqr_handle_t h, mpqr_timings* t);
+/* measurement aid (bench.py: breakdown_ms.ms_gh_solve = n_gh_leaves x this): launches the serial core of a Gram-Householder leaf
+ * (the w x w solve, one workgroup) `iters` times on scratch data and returns the mean launch time in microseconds; the value is
+ * also reported by later mpqr_get_timings calls.  Replaces nothing in the reference (its panel runs on the host, qr.cu:1080). */
+int mpqr_bench_leaf_solve(mpqr_handle_t h, int w, int iters, float* us_per_launch);
 /* results: A_out is (m+1) x n in the reference's shifted-reflector layout, Q is m x m */
 int mpqr_get_factor_host(mpqr_handle_t h, float* A_out);
 int mpqr_get_q_host(mpqr_handle_t h, float* Q);

@@ -32,7 +32,8 @@ class MpqrTimings(C.Structure):
                 ("ms_far_nn", C.c_float), ("n_far_launches", C.c_int), ("flops_far_tn", C.c_double),
                 ("flops_far_nn", C.c_double), ("ms_chain_wait", C.c_float), ("n_passes", C.c_int),
                 ("n_robust_leaves", C.c_int), ("ms_q_tn", C.c_float), ("ms_q_nn", C.c_float), ("n_q_launches", C.c_int),
-                ("tflop_q", C.c_float), ("ms_host_enqueue", C.c_float), ("gbytes_far_nn", C.c_double), ("gbytes_q_nn", C.c_double)]
+                ("tflop_q", C.c_float), ("ms_host_enqueue", C.c_float), ("gbytes_far_nn", C.c_double), ("gbytes_q_nn", C.c_double),
+                ("n_gh_leaves", C.c_int), ("us_gh_solve", C.c_float)]
 
 
 def build(force=False):
@@ -65,6 +66,7 @@ SIGNATURES = {
     "mpqr_factor": (_i, [_H]),
     "mpqr_sync": (_i, [_H]),
     "mpqr_get_timings": (_i, [_H, C.POINTER(MpqrTimings)]),
+    "mpqr_bench_leaf_solve": (_i, [_H, _i, _i, C.POINTER(C.c_float)]),
     "mpqr_get_factor_host": (_i, [_H, _f32]),
     "mpqr_get_q_host": (_i, [_H, _f32]),
     "mpqr_get_r_host": (_i, [_H, _f32]),

@@ -76,6 +76,12 @@ class Handle:
         self._chk(L.lib().mpqr_get_timings(self._h, C.byref(t)))
         return {k: getattr(t, k) for k, _ in L.MpqrTimings._fields_ if k != "reserved"}
 
+    def bench_leaf_solve(self, w=128, iters=50):
+        """Mean launch time (us) of the serial core of one Gram-Householder leaf of width w, timed alone."""
+        us = C.c_float()
+        self._chk(L.lib().mpqr_bench_leaf_solve(self._h, w, iters, C.byref(us)))
+        return us.value
+
     def factor_out(self):
         out = np.empty((self.m + 1, self.n), np.float32)
         self._chk(L.lib().mpqr_get_factor_host(self._h, out))

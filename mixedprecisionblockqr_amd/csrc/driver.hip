@@ -122,6 +122,8 @@ struct mpqr_handle_s {
     std::vector<char> leaf_robust;   // per tree node: this tall leaf was flagged by gh_solve and takes the robust path
     int nflag = 0;                // ints in dflag: one flag per tree node (gh_solve raises dflag[node id])
     int n_passes = 0, n_robust_leaves = 0;   // of the last mpqr_factor
+    int n_gh_leaves = 0;                     // Gram-Householder leaves launched by the last block-loop pass
+    float us_gh_solve = 0.f;                 // mpqr_bench_leaf_solve's last result
     float* rbTf = nullptr; half_t* rbTh = nullptr; half_t* rbTth = nullptr; size_t rb_elems = 0;   // T arena of a robust leaf's sub-tree
     bool force32 = false;         // tree building: only 32-column leaves (sub-tree of a robustly factored tall leaf)
     int gh_min_rows = 128;        // leaves with more rows than this below their first column use Gram-Householder
@@ -568,7 +570,7 @@ int factor_rec(mpqr_handle_t h, int id, bool do_panel) {
             a.P = h->P; a.maxwg = h->maxwg; a.Wk = h->Wk;
             const bool fused = tall && !h->Vf;    // fp16 mode: the Gram of the rounded reflectors comes out of gh_apply
             int* flag = h->dflag + (id < h->nflag ? id : 0);
-            if (tall) launch_leaf_gram_householder(a, h->Gp, h->Gs, h->Cv, flag, fused ? h->Sp : nullptr, nullptr, h->s0);
+            if (tall) { launch_leaf_gram_householder(a, h->Gp, h->Gs, h->Cv, flag, fused ? h->Sp : nullptr, nullptr, h->s0); h->n_gh_leaves++; }
             else launch_leaf_factor(a, h->s0);
             if (h->Vf) launch_extract_vf(h->Aeff, h->lda, h->vdiag, h->Vf, h->n_pad, h->m, nd.c0, nd.c1, h->s0);
             have_s = fused;
@@ -705,6 +707,7 @@ int factor_block_flat(mpqr_handle_t h, int top, const std::vector<int>& leaves) 
             a.Vh = h->Vh; a.ldvh = h->ldvh; a.Vt = h->Vt; a.ldvt = h->ldvt; a.vdiag = h->vdiag;
             a.P = h->P; a.maxwg = h->maxwg; a.Wk = h->Wk;
             launch_leaf_gram_householder(a, h->Gp, h->Gs, h->Cv, h->dflag + (id < h->nflag ? id : 0), h->Sp, nullptr, h->s0);
+            h->n_gh_leaves++;
             if (h->wait_after_first_leaf && !tq) {       // look-ahead: the block's other columns arrive with this event
                 (void)hipStreamWaitEvent(h->s0, h->wait_after_first_leaf, 0);
                 h->wait_after_first_leaf = nullptr;
@@ -1610,6 +1613,7 @@ int mpqr_factor(mpqr_handle_t h) {
     h->n_passes = 0;
     for (int pass = 0; pass < 5; pass++) {
         h->n_passes++;
+        h->n_gh_leaves = 0;
         if ((rc = run_block_loop(h, flags))) return rc;
         int fresh = 0;
         for (size_t id = 0; id < flags.size(); id++)
@@ -1680,8 +1684,48 @@ int mpqr_get_timings(mpqr_handle_t h, mpqr_timings* t) {
     t->ms_chain_wait = t->ms_factor - ch;
     t->n_passes = h->n_passes;
     t->n_robust_leaves = h->n_robust_leaves;
+    t->n_gh_leaves = h->n_gh_leaves;
+    t->us_gh_solve = h->us_gh_solve;
     h->last_t = *t;
     return MPQR_OK;
+}
+
+// measurement aid: the serial core of a Gram-Householder leaf (gh_solve, one workgroup) timed alone on scratch data -- an
+// identity-dominated Gram matrix and a unit top block; the kernel's instruction stream does not depend on the values.
+int mpqr_bench_leaf_solve(mpqr_handle_t h, int w, int iters, float* us_per_launch) {
+    if (!h || !us_per_launch || w < 1 || w > 128 || iters < 1) return MPQR_ERR_INVALID;
+    HIPCHK(h, hipSetDevice(h->device));
+    const int lda = 128;
+    std::vector<double> G(128 * 128, 0.25);
+    std::vector<float> B(128 * lda, 0.125f);
+    for (int i = 0; i < 128; i++) { G[i * 128 + i] = 1000.0; B[i * lda + i] = 1.f; }
+    double* dG = nullptr; float *dA = nullptr, *dCv = nullptr, *dvd = nullptr; half_t *dVh = nullptr, *dVt = nullptr; int* dfl = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    int rc = MPQR_OK;
+    auto bad = [&](hipError_t e) { if (e != hipSuccess && rc == MPQR_OK) rc = fail(h, MPQR_ERR_HIP, hipGetErrorString(e)); return e != hipSuccess; };
+    if (!bad(hipMalloc(&dG, G.size() * 8)) && !bad(hipMalloc(&dA, B.size() * 4)) && !bad(hipMalloc(&dCv, 128 * 128 * 4)) &&
+        !bad(hipMalloc(&dvd, 128 * 4)) && !bad(hipMalloc(&dVh, 128 * lda * 2)) && !bad(hipMalloc(&dVt, 128 * lda * 2)) &&
+        !bad(hipMalloc(&dfl, 4)) && !bad(hipEventCreate(&e0)) && !bad(hipEventCreate(&e1)) &&
+        !bad(hipMemcpy(dG, G.data(), G.size() * 8, hipMemcpyHostToDevice)) && !bad(hipMemset(dfl, 0, 4))) {
+        LeafArgs a{};
+        a.A = dA; a.lda = lda; a.mrows = 128; a.cb = 0; a.c0 = 0; a.c1 = w;
+        a.Vh = dVh; a.ldvh = lda; a.Vt = dVt; a.ldvt = lda; a.vdiag = dvd;
+        float ms = 0.f;
+        for (int it = -2; it < iters && rc == MPQR_OK; it++) {        // two warm-up launches; the top block is an input AND an output
+            if (bad(hipMemcpyAsync(dA, B.data(), B.size() * 4, hipMemcpyHostToDevice, h->s0))) break;
+            if (bad(hipEventRecord(e0, h->s0))) break;
+            launch_gh_solve(a, dG, dCv, dfl, h->s0);
+            if (bad(hipEventRecord(e1, h->s0)) || bad(hipStreamSynchronize(h->s0))) break;
+            float x = 0.f;
+            if (bad(hipEventElapsedTime(&x, e0, e1))) break;
+            if (it >= 0) ms += x;
+        }
+        if (rc == MPQR_OK) { h->us_gh_solve = ms * 1000.f / iters; *us_per_launch = h->us_gh_solve; }
+    }
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    (void)hipFree(dG); (void)hipFree(dA); (void)hipFree(dCv); (void)hipFree(dvd); (void)hipFree(dVh); (void)hipFree(dVt); (void)hipFree(dfl);
+    return rc;
 }
 
 // any Gram-Householder flag raised since the last clear?  (synchronises the chain stream)
