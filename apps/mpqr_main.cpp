@@ -6,7 +6,7 @@
 // for f in { householder + backward accumulation, fp32 block QR, mixed-precision block QR }, printing the three
 // error lines and appending the reference's CSV log rows (log/cpu_householder.txt, log/gpu_block.txt).
 //
-//   usage: mpqr_main [--jacobians DIR] [--m M --n N --r R] [--seed S] [--dtype fp16|fp32|fp8] [--gpus N]
+//   usage: mpqr_main [--jacobians DIR [--skip-random]] [--m M --n N --r R] [--seed S] [--dtype fp16|fp32|fp8] [--gpus N]
 //   --gpus N (with --m --n --r): the multi-GPU host driver -- one host thread per GPU of this node, column superblocks dealt
 //            round-robin (mpqr_dist_* step functions of the C ABI), V,T of every block broadcast with ncclBroadcast (RCCL over
 //            xGMI) on a communication stream of its own, look-ahead schedule of SURVEY.md 8e.  The reference is single-GPU.
@@ -113,22 +113,24 @@ static void test_qr(QR_FUNC f, const char* dir) {
 
 // ---------------------------------------------------------------- multi-GPU host driver (RCCL)
 namespace {
-struct HostBarrier {                      // all rank threads meet here (absmax exchange, start / stop of the timed region)
-    std::mutex mu; std::condition_variable cv; int count = 0, gen = 0, n;
+// all rank threads meet here (absmax exchange, start / stop of the timed region).  abort(): a rank that failed wakes everybody,
+// wait() then returns false and every rank leaves through its one exit path -- nobody is left blocked in a barrier or a collective
+struct HostBarrier {
+    std::mutex mu; std::condition_variable cv; int count = 0, gen = 0, n; bool aborted = false;
     explicit HostBarrier(int n_) : n(n_) {}
-    void wait() {
+    bool wait() {
         std::unique_lock<std::mutex> lk(mu);
+        if (aborted) return false;
         const int g = gen;
         if (++count == n) { count = 0; gen++; cv.notify_all(); }
-        else cv.wait(lk, [&] { return gen != g; });
+        else cv.wait(lk, [&] { return gen != g || aborted; });
+        return !aborted;
     }
+    void abort() { std::lock_guard<std::mutex> lk(mu); aborted = true; cv.notify_all(); }
 };
-#define MG_CHK(call) do { int rc_ = (call); if (rc_ != MPQR_OK) { fprintf(stderr, "rank %d: %s failed: %d (%s)\n", rank, #call, rc_, mpqr_last_error(h)); failed = true; return; } } while (0)
-#define MG_HIP(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { fprintf(stderr, "rank %d: %s failed: %s\n", rank, #call, hipGetErrorString(e_)); failed = true; return; } } while (0)
-#define MG_NCCL(call) do { ncclResult_t r_ = (call); if (r_ != ncclSuccess) { fprintf(stderr, "rank %d: %s failed: %s\n", rank, #call, ncclGetErrorString(r_)); failed = true; return; } } while (0)
 }  // namespace
 
-static int run_multi_gpu(int world, int m, int n, int r, uint64_t seed, int steps) {
+static int run_multi_gpu(int world, int m, int n, int r, uint64_t seed, int steps, const char* dtype) {
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < world) { fprintf(stderr, "error: %d GPUs requested, %d visible\n", world, ndev); return 1; }
     std::vector<int> devs(world);
@@ -141,73 +143,99 @@ static int run_multi_gpu(int world, int m, int n, int r, uint64_t seed, int step
     std::vector<double> ms(world, 0.0);
     std::atomic<bool> failed{false};
     mpqr_opts o; mpqr_default_opts(&o);
+    o.precision = !strcmp(dtype, "fp32") ? MPQR_PREC_FP32 : (!strcmp(dtype, "fp8") ? MPQR_PREC_FP8 : MPQR_PREC_FP16);
     if (world > 1) o.outer_block = std::max(r, std::min(1024, (n / (2 * world)) / r * r));   // >= 2 blocks per rank (see dist.py)
     auto rank_main = [&](int rank) {
         mpqr_handle_t h = nullptr;
-        hipStream_t cs = nullptr;                                       // communication stream: broadcasts only
+        hipStream_t cs = nullptr, chain = nullptr;                      // communication stream: broadcasts only; the library's chain stream
+        hipEvent_t ev_pack = nullptr, ev_bcast = nullptr, ev_unp[2] = {nullptr, nullptr};
         void* bufs[2] = {nullptr, nullptr}; long cap[2] = {0, 0};
-        MG_HIP(hipSetDevice(rank));
-        MG_CHK(mpqr_create(&h, rank));
-        MG_CHK(mpqr_dist_plan(h, m, n, r, world, rank, &o));
-        MG_HIP(hipStreamCreateWithFlags(&cs, hipStreamNonBlocking));
-        MG_CHK(mpqr_dist_generate_matrix(h, seed));
-        const int nb = mpqr_dist_num_blocks(h);
+        // first failure: message, flag, wake the barrier waiters, abort the communicators (a peer may sit inside a broadcast)
+        auto fail = [&](const char* what, const char* why) {
+            fprintf(stderr, "rank %d: %s failed: %s\n", rank, what, why);
+            if (!failed.exchange(true)) { bar.abort(); for (auto& c : comms) (void)ncclCommAbort(c); }
+            return false;
+        };
+        auto ok_q = [&](int rc, const char* what) { return rc == MPQR_OK ? !failed.load() : fail(what, mpqr_last_error(h)); };
+        auto ok_h = [&](hipError_t e, const char* what) { return e == hipSuccess ? !failed.load() : fail(what, hipGetErrorString(e)); };
+        auto ok_n = [&](ncclResult_t e, const char* what) { return e == ncclSuccess ? !failed.load() : fail(what, ncclGetErrorString(e)); };
         auto buffer = [&](int s) -> void* {
             const long need = mpqr_dist_block_bytes(h, s);
-            if (cap[s & 1] < need) { if (bufs[s & 1]) (void)hipFree(bufs[s & 1]); if (hipMalloc(&bufs[s & 1], (size_t)need) != hipSuccess) return nullptr; cap[s & 1] = need; }
+            if (cap[s & 1] < need) {
+                if (bufs[s & 1]) { (void)hipFree(bufs[s & 1]); bufs[s & 1] = nullptr; cap[s & 1] = 0; }
+                if (hipMalloc(&bufs[s & 1], (size_t)need) != hipSuccess) { fail("hipMalloc(payload)", "out of memory"); return nullptr; }
+                cap[s & 1] = need;
+            }
             return bufs[s & 1];
         };
-        auto factor = [&]() {
-            MG_CHK(mpqr_dist_local_absmax(h, &amax[rank]));
-            bar.wait();
+        int nb = 0;
+        // one factorisation.  The host never waits for a broadcast: pack -> ev_pack -> the communication stream waits; broadcast ->
+        // ev_bcast -> the chain stream waits -> unpack -> ev_unp[buffer] -> the next broadcast into that buffer waits.
+        auto factor = [&]() -> bool {
+            if (!ok_q(mpqr_dist_local_absmax(h, &amax[rank]), "mpqr_dist_local_absmax")) return false;
+            if (!bar.wait()) return false;
             float gmax = 0.f; for (float v : amax) gmax = std::max(gmax, v);
-            bar.wait();
-            MG_CHK(mpqr_dist_begin(h, gmax));
-            if (mpqr_dist_block_owner(h, 0) == rank) { MG_CHK(mpqr_dist_factor_block(h, 0)); if (comm_on) MG_CHK(mpqr_dist_pack_block(h, 0, buffer(0))); }
+            if (!bar.wait()) return false;
+            if (!ok_q(mpqr_dist_begin(h, gmax), "mpqr_dist_begin")) return false;
+            auto pack = [&](int s) -> bool {
+                void* b = buffer(s);
+                return b && ok_q(mpqr_dist_pack_block_async(h, s, b), "mpqr_dist_pack_block_async") && ok_h(hipEventRecord(ev_pack, chain), "hipEventRecord");
+            };
+            if (mpqr_dist_block_owner(h, 0) == rank) { if (!ok_q(mpqr_dist_factor_block(h, 0), "mpqr_dist_factor_block") || (comm_on && !pack(0))) return false; }
             for (int s = 0; s < nb; s++) {
                 const int owner = mpqr_dist_block_owner(h, s);
                 if (comm_on) {
                     void* b = buffer(s);
-                    MG_NCCL(ncclBroadcast(b, b, (size_t)mpqr_dist_block_bytes(h, s), ncclUint8, owner, comms[rank], cs));
-                    MG_HIP(hipStreamSynchronize(cs));                   // the GPU keeps working on the previous update meanwhile
-                    MG_CHK(mpqr_dist_unpack_block(h, s, b));
+                    if (!b) return false;
+                    if (owner == rank && !ok_h(hipStreamWaitEvent(cs, ev_pack, 0), "hipStreamWaitEvent")) return false;
+                    if (s >= 2 && !ok_h(hipStreamWaitEvent(cs, ev_unp[s & 1], 0), "hipStreamWaitEvent")) return false;     // the buffer is free again
+                    if (!ok_n(ncclBroadcast(b, b, (size_t)mpqr_dist_block_bytes(h, s), ncclUint8, owner, comms[rank], cs), "ncclBroadcast")) return false;
+                    if (!ok_h(hipEventRecord(ev_bcast, cs), "hipEventRecord") || !ok_h(hipStreamWaitEvent(chain, ev_bcast, 0), "hipStreamWaitEvent")) return false;
+                    if (!ok_q(mpqr_dist_unpack_block_async(h, s, b), "mpqr_dist_unpack_block_async") || !ok_h(hipEventRecord(ev_unp[s & 1], chain), "hipEventRecord")) return false;
                 }
                 if (s + 1 < nb && mpqr_dist_block_owner(h, s + 1) == rank) {     // look-ahead: my block first, the rest beside its factorisation
-                    MG_CHK(mpqr_dist_update_part(h, s, 0));
-                    MG_CHK(mpqr_dist_update_part(h, s, 1));
-                    MG_CHK(mpqr_dist_factor_block(h, s + 1));
-                    if (comm_on) MG_CHK(mpqr_dist_pack_block(h, s + 1, buffer(s + 1)));
-                } else {
-                    MG_CHK(mpqr_dist_update_part(h, s, 1));
-                }
+                    if (!ok_q(mpqr_dist_update_part(h, s, 0), "mpqr_dist_update_part") || !ok_q(mpqr_dist_update_part(h, s, 1), "mpqr_dist_update_part") ||
+                        !ok_q(mpqr_dist_factor_block(h, s + 1), "mpqr_dist_factor_block") || (comm_on && !pack(s + 1))) return false;
+                } else if (!ok_q(mpqr_dist_update_part(h, s, 1), "mpqr_dist_update_part")) return false;
             }
-            MG_CHK(mpqr_dist_form_q(h));
-            MG_CHK(mpqr_sync(h));
+            return ok_q(mpqr_dist_form_q(h), "mpqr_dist_form_q") && ok_h(hipStreamSynchronize(cs), "hipStreamSynchronize") && ok_q(mpqr_sync(h), "mpqr_sync");
         };
-        factor();                                                        // warm-up
-        bar.wait();
-        const auto t0 = std::chrono::high_resolution_clock::now();
-        for (int it = 0; it < steps && !failed; it++) factor();
-        bar.wait();
-        ms[rank] = std::chrono::duration<double, std::milli>(std::chrono::high_resolution_clock::now() - t0).count() / steps;
+        do {                                                             // one exit path: everything below the loop is released once
+            if (!ok_h(hipSetDevice(rank), "hipSetDevice") || !ok_q(mpqr_create(&h, rank), "mpqr_create") ||
+                !ok_q(mpqr_dist_plan(h, m, n, r, world, rank, &o), "mpqr_dist_plan") ||
+                !ok_h(hipStreamCreateWithFlags(&cs, hipStreamNonBlocking), "hipStreamCreateWithFlags") ||
+                !ok_q(mpqr_dist_chain_stream(h, (void**)&chain), "mpqr_dist_chain_stream") ||
+                !ok_h(hipEventCreateWithFlags(&ev_pack, hipEventDisableTiming), "hipEventCreate") || !ok_h(hipEventCreateWithFlags(&ev_bcast, hipEventDisableTiming), "hipEventCreate") ||
+                !ok_h(hipEventCreateWithFlags(&ev_unp[0], hipEventDisableTiming), "hipEventCreate") || !ok_h(hipEventCreateWithFlags(&ev_unp[1], hipEventDisableTiming), "hipEventCreate") ||
+                !ok_q(mpqr_dist_generate_matrix(h, seed), "mpqr_dist_generate_matrix")) break;
+            nb = mpqr_dist_num_blocks(h);
+            if (!factor()) break;                                        // warm-up
+            if (!bar.wait()) break;
+            const auto t0 = std::chrono::high_resolution_clock::now();
+            bool good = true;
+            for (int it = 0; it < steps && good; it++) good = factor();
+            if (!good || !bar.wait()) break;
+            ms[rank] = std::chrono::duration<double, std::milli>(std::chrono::high_resolution_clock::now() - t0).count() / steps;
+        } while (0);
         for (void* b : bufs) if (b) (void)hipFree(b);
-        (void)hipStreamDestroy(cs);
-        (void)mpqr_destroy(h);
+        for (hipEvent_t e : {ev_pack, ev_bcast, ev_unp[0], ev_unp[1]}) if (e) (void)hipEventDestroy(e);
+        if (cs) (void)hipStreamDestroy(cs);
+        if (h) (void)mpqr_destroy(h);
     };
     std::vector<std::thread> th;
     for (int rk = 0; rk < world; rk++) th.emplace_back(rank_main, rk);
     for (auto& t : th) t.join();
-    for (auto& c : comms) (void)ncclCommDestroy(c);
-    if (failed) return 1;
-    double t = 0; for (double v : ms) t = std::max(t, v);
-    const double gf = mpqr_flops_geqrf(m, n) / (t * 1e-3) / 1e9;
-    printf("multi-GPU block QR: %d GPU(s), %d x %d, r = %d, outer block %d: %.2f ms per factorisation incl. Q, %.1f GFLOP/s (GEQRF-equivalent)\n",
-           world, m, n, r, o.outer_block ? o.outer_block : 1024, t, gf);
+    if (!failed) for (auto& c : comms) (void)ncclCommDestroy(c);         // (aborted communicators are gone already)
+    if (failed) { fprintf(stderr, "multi-GPU run failed\n"); return 1; }
+    double worst = 0; for (double v : ms) worst = std::max(worst, v);
+    const double geqrf = 2.0 * m * (double)n * n - 2.0 / 3.0 * (double)n * n * n;
+    printf("multi-GPU block QR: %d GPU(s), %d x %d, r = %d, outer block %d, %s: %.2f ms per factorisation incl. Q, %.1f GFLOP/s (GEQRF-equivalent flops)\n",
+           world, m, n, r, o.outer_block ? o.outer_block : 1024, dtype, worst, geqrf / (worst * 1e-3) / 1e9);
     return 0;
 }
 
 int main(int argc, char** argv) {
-    const char* jac = nullptr; int m = 0, n = 0, r = 0, gpus = 0, steps = 3; const char* dtype = "fp16";
+    const char* jac = nullptr; int m = 0, n = 0, r = 0, gpus = 0, steps = 3; const char* dtype = "fp16"; bool random_list = true;
     for (int i = 1; i < argc; i++) {
         if (!strcmp(argv[i], "--jacobians") && i + 1 < argc) jac = argv[++i];
         else if (!strcmp(argv[i], "--m") && i + 1 < argc) m = atoi(argv[++i]);
@@ -217,12 +245,13 @@ int main(int argc, char** argv) {
         else if (!strcmp(argv[i], "--gpus") && i + 1 < argc) gpus = atoi(argv[++i]);
         else if (!strcmp(argv[i], "--steps") && i + 1 < argc) steps = atoi(argv[++i]);
         else if (!strcmp(argv[i], "--dtype") && i + 1 < argc) dtype = argv[++i];
-        else { fprintf(stderr, "usage: %s [--jacobians DIR] [--m M --n N --r R] [--seed S] [--dtype fp16|fp32|fp8] [--gpus N [--steps K]]\n", argv[0]); return 2; }
+        else if (!strcmp(argv[i], "--skip-random")) random_list = false;      // with --jacobians: only the Jacobian run list (qr.cu:1794-1804)
+        else { fprintf(stderr, "usage: %s [--jacobians DIR [--skip-random]] [--m M --n N --r R] [--seed S] [--dtype fp16|fp32|fp8] [--gpus N [--steps K]]\n", argv[0]); return 2; }
     }
     try {
         if (gpus > 0) {
             if (!(m > 0 && n > 0 && r > 0)) { fprintf(stderr, "--gpus needs --m --n --r\n"); return 2; }
-            return run_multi_gpu(gpus, m, n, r, g_seed, std::max(1, steps));
+            return run_multi_gpu(gpus, m, n, r, g_seed, std::max(1, steps), dtype);
         }
         if (m > 0 && n > 0 && r > 0) {
             if (!strcmp(dtype, "fp32")) test_dev_block_qr(m, n, r, generate(m, n));
@@ -230,9 +259,11 @@ int main(int argc, char** argv) {
             else test_dev_mixed_precision_block_qr(m, n, r, generate(m, n));
             return 0;
         }
-        test_qr_by_random_matrix(test_h_householder_qr);
-        test_qr_by_random_matrix(test_dev_block_qr);
-        test_qr_by_random_matrix(test_dev_mixed_precision_block_qr);
+        if (random_list) {
+            test_qr_by_random_matrix(test_h_householder_qr);
+            test_qr_by_random_matrix(test_dev_block_qr);
+            test_qr_by_random_matrix(test_dev_mixed_precision_block_qr);
+        }
         if (jac) { test_qr(test_h_householder_qr, jac); test_qr(test_dev_block_qr, jac); test_qr(test_dev_mixed_precision_block_qr, jac); }
     } catch (const std::exception& e) { fprintf(stderr, "error: %s\n", e.what()); return 1; }
     return 0;

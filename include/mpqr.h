@@ -94,6 +94,7 @@ typedef struct mpqr_timings {
     double gbytes_q_nn;   /* the same for Q formation's Q2 -= V Y^T launches (+ the fp16 shadow they write)          */
     int   n_gh_leaves;    /* Gram-Householder leaves (gram / solve / apply launches) of the last block-loop pass     */
     float us_gh_solve;    /* one gh_solve launch at this plan's leaf width, timed alone (mpqr_bench_leaf_solve; 0 = not measured) */
+    int   n_q_ident_rows; /* Q formation: rows of X = Q2^T V copied from V because their columns of Q were still identity columns */
 } mpqr_timings;
 
 typedef struct mpqr_handle_s* mpqr_handle_t;
@@ -139,6 +140,15 @@ int mpqr_get_timings(mpqr_handle_t h, mpqr_timings* t);
  * (the w x w solve, one workgroup) `iters` times on scratch data and returns the mean launch time in microseconds; the value is
  * also reported by later mpqr_get_timings calls.  Replaces nothing in the reference (its panel runs on the host, qr.cu:1080). */
 int mpqr_bench_leaf_solve(mpqr_handle_t h, int w, int iters, float* us_per_launch);
+/* test aid: C (-)= A B through ONE of the library's MFMA GEMM kernels, so that the edge tiles (M, N not multiples of the tile,
+ * K padded to the kernel's k step with zeros) can be driven directly -- the counterpart of the reference's kernel-level sweep
+ * test_template_tensorcore_mmult_tiled (Cuda/mmult.cuh:387-435, iterated by Cuda/qr.cu:1944-1959) against h_mmult.
+ * A: M x K, B: K x N, C: M x N, row-major fp32 on the host; A and B are rounded to the kernel's operand type.
+ * kernel: 1 = 128-tile fp16 kernel, 2 = 256-tile kernel with the fp32 source converted and transposed while staged
+ *         (the far X = A2^T V), 6 = 256-tile ping-pong kernel (both operands fp16 by LDS-DMA), 8 = e4m3 kernel.
+ * mode:   0: C = A B,  2: C -= A B (read-modify-write epilogue; kernels 1, 6, 8; M % 32 == 0 -- the library's own callers pad the
+ *         row count of the matrix being updated, the epilogue treats a 32-row sub-tile as valid or invalid as a whole). */
+int mpqr_gemm_test_f32(mpqr_handle_t h, const float* A, const float* B, float* C, int M, int N, int K, int kernel, int mode);
 /* results: A_out is (m+1) x n in the reference's shifted-reflector layout, Q is m x m */
 int mpqr_get_factor_host(mpqr_handle_t h, float* A_out);
 int mpqr_get_q_host(mpqr_handle_t h, float* Q);
@@ -244,6 +254,12 @@ int  mpqr_dist_factor_block(mpqr_handle_t h, int s);
 long mpqr_dist_block_bytes(mpqr_handle_t h, int s);
 int  mpqr_dist_pack_block(mpqr_handle_t h, int s, void* device_buf);
 int  mpqr_dist_unpack_block(mpqr_handle_t h, int s, const void* device_buf);
+/* the same without the host synchronisation: the copies are enqueued on the handle's chain stream (mpqr_dist_chain_stream returns it
+ * as a hipStream_t) and the caller orders its broadcasts against them with events -- pack -> event -> communication stream waits;
+ * broadcast -> event -> chain stream waits -> unpack -> event -> the next broadcast into the same buffer waits */
+int  mpqr_dist_pack_block_async(mpqr_handle_t h, int s, void* device_buf);
+int  mpqr_dist_unpack_block_async(mpqr_handle_t h, int s, const void* device_buf);
+int  mpqr_dist_chain_stream(mpqr_handle_t h, void** hip_stream);
 int  mpqr_dist_update(mpqr_handle_t h, int s);               /* = mpqr_dist_update_part(h, s, 2) */
 /* look-ahead form: part 0 = the columns of block s+1 only (its owner factors that block next), chain stream;
  * part 1 = the local columns right of block s+1, far-update stream, runs beside the factorisation of block s+1;

@@ -33,7 +33,7 @@ class MpqrTimings(C.Structure):
                 ("flops_far_nn", C.c_double), ("ms_chain_wait", C.c_float), ("n_passes", C.c_int),
                 ("n_robust_leaves", C.c_int), ("ms_q_tn", C.c_float), ("ms_q_nn", C.c_float), ("n_q_launches", C.c_int),
                 ("tflop_q", C.c_float), ("ms_host_enqueue", C.c_float), ("gbytes_far_nn", C.c_double), ("gbytes_q_nn", C.c_double),
-                ("n_gh_leaves", C.c_int), ("us_gh_solve", C.c_float)]
+                ("n_gh_leaves", C.c_int), ("us_gh_solve", C.c_float), ("n_q_ident_rows", C.c_int)]
 
 
 def build(force=False):
@@ -67,6 +67,7 @@ SIGNATURES = {
     "mpqr_sync": (_i, [_H]),
     "mpqr_get_timings": (_i, [_H, C.POINTER(MpqrTimings)]),
     "mpqr_bench_leaf_solve": (_i, [_H, _i, _i, C.POINTER(C.c_float)]),
+    "mpqr_gemm_test_f32": (_i, [_H, _f32, _f32, _f32, _i, _i, _i, _i, _i]),
     "mpqr_get_factor_host": (_i, [_H, _f32]),
     "mpqr_get_q_host": (_i, [_H, _f32]),
     "mpqr_get_r_host": (_i, [_H, _f32]),
@@ -111,6 +112,9 @@ SIGNATURES = {
     "mpqr_dist_block_bytes": (_l, [_H, _i]),
     "mpqr_dist_pack_block": (_i, [_H, _i, _p]),
     "mpqr_dist_unpack_block": (_i, [_H, _i, _p]),
+    "mpqr_dist_pack_block_async": (_i, [_H, _i, _p]),
+    "mpqr_dist_unpack_block_async": (_i, [_H, _i, _p]),
+    "mpqr_dist_chain_stream": (_i, [_H, C.POINTER(C.c_void_p)]),
     "mpqr_dist_update": (_i, [_H, _i]),
     "mpqr_dist_update_part": (_i, [_H, _i, _i]),
     "mpqr_dist_form_q": (_i, [_H]),

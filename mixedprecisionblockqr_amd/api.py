@@ -178,6 +178,16 @@ def apply_panel_to_trailing(A, m, n, global_offset, panel_width, precision=L.PRE
     h._chk(L.lib().mpqr_apply_panel_to_trailing_f32(h._h, A, m, n, global_offset, panel_width, precision))
 
 
+def gemm_test(A, B, Cm, kernel, mode=0, handle=None):
+    """Test aid: Cm (-)= A B through one of the library's MFMA GEMM kernels (include/mpqr.h: mpqr_gemm_test_f32); the
+    counterpart of the reference's test_template_tensorcore_mmult_tiled (Cuda/mmult.cuh:387-435).  Cm is modified in place."""
+    h = handle or default_handle()
+    M, K = A.shape; K2, N = B.shape
+    assert K == K2 and Cm.shape == (M, N) and all(x.dtype == np.float32 and x.flags.c_contiguous for x in (A, B, Cm))
+    h._chk(L.lib().mpqr_gemm_test_f32(h._h, A, B, Cm, M, N, K, kernel, mode))
+    return Cm
+
+
 def qr_metrics(A, R, Q, handle=None):
     """h_backward_error / h_q_error / h_lower_trapezoid_error (Cuda/qr.cu:115-196) on the GPU."""
     h = handle or default_handle()

@@ -29,6 +29,7 @@
 #include <rocprofiler-sdk-roctx/roctx.h>
 
 #include "mpqr_internal.h"
+#include <atomic>
 
 using namespace mpqr;
 
@@ -68,20 +69,8 @@ struct mpqr_handle_s {
     bool defer_join = false;            // block loop with look-ahead: the chain does not wait for a block's T (its users wait on ev_T)
     std::vector<hipEvent_t> ev_cols2;
     bool tq_on = false;         // this plan builds its T's on sT (fp16 mode)
-    // Gram-level look-ahead of the panel chain (factor_block_la): the chain stream runs solve -> glue -> solve ..., every
-    // pass over the tall data (apply, in-block updates, the pair Gram of the next two leaves) runs on sA
-    hipStream_t sA = nullptr;
-    hipEvent_t ev_glue = nullptr, ev_pg = nullptr, ev_cold = nullptr;   // chain -> sA (C, Y ready), sA -> chain (pair Gram ready), sA -> chain (join)
-    bool la_on = false;          // set by the block loop while look-ahead blocks may be used
-    bool la_warm = false;        // the next leaf's N (GsN) and top block are predicted already
-    bool la_pg_issued = false;   // ... and the pair Gram its glue needs is enqueued on sA
-    bool la_dirty = false;       // sA holds work the chain stream has not been ordered after
-    bool la_next_robust = false; // the next block's first leaf takes the robust path (no look-ahead into it)
-    int la_idx = 0;              // leaf counter: parity selects the ping-pong buffers
     hipStream_t node_done_stream = nullptr;   // stream on which the last factor_node left the block's reflectors complete
     hipStream_t inblock_stream = nullptr;     // apply_node, lane 0: run on this stream instead of s0
-    double* GsN[2] = {nullptr, nullptr}; double* Gp2 = nullptr; double* G2 = nullptr;
-    float* Bsv[2] = {nullptr, nullptr}; float* Cv2[2] = {nullptr, nullptr}; float* Yg = nullptr;
     hipStream_t op1_stream = nullptr;   // set by factor_block_flat: X = C2^T V (+ its slab sum) of the next apply runs there
     hipEvent_t ev_x = nullptr;          // ... and this event orders it before the apply's second GEMM
     hipEvent_t ev_dist_chain = nullptr, ev_dist_far = nullptr;   // distributed look-ahead: chain -> far stream, far -> chain stream
@@ -113,7 +102,6 @@ struct mpqr_handle_s {
     float* Xt1 = nullptr;  half_t* Yt1 = nullptr;      // scratch of the far-update stream (look-ahead)
     std::vector<hipEvent_t> ev_node, ev_cols;          // per top-level node: reflectors ready / columns up to date
     float* S = nullptr;    size_t s_elems = 0;
-    float* Wk = nullptr;          // gh_solve2 scratch (Cholesky factor and its inverse of the current leaf)
     float* Sleaf = nullptr;       // 128 x 128 Gram of a leaf's fp16 reflectors (chain stream; S itself is used by the T stream)
     float* P = nullptr;    int maxwg = 0;
     double* Gp = nullptr; double* Gs = nullptr; float* Cv = nullptr; int* dflag = nullptr;   // Gram-Householder leaf workspace
@@ -123,6 +111,7 @@ struct mpqr_handle_s {
     int nflag = 0;                // ints in dflag: one flag per tree node (gh_solve raises dflag[node id])
     int n_passes = 0, n_robust_leaves = 0;   // of the last mpqr_factor
     int n_gh_leaves = 0;                     // Gram-Householder leaves launched by the last block-loop pass
+    int n_q_ident_rows = 0;                  // rows of X copied from V in the last Q formation (identity columns of Q)
     float us_gh_solve = 0.f;                 // mpqr_bench_leaf_solve's last result
     float* rbTf = nullptr; half_t* rbTh = nullptr; half_t* rbTth = nullptr; size_t rb_elems = 0;   // T arena of a robust leaf's sub-tree
     bool force32 = false;         // tree building: only 32-column leaves (sub-tree of a robustly factored tall leaf)
@@ -213,17 +202,16 @@ int dalloc(mpqr_handle_t h, T** p, size_t elems) {
 void free_plan(mpqr_handle_t h) {
     void* ptrs[] = {h->dA, h->dA0, h->dQ, h->Vh, h->Vt, h->vdiag, h->Xt, h->Yt, h->S, h->P, h->tmp1, h->tmp2,
                     h->Tf, h->Th, h->Tth, h->dstage, h->Gp, h->Gs, h->Cv, h->dflag, h->Vf, h->Yf, h->Xt1, h->Yt1, h->Sp,
-                    h->rbTf, h->rbTh, h->rbTth, h->Sleaf, h->Wk, h->V8n, h->V8t, h->A8t, h->Y8,
-                    h->GsN[0], h->GsN[1], h->Gp2, h->G2, h->Bsv[0], h->Bsv[1], h->Cv2[1], h->Yg, h->S2, h->tmp1b, h->tmp2b, h->Qt, h->At, h->Xh, h->Wh, h->Xl, h->Xh1, h->Xl1};
+                    h->rbTf, h->rbTh, h->rbTth, h->Sleaf, h->V8n, h->V8t, h->A8t, h->Y8,
+                    h->S2, h->tmp1b, h->tmp2b, h->Qt, h->At, h->Xh, h->Wh, h->Xl, h->Xh1, h->Xl1};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     h->S2 = h->tmp1b = h->tmp2b = nullptr; h->s2_elems = 0; h->Qt = nullptr; h->shadow = nullptr; h->At = nullptr; h->at_read = false; h->Xh = nullptr; h->Xl = h->Xh1 = h->Xl1 = nullptr; h->Wh = nullptr; h->qroot = -1; h->qmerge_after.clear(); h->qpair.clear(); h->pairs_ready = false;
-    h->GsN[0] = h->GsN[1] = nullptr; h->Gp2 = h->G2 = nullptr; h->Bsv[0] = h->Bsv[1] = nullptr; h->Cv2[0] = h->Cv2[1] = nullptr; h->Yg = nullptr;
     h->dA = h->dA0 = h->dQ = nullptr; h->Vh = h->Vt = nullptr; h->vdiag = nullptr; h->Xt = nullptr; h->Yt = nullptr;
     h->S = nullptr; h->P = nullptr; h->tmp1 = h->tmp2 = nullptr; h->Tf = nullptr; h->Th = h->Tth = nullptr;
     h->dstage = nullptr; h->stage_elems = 0;
     h->Gp = nullptr; h->Gs = nullptr; h->Cv = nullptr; h->dflag = nullptr; h->Vf = nullptr; h->Yf = nullptr;
     h->Xt1 = nullptr; h->Yt1 = nullptr; h->Sp = nullptr;
-    h->rbTf = nullptr; h->rbTh = h->rbTth = nullptr; h->rb_elems = 0; h->nflag = 0; h->leaf_robust.clear(); h->Sleaf = nullptr; h->Wk = nullptr;
+    h->rbTf = nullptr; h->rbTh = h->rbTth = nullptr; h->rb_elems = 0; h->nflag = 0; h->leaf_robust.clear(); h->Sleaf = nullptr;
     h->V8n = h->V8t = h->A8t = h->Y8 = nullptr; h->v8_node = -1;
     for (hipEvent_t e : h->chain_ev) (void)hipEventDestroy(e);
     h->chain_ev.clear(); h->chain_used = 0; h->far_used = 0;
@@ -283,17 +271,21 @@ int gemm2_config() {        // test/tuning hook: MPQR_GEMM2_CONFIG selects the l
     static const int c = []() { const char* e = getenv("MPQR_GEMM2_CONFIG"); return e ? atoi(e) : 0; }();
     return c;
 }
+// 256 x 256 output tiles from which the 256-wide kernels take a GEMM (test hook: MPQR_GEMM2_MIN_TILES=1 forces them early).
+// apply_node derives from the SAME number whether an update may hand X over as fp16 hi + lo parts, which only those kernels honour.
+static long gemm2_min_tiles() {
+    static const long v = []() { const char* e = getenv("MPQR_GEMM2_MIN_TILES"); return e ? atol(e) : 48L; }();
+    return v;
+}
+// set when a GEMM found no kernel: mpqr_factor / form_q report it instead of returning garbage
+static std::atomic<int> g_dispatch_error{0};
 void gemm_dispatch(AMode am, EMode em, const GemmArgs& g, hipStream_t s) {
-    static const long min_tiles = []() {            // test hook: MPQR_GEMM2_MIN_TILES=1 forces the large kernel early
-        const char* e = getenv("MPQR_GEMM2_MIN_TILES");
-        return e ? atol(e) : 48L;
-    }();
     const long tiles = (long)(g.M / 256) * (g.N / 256);
     if ((g.nsplit <= 1 || (em == E_STORE_F32 && am == A_F32T)) && (g.nslab_in <= 1) && g.M >= 256 && g.N >= 256 &&
-        tiles >= min_tiles && (g.K % 64) == 0 &&
+        tiles >= gemm2_min_tiles() && (g.K % 64) == 0 &&
         launch_gemm2_f16(am, em, g, s, gemm2_config()))
         return;
-    launch_gemm_f16(am, em, g, s);
+    if (!launch_gemm_f16(am, em, g, s)) g_dispatch_error.store(1);
 }
 
 int choose_split(int M, int N, int K, size_t cap_elems, long slab) {
@@ -411,7 +403,7 @@ void apply_node(mpqr_handle_t h, const Node& nd, float* C, long ldc, int clo, in
     const bool q_apply = h->shadow && lane == 0 && !far;
     half_t* const Xlo = (xsplit && (!q_apply || qsplit)) ? (lane ? h->Xl1 : h->Xl) : nullptr;
     const bool x16 = x16_env && Xhi && (!xsplit || Xlo || q_apply) && !f8 && g1.nsplit == 1 && M1 >= 256 && Kr >= 256 && (Kr % 64) == 0 &&
-                     (long)(M1 / 256) * (Kr / 256) >= 48 && h->opts.precision != MPQR_PREC_FP32;
+                     (long)(M1 / 256) * (Kr / 256) >= gemm2_min_tiles() && h->opts.precision != MPQR_PREC_FP32;
     // one leaf (128 reflectors) onto a few columns: slab sum and Y = X T' in one small kernel (leaf_xt_kernel)
     static const int fuse_env = []() { const char* e = getenv("MPQR_FUSE_XT"); return e ? atoi(e) : 1; }();
     const bool fuse_xt = fuse_env && !f8 && !far && lane == 0 && Kr == 128 && M1 <= 4096 && !(h->shadow && lane == 0);
@@ -446,13 +438,14 @@ void apply_node(mpqr_handle_t h, const Node& nd, float* C, long ldc, int clo, in
             // X = Q2^T V are rows of V (exact in fp16): copied, and the GEMM starts behind them
             const int idc = (h->q_ident_cols > 0 && clo == clo_al && nd.a0 == nd.c0 && rlo == nd.c0 && clo == nd.c0) ?
                             std::min({h->q_ident_cols, M1 - 256, (nd.c1 - nd.c0) / 256 * 256}) : 0;
-            if (idc >= 256 && (long)((M1 - idc) / 256) * (Kr / 256) >= 48) {   // (the rest still goes to the 256-wide kernel)
+            if (idc >= 256 && (long)((M1 - idc) / 256) * (Kr / 256) >= gemm2_min_tiles()) {   // (the rest still goes to the 256-wide kernel)
                 (void)hipMemcpy2DAsync(Xhi, (size_t)Kr * sizeof(half_t), h->Vh + (long)nd.c0 * h->ldvh + nd.a0, h->ldvh * sizeof(half_t),
                                        (size_t)Kr * sizeof(half_t), idc, hipMemcpyDeviceToDevice, st1);
                 if (Xlo) (void)hipMemsetAsync(Xlo, 0, (size_t)idc * Kr * sizeof(half_t), st1);
                 g1.A = h->shadow + (long)(clo_al + idc) * h->ldshadow + rlo;
                 g1.C = Xhi + (long)idc * Kr; if (Xlo) g1.C2 = Xlo + (long)idc * Kr;
                 g1.M = M1 - idc;
+                h->n_q_ident_rows += idc;
             }
             gemm_dispatch(A_H16, E_STORE_H16, g1, st1);
         }
@@ -567,7 +560,7 @@ int factor_rec(mpqr_handle_t h, int id, bool do_panel) {
             Range rg("mpqr:panel");
             a.A = h->Aeff; a.lda = h->lda; a.mrows = h->m; a.cb = rdown(nd.c0, tall ? 128 : 32); a.c0 = nd.c0; a.c1 = nd.c1;
             a.Vh = h->Vh; a.ldvh = h->ldvh; a.Vt = h->Vt; a.ldvt = h->ldvt; a.vdiag = h->vdiag;
-            a.P = h->P; a.maxwg = h->maxwg; a.Wk = h->Wk;
+            a.P = h->P; a.maxwg = h->maxwg;
             const bool fused = tall && !h->Vf;    // fp16 mode: the Gram of the rounded reflectors comes out of gh_apply
             int* flag = h->dflag + (id < h->nflag ? id : 0);
             if (tall) { launch_leaf_gram_householder(a, h->Gp, h->Gs, h->Cv, flag, fused ? h->Sp : nullptr, nullptr, h->s0); h->n_gh_leaves++; }
@@ -705,7 +698,7 @@ int factor_block_flat(mpqr_handle_t h, int top, const std::vector<int>& leaves) 
             LeafArgs a{};
             a.A = h->Aeff; a.lda = h->lda; a.mrows = h->m; a.cb = rdown(lf.c0, 128); a.c0 = lf.c0; a.c1 = lf.c1;
             a.Vh = h->Vh; a.ldvh = h->ldvh; a.Vt = h->Vt; a.ldvt = h->ldvt; a.vdiag = h->vdiag;
-            a.P = h->P; a.maxwg = h->maxwg; a.Wk = h->Wk;
+            a.P = h->P; a.maxwg = h->maxwg;
             launch_leaf_gram_householder(a, h->Gp, h->Gs, h->Cv, h->dflag + (id < h->nflag ? id : 0), h->Sp, nullptr, h->s0);
             h->n_gh_leaves++;
             if (h->wait_after_first_leaf && !tq) {       // look-ahead: the block's other columns arrive with this event
@@ -759,141 +752,6 @@ int factor_block_flat(mpqr_handle_t h, int top, const std::vector<int>& leaves) 
     return MPQR_OK;
 }
 
-// ---- flat block schedule with the Gram-level look-ahead (kernels_panel.hip, "Gram-level look-ahead")
-// Chain stream s0:  [gram + save top, cold start only] solve_j -> glue_j -> solve_{j+1} -> ...
-// Tall stream  sA:  apply_j (+ fp32 update of leaf j+1's tall rows) -> T_j -> fp16 update of the block's columns beyond leaf
-//                   j+1 -> pair Gram for glue_{j+1}
-// T stream     sT:  column block j of the block's T (as in factor_block_flat)
-// glue_j waits for the pair Gram (ev_pg), apply_j for glue_j (ev_glue).  A leaf on the robust path, a leaf without a
-// following full leaf, or the first leaf ever is a cold start: the chain joins sA and takes its Gram matrix from the data.
-int factor_block_la(mpqr_handle_t h, int top, const std::vector<int>& leaves) {
-    const Node tp = h->nodes[top];
-    const int ld = tp.ldt;
-    const int nl = (int)leaves.size();
-    hipStream_t s0 = h->s0, sA = h->sA, sT = h->sT;
-    int rc;
-    const int upd_end = std::max(tp.c1, h->ext_c1);
-    auto is_robust = [&](int jj) { return h->robust || (leaves[jj] < (int)h->leaf_robust.size() && h->leaf_robust[leaves[jj]]); };
-    // leaf jj hands predicted inputs to the leaf after it?
-    auto can_la = [&](int jj) {
-        if (is_robust(jj)) return false;
-        const Node& lf = h->nodes[leaves[jj]];
-        if (jj + 1 < nl) return !is_robust(jj + 1);
-        return h->ext_c1 == lf.c1 + 128 && !h->la_next_robust && lf.c1 + 128 <= h->n;
-    };
-    auto tall_waits_far = [&]() {                            // the block's other columns become valid with this event
-        if (h->wait_after_first_leaf) { (void)hipStreamWaitEvent(sA, h->wait_after_first_leaf, 0); h->wait_after_first_leaf = nullptr; }
-    };
-    auto t_column_block = [&](const Node& lf, int o) {
-        if (o <= 0) return;
-        Range rg("mpqr:wy_T_merge");
-        Node P = tp; P.c1 = lf.c0; P.a1 = lf.c0; P.ldt = o;
-        int nslab; long slab;
-        gram(h, P, lf, &nslab, &slab, sT);
-        SgemmArgs s1{};
-        s1.A = h->S; s1.lda = lf.ldt; s1.transA = 0; s1.nslab_a = nslab; s1.slab_a = slab;
-        s1.B = h->Tf + lf.toff; s1.ldb = ld; s1.transB = 0;
-        s1.C = h->tmp1; s1.ldc = lf.ldt; s1.M = o; s1.N = lf.ldt; s1.K = lf.ldt; s1.alpha = 1.f; s1.beta = 0.f; s1.upperB = 1;
-        launch_sgemm(s1, sT);
-        SgemmArgs s2{};
-        s2.A = h->Tf + tp.toff; s2.lda = ld; s2.transA = 0; s2.nslab_a = 1;
-        s2.B = h->tmp1; s2.ldb = lf.ldt; s2.transB = 0;
-        s2.C = h->Tf + tp.toff + o; s2.ldc = ld; s2.M = o; s2.N = lf.ldt; s2.K = o; s2.alpha = -1.f; s2.beta = 0.f; s2.upperA = 1;
-        launch_sgemm(s2, sT);
-        launch_t_colblock_h16(h->Tf + tp.toff, h->Th + tp.toff, h->Tth + tp.toff, ld, o, o, lf.ldt, sT);
-    };
-    for (int j = 0; j < nl; j++) {
-        const int id = leaves[j];
-        Node lf = h->nodes[id];
-        const int o = lf.c0 - tp.c0;
-        lf.toff = tp.toff + (size_t)o * (ld + 1);
-        lf.tld = ld;
-        lf.id = -1;                                          // no per-leaf T event in this schedule
-        const int par = h->la_idx & 1;
-        const bool la = can_la(j);
-        bool warm_next = false;
-        if (is_robust(j)) {
-            // column-by-column kernels on the chain stream, after everything the tall stream still holds
-            if (h->la_dirty) { (void)hipEventRecord(h->ev_cold, sA); (void)hipStreamWaitEvent(s0, h->ev_cold, 0); h->la_dirty = false; }
-            if (h->wait_after_first_leaf) { (void)hipStreamWaitEvent(s0, h->wait_after_first_leaf, 0); h->wait_after_first_leaf = nullptr; }
-            const size_t keep = h->nodes[id].toff;
-            if ((rc = robust_tall_leaf(h, h->nodes[id], true))) return rc;
-            (void)hipMemcpy2DAsync(h->Tf + lf.toff, (size_t)ld * 4, h->Tf + keep, (size_t)lf.ldt * 4, (size_t)lf.ldt * 4, lf.ldt, hipMemcpyDeviceToDevice, s0);
-            (void)hipMemcpy2DAsync(h->Th + lf.toff, (size_t)ld * 2, h->Th + keep, (size_t)lf.ldt * 2, (size_t)lf.ldt * 2, lf.ldt, hipMemcpyDeviceToDevice, s0);
-            (void)hipMemcpy2DAsync(h->Tth + lf.toff, (size_t)ld * 2, h->Tth + keep, (size_t)lf.ldt * 2, (size_t)lf.ldt * 2, lf.ldt, hipMemcpyDeviceToDevice, s0);
-            (void)hipEventRecord(h->ev_glue, s0);
-            (void)hipStreamWaitEvent(sA, h->ev_glue, 0);
-            h->la_warm = false; h->la_pg_issued = false;
-        } else {
-            Range rg("mpqr:panel");
-            LeafArgs a{};
-            a.A = h->Aeff; a.lda = h->lda; a.mrows = h->m; a.cb = rdown(lf.c0, 128); a.c0 = lf.c0; a.c1 = lf.c1;
-            a.Vh = h->Vh; a.ldvh = h->ldvh; a.Vt = h->Vt; a.ldvt = h->ldvt; a.vdiag = h->vdiag;
-            a.P = h->P; a.maxwg = h->maxwg; a.Wk = h->Wk;
-            if (!h->la_warm) {
-                // cold start: the Gram matrix comes from the data, i.e. after every update the tall stream still holds
-                if (h->la_dirty) { (void)hipEventRecord(h->ev_cold, sA); (void)hipStreamWaitEvent(s0, h->ev_cold, 0); h->la_dirty = false; }
-                launch_gh_gram(a, h->Gp, h->GsN[par], s0);
-                if (la) launch_gh_save_top(h->Aeff, h->lda, lf.c0, h->Bsv[par], s0);
-                h->la_pg_issued = false;
-            }
-            launch_gh_solve(a, h->GsN[par], h->Cv2[par], h->dflag + (id < h->nflag ? id : 0), s0);
-            if (la) {
-                if (!h->la_pg_issued) {                      // the pair Gram of (this leaf, next leaf): data without this leaf's update
-                    tall_waits_far();
-                    launch_gh_pair_gram(h->Aeff, h->lda, h->m, lf.c1, lf.c0, h->Gp2, h->maxwg, h->G2, sA);
-                    (void)hipEventRecord(h->ev_pg, sA);
-                    h->la_dirty = true;
-                }
-                (void)hipStreamWaitEvent(s0, h->ev_pg, 0);
-                GlueArgs g{};
-                g.A = h->Aeff; g.lda = h->lda; g.c0 = lf.c0; g.vdiag = h->vdiag; g.Cv = h->Cv2[par];
-                g.N = h->GsN[par]; g.Glx = h->G2; g.Gld = h->G2 + 16384; g.Bs = h->Bsv[par];
-                g.Bn = h->Bsv[par ^ 1]; g.Nn = h->GsN[par ^ 1]; g.Yg = h->Yg;
-                launch_gh_glue(g, s0);
-                warm_next = true;
-            }
-            (void)hipEventRecord(h->ev_glue, s0);             // C_j (and Y_j) are ready
-            (void)hipStreamWaitEvent(sA, h->ev_glue, 0);
-            tall_waits_far();
-            launch_gh_apply(a, h->Cv2[par], h->Sp, la ? h->Yg : nullptr, sA);
-            Range rt("mpqr:wy_T");
-            launch_gh_reduce_f32(h->Sp, gh_num_partials(a), h->Sleaf, sA);
-            const int sh = lf.a0 - a.cb;
-            launch_t_leaf(h->Sleaf + (long)sh * 128 + sh, 1, 0, 128, lf.a0, lf.c0, lf.c1, h->Tf + lf.toff, h->Th + lf.toff,
-                          h->Tth + lf.toff, lf.ldt, sA, ld);
-            h->la_warm = warm_next;
-        }
-        h->la_dirty = true;
-        // this leaf's reflectors and T are complete on sA from here on: its column block of the block's T on the T stream
-        (void)hipEventRecord(h->ev_v, sA);
-        (void)hipStreamWaitEvent(sT, h->ev_v, 0);
-        t_column_block(lf, o);
-        // the block's remaining columns (beyond the next leaf when that one got the fp32 update): fp16 path on the tall stream
-        const int u0 = warm_next ? lf.c1 + 128 : lf.c1;
-        if (u0 < upd_end) {
-            Range rg("mpqr:in_block_update");
-            tall_waits_far();
-            h->inblock_stream = sA;
-            apply_node(h, lf, h->Aeff, h->lda, u0, upd_end, true, h->a_scale, false);
-            h->inblock_stream = nullptr;
-        }
-        // the pair Gram for the NEXT leaf's glue, if that leaf is in this block (across a block boundary it is issued by the
-        // next block, behind the far update its columns are waiting for)
-        h->la_pg_issued = false;
-        if (warm_next && j + 1 < nl && can_la(j + 1)) {
-            const Node& nx = h->nodes[leaves[j + 1]];
-            launch_gh_pair_gram(h->Aeff, h->lda, h->m, nx.c1, nx.c0, h->Gp2, h->maxwg, h->G2, sA);
-            (void)hipEventRecord(h->ev_pg, sA);
-            h->la_pg_issued = true;
-        }
-        h->la_idx++;
-    }
-    (void)hipEventRecord(h->ev_T[top], sT);
-    h->node_done_stream = sA;
-    return MPQR_OK;
-}
-
 // factor the sub-tree `id`; on return every T below it is ordered before whatever is enqueued on the chain stream next
 int factor_node(mpqr_handle_t h, int id, bool do_panel) {
     if (h->tq_on) {
@@ -907,11 +765,7 @@ int factor_node(mpqr_handle_t h, int id, bool do_panel) {
     const bool is_top = std::find(h->tops.begin(), h->tops.end(), id) != h->tops.end();
     h->node_done_stream = h->s0;
     const bool flat = do_panel && is_top && flat_block_ok(h, id, leaves);
-    if (!(flat && h->la_on) && h->la_dirty) {            // leaving the look-ahead schedule: the chain stream takes over
-        (void)hipEventRecord(h->ev_cold, h->sA); (void)hipStreamWaitEvent(h->s0, h->ev_cold, 0);
-        h->la_dirty = false; h->la_warm = false; h->la_pg_issued = false;
-    }
-    const int rc = flat ? (h->la_on ? factor_block_la(h, id, leaves) : factor_block_flat(h, id, leaves)) : factor_rec(h, id, do_panel);
+    const int rc = flat ? factor_block_flat(h, id, leaves) : factor_rec(h, id, do_panel);
     if (h->tq_on && !(h->defer_join && !h->force32)) {
         (void)hipEventRecord(h->ev_join, h->sT);
         (void)hipStreamWaitEvent(h->s0, h->ev_join, 0);
@@ -1047,6 +901,7 @@ int form_q(mpqr_handle_t h) {
         h->shadow = h->Qt; h->ldshadow = h->ldqt;
     }
     const bool rec = h->world == 1 && h->factored;        // timed like the far updates (mpqr_get_timings: ms_q_*)
+    h->n_q_ident_rows = 0;
     h->q_first = rec ? h->far_used : (size_t)-1;
     for (int t = (int)h->tops.size() - 1; t >= 0; t--) {
         if (h->pairs_ready && t < (int)h->qpair.size() && h->qpair[t] >= 0) {      // two blocks at once, K = 2 outer_block
@@ -1082,7 +937,6 @@ hipError_t create_update_stream(hipStream_t* st, int prio) {
     for (int i = 0; i < 8; i++) mask[i] = pat;
     hipError_t rc = hipExtStreamCreateWithCUMask(st, 8, mask);
     if (rc != hipSuccess) return hipStreamCreateWithPriority(st, hipStreamNonBlocking, prio);
-    gemm_register_stream_cus(*st, 8 * __builtin_popcount(pat));
     return rc;
 }
 
@@ -1137,13 +991,9 @@ int mpqr_create(mpqr_handle_t* out, int device) {
         hipStreamCreateWithPriority(&h->s0, hipStreamNonBlocking, prio_hi) != hipSuccess ||
         create_update_stream(&h->s1, prio_lo) != hipSuccess ||
         hipStreamCreateWithPriority(&h->sT, hipStreamNonBlocking, prio_hi) != hipSuccess ||
-        hipStreamCreateWithPriority(&h->sA, hipStreamNonBlocking, prio_hi) != hipSuccess ||
         hipEventCreateWithFlags(&h->ev_v, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&h->ev_x, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&h->ev_glue, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&h->ev_pg, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&h->ev_cold, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&h->ev_dist_chain, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&h->ev_dist_far, hipEventDisableTiming) != hipSuccess) {
         g_create_err = "hipSetDevice/hipStreamCreate failed";
@@ -1167,7 +1017,6 @@ int mpqr_destroy(mpqr_handle_t h) {
     (void)hipStreamSynchronize(h->s0);
     if (h->s1) (void)hipStreamSynchronize(h->s1);
     if (h->sT) (void)hipStreamSynchronize(h->sT);
-    if (h->sA) (void)hipStreamSynchronize(h->sA);
     free_plan(h);
     if (h->dmetric) (void)hipFree(h->dmetric);
     if (h->dscalar) (void)hipFree(h->dscalar);
@@ -1176,15 +1025,11 @@ int mpqr_destroy(mpqr_handle_t h) {
     if (h->ev_v) (void)hipEventDestroy(h->ev_v);
     if (h->ev_join) (void)hipEventDestroy(h->ev_join);
     if (h->ev_x) (void)hipEventDestroy(h->ev_x);
-    if (h->ev_glue) (void)hipEventDestroy(h->ev_glue);
-    if (h->ev_pg) (void)hipEventDestroy(h->ev_pg);
-    if (h->ev_cold) (void)hipEventDestroy(h->ev_cold);
     if (h->ev_dist_chain) (void)hipEventDestroy(h->ev_dist_chain);
     if (h->ev_dist_far) (void)hipEventDestroy(h->ev_dist_far);
     (void)hipStreamDestroy(h->s0);
     if (h->s1) (void)hipStreamDestroy(h->s1);
     if (h->sT) (void)hipStreamDestroy(h->sT);
-    if (h->sA) (void)hipStreamDestroy(h->sA);
     delete h;
     return MPQR_OK;
 }
@@ -1347,18 +1192,11 @@ static int plan_common(mpqr_handle_t h, int m, int n, int r, const mpqr_opts* op
     }
     if ((rc = dalloc(h, &h->S, h->s_elems))) return rc;
     if ((rc = dalloc(h, &h->Sleaf, (size_t)128 * 128))) return rc;
-    if ((rc = dalloc(h, &h->Wk, (size_t)2 * 128 * 128))) return rc;
     if ((rc = dalloc(h, &h->P, (size_t)2 * h->maxwg * 32))) return rc;
     if ((rc = dalloc(h, &h->Gp, (size_t)(h->m_pad / 128 + 2) * 16384))) return rc;
     if ((rc = dalloc(h, &h->Gs, (size_t)16384))) return rc;
     if ((rc = dalloc(h, &h->Sp, (size_t)(h->m_pad / 64 + 4) * 16384))) return rc;
     if ((rc = dalloc(h, &h->Cv, (size_t)16384))) return rc;
-    // Gram-level look-ahead (factor_block_la): ping-pong Gram / top-block / coefficient buffers, pair-Gram partials
-    h->Cv2[0] = h->Cv;
-    if ((rc = dalloc(h, &h->Cv2[1], (size_t)16384)) || (rc = dalloc(h, &h->Yg, (size_t)16384)) ||
-        (rc = dalloc(h, &h->GsN[0], (size_t)16384)) || (rc = dalloc(h, &h->GsN[1], (size_t)16384)) ||
-        (rc = dalloc(h, &h->Bsv[0], (size_t)16384)) || (rc = dalloc(h, &h->Bsv[1], (size_t)16384)) ||
-        (rc = dalloc(h, &h->G2, (size_t)2 * 16384)) || (rc = dalloc(h, &h->Gp2, (size_t)64 * 2 * 16384))) return rc;
     h->nflag = (int)h->nodes.size() + 1024;               // one flag per tree node (+ room for the stage calls' private trees)
     if ((rc = dalloc(h, &h->dflag, (size_t)h->nflag))) return rc;
     h->leaf_robust.assign(h->nodes.size(), 0);
@@ -1498,16 +1336,6 @@ static int run_block_loop(mpqr_handle_t h, std::vector<int>& flags) {
     }
     std::vector<int> lvtmp;
     h->defer_join = la && h->tq_on;
-    {   // Gram-level look-ahead inside flat blocks: OPT-IN (MPQR_LA=1).  Parity-green and slightly more accurate (the next
-        // leaf's columns get an fp32 update), but measured slower at 16384^2: the pair Gram for glue_{j+1} needs leaf j's
-        // update in the data, so glue_j -> apply_j -> update -> pair Gram -> glue_{j+1} is a serial cycle (~195 us of small
-        // tall kernels + the glue) that only the solve overlaps; per leaf 377 us with the exact-f32 glue (154 us), ~265 us
-        // projected with split-fp16 products, against 224 us for the flat schedule.  Kept as a tested experiment.
-        static const int la_env = []() { const char* e = getenv("MPQR_LA"); return e ? atoi(e) : 0; }();
-        h->la_on = la && h->tq_on && h->sA && la_env && !h->robust;
-        h->la_warm = false; h->la_pg_issued = false; h->la_dirty = false; h->la_idx = 0;
-        if (h->la_on) HIPCHK(h, hipStreamWaitEvent(h->sA, h->ev[3], 0));     // sA sees the copy-in / clears as s1 does
-    }
     // far updates beyond the next two blocks are taken pairwise (K = 2 outer blocks: the GEMMs run ~25 % faster and there
     // are half as many), with the pair T that Q formation needs anyway (MPQR_FAR_PAIR=0: every block on its own)
     static const int fp_env = []() { const char* e = getenv("MPQR_FAR_PAIR"); return e ? atoi(e) : 1; }();
@@ -1520,19 +1348,11 @@ static int run_block_loop(mpqr_handle_t h, std::vector<int>& flags) {
             h->wait_after_first_leaf = h->ev_cols2[t];
         }
         h->ext_c1 = ext[t] ? cfirst[t + 1] : 0;
-        h->la_next_robust = false;
-        if (t + 1 < nt) {
-            int fl = h->tops[t + 1];
-            while (h->nodes[fl].left >= 0) fl = h->nodes[fl].left;
-            // (a glue + fp32 update into a leaf that then starts cold is still a complete, exact update: only wasted work)
-            h->la_next_robust = h->robust || (fl < (int)h->leaf_robust.size() && h->leaf_robust[fl]) ||
-                                !flat_block_ok(h, h->tops[t + 1], lvtmp);
-        }
         const bool timed = h->chain_used + 2 <= h->chain_ev.size();
         if (timed) HIPCHK(h, hipEventRecord(h->chain_ev[h->chain_used], h->s0));
         rc = factor_node(h, h->tops[t], true);
         h->ext_c1 = 0;
-        if (rc) { h->defer_join = false; h->la_on = false; return rc; }
+        if (rc) { h->defer_join = false; return rc; }
         if (h->wait_after_first_leaf) {       // (no leaf launched: cannot happen, but never leave the wait pending)
             HIPCHK(h, hipStreamWaitEvent(h->s0, h->wait_after_first_leaf, 0));
             h->wait_after_first_leaf = nullptr;
@@ -1579,11 +1399,6 @@ static int run_block_loop(mpqr_handle_t h, std::vector<int>& flags) {
         if (h->opts.form_q && h->qroot >= 0) for (int id : h->qmerge_after[t]) merge_prefix(h, id, h->s1);   // ... or the T of all blocks so far
     }
     h->pairs_ready = h->opts.form_q && h->S2 != nullptr;     // (pairs or the whole tree)
-    if (h->la_dirty) {                                      // the tall stream's work, once
-        HIPCHK(h, hipEventRecord(h->ev_cold, h->sA));
-        HIPCHK(h, hipStreamWaitEvent(h->s0, h->ev_cold, 0));
-    }
-    h->la_on = false; h->la_dirty = false; h->la_warm = false; h->la_pg_issued = false;
     if (h->defer_join) {                                    // the T stream's work of every block, once
         h->defer_join = false;
         HIPCHK(h, hipEventRecord(h->ev_join, h->sT));
@@ -1627,6 +1442,7 @@ int mpqr_factor(mpqr_handle_t h) {
     if (h->opts.form_q) { if ((rc = form_q(h))) return rc; }
     HIPCHK(h, hipEventRecord(h->ev[2], h->s0));
     HIPCHK(h, hipGetLastError());
+    if (g_dispatch_error.exchange(0)) return fail(h, MPQR_ERR_STATE, "a GEMM of the factorisation found no kernel for its operand staging / epilogue");
     return MPQR_OK;
 }
 
@@ -1636,7 +1452,6 @@ int mpqr_sync(mpqr_handle_t h) {
     HIPCHK(h, hipStreamSynchronize(h->s0));
     if (h->s1) HIPCHK(h, hipStreamSynchronize(h->s1));
     if (h->sT) HIPCHK(h, hipStreamSynchronize(h->sT));
-    if (h->sA) HIPCHK(h, hipStreamSynchronize(h->sA));
     return MPQR_OK;
 }
 
@@ -1686,6 +1501,7 @@ int mpqr_get_timings(mpqr_handle_t h, mpqr_timings* t) {
     t->n_robust_leaves = h->n_robust_leaves;
     t->n_gh_leaves = h->n_gh_leaves;
     t->us_gh_solve = h->us_gh_solve;
+    t->n_q_ident_rows = h->n_q_ident_rows;
     h->last_t = *t;
     return MPQR_OK;
 }
@@ -1725,6 +1541,58 @@ int mpqr_bench_leaf_solve(mpqr_handle_t h, int w, int iters, float* us_per_launc
     if (e0) (void)hipEventDestroy(e0);
     if (e1) (void)hipEventDestroy(e1);
     (void)hipFree(dG); (void)hipFree(dA); (void)hipFree(dCv); (void)hipFree(dvd); (void)hipFree(dVh); (void)hipFree(dVt); (void)hipFree(dfl);
+    return rc;
+}
+
+// test aid: one GEMM through a chosen kernel (include/mpqr.h).  Operands are rounded on the host / by the library's own
+// quantisation kernel and zero-padded to the sizes the kernels may read (256 rows, the k step).
+int mpqr_gemm_test_f32(mpqr_handle_t h, const float* A, const float* B, float* C, int M, int N, int K, int kernel, int mode) {
+    if (!h || !A || !B || !C || M < 1 || N < 1 || K < 1 || (mode != 0 && mode != 2)) return MPQR_ERR_INVALID;
+    if (kernel != 1 && kernel != 2 && kernel != 6 && kernel != 8) return MPQR_ERR_INVALID;
+    if (kernel == 2 && mode != 0) return MPQR_ERR_INVALID;
+    if (mode == 2 && (M % 32) != 0) return fail(h, MPQR_ERR_INVALID, "mpqr_gemm_test_f32: the read-modify-write epilogue needs M % 32 == 0");
+    HIPCHK(h, hipSetDevice(h->device));
+    const int Mp = rup(M, 256), Np = rup(N, 256), Kp = rup(K, kernel == 8 ? 128 : 64);
+    std::vector<half_t> Ah((size_t)Mp * Kp, (half_t)0.f), Bt((size_t)Np * Kp, (half_t)0.f);
+    std::vector<float> Af, Cp((size_t)Mp * Np, 0.f);
+    for (int i = 0; i < M; i++) for (int k = 0; k < K; k++) Ah[(size_t)i * Kp + k] = (half_t)A[(size_t)i * K + k];
+    for (int k = 0; k < K; k++) for (int j = 0; j < N; j++) Bt[(size_t)j * Kp + k] = (half_t)B[(size_t)k * N + j];
+    if (kernel == 2) {                                       // fp32 source [K][M]: the kernel rounds it to fp16 while staging
+        Af.assign((size_t)Kp * Mp, 0.f);
+        for (int i = 0; i < M; i++) for (int k = 0; k < K; k++) Af[(size_t)k * Mp + i] = A[(size_t)i * K + k];
+    }
+    for (int i = 0; i < M; i++) for (int j = 0; j < N; j++) Cp[(size_t)i * Np + j] = C[(size_t)i * N + j];
+    half_t *dA = nullptr, *dB = nullptr; float *dAf = nullptr, *dC = nullptr; uint8_t *dA8 = nullptr, *dB8 = nullptr;
+    int rc = MPQR_OK;
+    auto bad = [&](hipError_t e) { if (e != hipSuccess && rc == MPQR_OK) rc = fail(h, MPQR_ERR_HIP, hipGetErrorString(e)); return e != hipSuccess; };
+    do {
+        if (bad(hipMalloc(&dA, Ah.size() * 2)) || bad(hipMalloc(&dB, Bt.size() * 2)) || bad(hipMalloc(&dC, Cp.size() * 4))) break;
+        if (bad(hipMemcpy(dA, Ah.data(), Ah.size() * 2, hipMemcpyHostToDevice)) || bad(hipMemcpy(dB, Bt.data(), Bt.size() * 2, hipMemcpyHostToDevice)) ||
+            bad(hipMemcpy(dC, Cp.data(), Cp.size() * 4, hipMemcpyHostToDevice))) break;
+        GemmArgs g{};
+        g.A = dA; g.lda = Kp; g.Bt = dB; g.ldb = Kp; g.C = dC; g.ldc = Np;
+        g.M = M; g.N = N; g.K = Kp; g.in_scale = 1.f; g.alpha = 1.f; g.nsplit = 1; g.nslab_in = 1;
+        const EMode em = mode == 2 ? E_SUB_F32 : E_STORE_F32;
+        bool ok = true;
+        if (kernel == 1) ok = launch_gemm_f16(A_H16, em, g, h->s0);
+        else if (kernel == 6) ok = launch_gemm2_f16(A_H16, em, g, h->s0, 0);
+        else if (kernel == 2) {
+            if (bad(hipMalloc(&dAf, Af.size() * 4)) || bad(hipMemcpy(dAf, Af.data(), Af.size() * 4, hipMemcpyHostToDevice))) break;
+            g.A = dAf; g.lda = Mp;
+            ok = launch_gemm2_f16(A_F32T, E_STORE_F32, g, h->s0, 0);
+        } else {
+            if (bad(hipMalloc(&dA8, Ah.size())) || bad(hipMalloc(&dB8, Bt.size()))) break;
+            launch_quant_h16_fp8(dA, Kp, dA8, Kp, Mp, Kp, 1.f, h->s0);
+            launch_quant_h16_fp8(dB, Kp, dB8, Kp, Np, Kp, 1.f, h->s0);
+            g.A = dA8; g.lda = Kp; g.Bt = (const half_t*)dB8; g.ldb = Kp;
+            ok = launch_gemm_fp8(em, g, h->s0);
+        }
+        if (!ok) { rc = fail(h, MPQR_ERR_INVALID, "mpqr_gemm_test_f32: the kernel does not take this shape / mode"); break; }
+        if (bad(hipStreamSynchronize(h->s0)) || bad(hipGetLastError())) break;
+        if (bad(hipMemcpy(Cp.data(), dC, Cp.size() * 4, hipMemcpyDeviceToHost))) break;
+        for (int i = 0; i < M; i++) for (int j = 0; j < N; j++) C[(size_t)i * N + j] = Cp[(size_t)i * Np + j];
+    } while (0);
+    (void)hipFree(dA); (void)hipFree(dB); (void)hipFree(dC); (void)hipFree(dAf); (void)hipFree(dA8); (void)hipFree(dB8);
     return rc;
 }
 
@@ -2295,7 +2163,7 @@ long mpqr_dist_block_bytes(mpqr_handle_t h, int s) {
     return (Kr * Wc + 2 * Kr * Kr) * (long)sizeof(half_t) + Kr * Kr * (long)sizeof(float);   // V^T | T | T^T (fp16) | T (fp32: pair merges)
 }
 
-int mpqr_dist_pack_block(mpqr_handle_t h, int s, void* dbuf) {
+int mpqr_dist_pack_block_async(mpqr_handle_t h, int s, void* dbuf) {
     int rc = need_plan(h, true); if (rc) return rc;
     if (s < 0 || s >= (int)h->tops.size() || !dbuf) return fail(h, MPQR_ERR_INVALID, "bad arguments");
     const Node& nd = h->nodes[h->tops[s]];
@@ -2306,11 +2174,22 @@ int mpqr_dist_pack_block(mpqr_handle_t h, int s, void* dbuf) {
     HIPCHK(h, hipMemcpyAsync(out + Kr * Wc, h->Th + nd.toff, Kr * Kr * sizeof(half_t), hipMemcpyDeviceToDevice, h->s0));
     HIPCHK(h, hipMemcpyAsync(out + Kr * Wc + Kr * Kr, h->Tth + nd.toff, Kr * Kr * sizeof(half_t), hipMemcpyDeviceToDevice, h->s0));
     HIPCHK(h, hipMemcpyAsync(out + Kr * Wc + 2 * Kr * Kr, h->Tf + nd.toff, Kr * Kr * sizeof(float), hipMemcpyDeviceToDevice, h->s0));
+    return MPQR_OK;
+}
+int mpqr_dist_pack_block(mpqr_handle_t h, int s, void* dbuf) {
+    int rc = mpqr_dist_pack_block_async(h, s, dbuf); if (rc) return rc;
     HIPCHK(h, hipStreamSynchronize(h->s0));
     return MPQR_OK;
 }
+// the HIP stream the pack / unpack copies are enqueued on (hipStream_t): a host that orders its broadcasts with events
+// (hipStreamWaitEvent) instead of synchronising uses the _async forms
+int mpqr_dist_chain_stream(mpqr_handle_t h, void** stream) {
+    if (!h || !stream) return MPQR_ERR_INVALID;
+    *stream = (void*)h->s0;
+    return MPQR_OK;
+}
 
-int mpqr_dist_unpack_block(mpqr_handle_t h, int s, const void* dbuf) {
+int mpqr_dist_unpack_block_async(mpqr_handle_t h, int s, const void* dbuf) {
     int rc = need_plan(h, true); if (rc) return rc;
     if (s < 0 || s >= (int)h->tops.size() || !dbuf) return fail(h, MPQR_ERR_INVALID, "bad arguments");
     if (s % h->world == h->rank) return MPQR_OK;            // the owner already holds everything
@@ -2324,6 +2203,10 @@ int mpqr_dist_unpack_block(mpqr_handle_t h, int s, const void* dbuf) {
     HIPCHK(h, hipMemcpyAsync(h->Tf + nd.toff, in + Kr * Wc + 2 * Kr * Kr, Kr * Kr * sizeof(float), hipMemcpyDeviceToDevice, h->s0));
     // Vh[rlo + c][a0 + k] = Vt[a0 + k][rlo + c]
     launch_transpose_h16(in, Wc, h->Vh + (size_t)rlo * h->ldvh + nd.a0, h->ldvh, (int)Kr, (int)Wc, h->s0);
+    return MPQR_OK;
+}
+int mpqr_dist_unpack_block(mpqr_handle_t h, int s, const void* dbuf) {
+    int rc = mpqr_dist_unpack_block_async(h, s, dbuf); if (rc) return rc;
     HIPCHK(h, hipStreamSynchronize(h->s0));              // the caller may refill the buffer (double-buffered broadcasts)
     return MPQR_OK;
 }

@@ -208,16 +208,18 @@ static void launch_one(const GemmArgs& g, hipStream_t s) {
     hipLaunchKernelGGL((gemm_f16_kernel<AM, EM>), grid, dim3(256), 0, s, a);
 }
 
-void launch_gemm_f16(AMode am, EMode em, const GemmArgs& g, hipStream_t s) {
+bool launch_gemm_f16(AMode am, EMode em, const GemmArgs& g, hipStream_t s) {
     if (am == A_F32S) am = A_F32;                          // the 128-tile kernel has no split staging (small shapes only)
-    if (g.M <= 0 || g.N <= 0 || g.K <= 0) return;
-#define MPQR_CASE(A_, E_) if (am == A_ && em == E_) { launch_one<A_, E_>(g, s); return; }
+    if (g.M <= 0 || g.N <= 0 || g.K <= 0) return true;
+    if (g.C2 || g.A2) return false;                        // hi + lo operands exist in the 256-wide kernels only: a caller bug
+#define MPQR_CASE(A_, E_) if (am == A_ && em == E_) { launch_one<A_, E_>(g, s); return true; }
     MPQR_CASE(A_F32T, E_STORE_F32)
     MPQR_CASE(A_F32, E_STORE_H16)
     MPQR_CASE(A_H16, E_SUB_F32)
     MPQR_CASE(A_H16, E_STORE_F32)
     MPQR_CASE(A_H16, E_STORE_H16)
 #undef MPQR_CASE
+    return false;                                          // no kernel for this staging / epilogue pair
 }
 
 // ------------------------------------------------------------------ exact-f32 MFMA GEMM (T merges, metrics, fp32 mode)

@@ -410,118 +410,10 @@ __device__ __forceinline__ void epilogue_sub_f32_dma(ACC (&acc)[4][2], char* sme
     }
 }
 
-// ------------------------------------------------------------------ all-DMA 4-stage ring (both operands fp16)
-// C[M x N] (-)= A[M][K] * Bt[N][K]^T with A and Bt both fp16 and k contiguous: the far trailing update
-// A2 -= V Y^T and the Q-formation twin, the dominant kernels of the factorisation.  256 x 256 x 32 tiles,
-// 512 threads = 8 waves (2 x 4), a ring of 4 LDS stages (4 x 32 KiB); A and Bt both go HBM -> LDS with
-// global_load_lds_dwordx4 (4 per wave and K-tile), three K-tiles in flight behind a COUNTED s_waitcnt vmcnt and
-// a raw s_barrier (one per K-tile; __syncthreads() would drain the DMA queue).  Source-side XOR swizzle as above.
-template <int EM, int DMA_EPI = 0>
-__global__ __launch_bounds__(512) void gemm3_f16_kernel(GemmArgs g, int tilesM, int tilesN) {
-    using namespace g2;
-    constexpr int BM = 256, BN = 256, BK = 32, NS = 4;
-    constexpr int ROWB = 64, CPR = 4, RB = 4;
-    constexpr int A_BYTES = BM * ROWB, STAGE = 2 * A_BYTES;
-    auto swz = [](int r, int c) -> int { return r * ROWB + ((c ^ ((r / RB) & (CPR - 1))) << 4); };
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int r = lane & 31, h = lane >> 5;
-    const int nwg = gridDim.x, bid = blockIdx.x;
-    const int q = nwg / 8, rem = nwg % 8, xcd = bid % 8;
-    const int seq = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + bid / 8;
-    const int groupsN = (tilesN + 7) / 8;
-    const int grp = seq / 32, within = seq % 32;
-    const int tm = (grp / groupsN) * 4 + within / 8;
-    const int tn = (grp % groupsN) * 8 + within % 8;
-    if (tm >= tilesM || tn >= tilesN) return;
-    const int bm = tm * BM, bn = tn * BN;
-    const int ktiles = g.K / BK;
-    const half_t* const A = (const half_t*)g.A;
-
-    // lane l of wave-instruction (i, wave) lands on row rb + l/4, physical chunk l%4 of a 16-row slab
-    auto issue = [&](int kt) {                              // kt past the end re-fetches the last tile into a free stage
-        char* base = g2_smem + (kt & (NS - 1)) * STAGE;
-        const int k = min(kt, ktiles - 1) * BK;
-#pragma unroll
-        for (int i = 0; i < 2; i++) {
-            const int rb = (i * 8 + wave) * 16;
-            const int rr = rb + (lane >> 2);
-            const int c = (lane & 3) ^ ((rr >> 2) & 3);
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(A + (long)(bm + rr) * g.lda + k + c * 8),
-                                             (__attribute__((address_space(3))) void*)(base + rb * ROWB), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g.Bt + (long)(bn + rr) * g.ldb + k + c * 8),
-                                             (__attribute__((address_space(3))) void*)(base + A_BYTES + rb * ROWB), 16, 0, 0);
-        }
-    };
-
-    floatx16 acc[4][2];
-#pragma unroll
-    for (int i = 0; i < 4; i++)
-#pragma unroll
-        for (int j = 0; j < 2; j++)
-#pragma unroll
-            for (int e = 0; e < 16; e++) acc[i][j][e] = 0.f;
-    const int wm = (wave >> 2) * 128, wn = (wave & 3) * 64;
-
-    for (int s = 0; s < 3; s++) issue(s);
-    for (int kt = 0; kt < ktiles; kt++) {
-        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");     // exactly three tiles are always in flight: kt has landed
-        __builtin_amdgcn_s_barrier();                        // tile kt landed everywhere; stage (kt-1)&3 is free
-        const char* As = g2_smem + (kt & (NS - 1)) * STAGE;
-        const char* Bs = As + A_BYTES;
-        half8 a[2][4], b[2][2];
-#pragma unroll
-        for (int ks = 0; ks < 2; ks++) {
-#pragma unroll
-            for (int i = 0; i < 4; i++) a[ks][i] = *(const half8*)(As + swz(wm + i * 32 + r, ks * 2 + h));
-#pragma unroll
-            for (int j = 0; j < 2; j++) b[ks][j] = *(const half8*)(Bs + swz(wn + j * 32 + r, ks * 2 + h));
-        }
-        issue(kt + 3);                                       // unconditional: keeps the loop body one basic block
-#pragma unroll
-        for (int ks = 0; ks < 2; ks++)
-#pragma unroll
-            for (int i = 0; i < 4; i++)
-#pragma unroll
-                for (int j = 0; j < 2; j++)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[ks][i], b[ks][j], acc[i][j], 0, 0, 0);
-        // issue order: the 12 fragment reads, then one LDS-DMA after every 4 MFMAs (its ~60-100 issue cycles hide in
-        // the matrix pipe's shadow instead of stalling both waves of the SIMD right after the barrier)
-        __builtin_amdgcn_sched_group_barrier(0x100, 12, 0);
-#pragma unroll
-        for (int q = 0; q < 4; q++) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
-            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-        }
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // the three trailing (redundant) tiles
-    __builtin_amdgcn_s_barrier();
-    const float alpha = g.alpha;
-    if (EM == E_SUB_F32) {
-        const bool full = DMA_EPI && bm + BM <= g.M && bn + BN <= g.N && bn >= g.col_lo;      // uniform over the workgroup
-        if (full) {
-            if (g.Ct) epilogue_sub_f32_dma<true>(acc, g2_smem, (float*)g.C, g.ldc, alpha, bm, bn, wave, lane, g.Ct, g.ldct, g.ct_scale);
-            else epilogue_sub_f32_dma<false>(acc, g2_smem, (float*)g.C, g.ldc, alpha, bm, bn, wave, lane);
-        }
-        else epilogue_sub_f32<4, 2>(acc, (float*)g.C, g.ldc, g.M, g.N, g.col_lo, alpha, bm + wm, bn + wn, r, h, g.Ct, g.ldct, g.ct_scale);
-        return;
-    }
-#pragma unroll
-    for (int i = 0; i < 4; i++)
-#pragma unroll
-        for (int j = 0; j < 2; j++) {
-            const int n = bn + wn + j * 32 + r;
-#pragma unroll
-            for (int e = 0; e < 16; e++) {
-                const int m = bm + wm + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-                if (m < g.M && n < g.N) ((float*)g.C)[(long)m * g.ldc + n] = alpha * acc[i][j][e];
-            }
-        }
-}
-
 // ------------------------------------------------------------------ gemm6: ping-pong wave groups, 256 x 256 x 64
-// Same contract as gemm3 (A, Bt fp16, k contiguous; E_SUB_F32 / E_STORE_F32), different main loop.  gemm3 syncs all
-// eight waves once per 32-deep K step and every wave then reads its fragments before anybody can issue an MFMA: the
-// matrix pipes idle while the LDS bursts (in steady state 44 % of the MFMA rate inside the K loop).  Here:
+// Both operands fp16, k contiguous, staged by LDS-DMA; E_SUB_F32 / E_STORE_F32 / E_STORE_H16.  (Round 1's 4-stage ring kernel
+// synchronised all eight waves once per 32-deep K step, and every wave then read its fragments before anybody could issue an
+// MFMA: the matrix pipes idled while the LDS bursts, 44 % of the MFMA rate inside the K loop.  It is gone; git history.)  Here:
 //   * K tile 64, two LDS buffers of 64 KiB (A 256 x 128 B, B 256 x 128 B, XOR-swizzled 16-B chunks as in gemm2);
 //   * a wave's 128 x 64 output is cut into four 64 x 32 quadrants; one PHASE computes one quadrant over the K tile
 //     (8 MFMA 32x32x16) and needs only the fragments of one 64-row A sub-tile / one 32-column B sub-tile:
@@ -744,440 +636,18 @@ static void launch6(const GemmArgs& g, hipStream_t s) {
     hipLaunchKernelGGL((gemm6_f16_kernel<EM, DMA_EPI>), dim3(groups * 32), dim3(512), LDS, s, g, tilesM, tilesN);
 }
 
-// ------------------------------------------------------------------ gemm7: persistent form of gemm6
-// One workgroup per CU walks the tile sequence (same XCD-aware order as above) with a stride of gridDim.x.  What this
-// buys at K = 1024, where a tile is only ~40 us of work: no workgroup turnaround between tiles (dispatch, LDS
-// allocation, argument loads: ~6-8 us per tile in gemm6, measured with in-kernel stamps) and the first seven half
-// tiles of the NEXT tile are already on their way into the LDS regions that the read-modify-write epilogue of the
-// current tile has released (chunk buffers 0..3 are exactly A(b0), B(b0), A(b1), B(b1) of the K loop's layout).
-// Vector-memory issue order of a wave in the epilogue of an interior tile with a successor ([k] = 4 DMAs of C chunk k,
-// st = 16 stores, eN = 2 DMAs of half tile N of the next tile):
-//     [0][1][2][3] st0 [4] st1 [5] st2 [6] st3 [7] st4 e0 e3 st5 e1 e2 st6 e4 st7 | e5 e6
-// The counted waits below follow from it.  Without a successor the same DMAs are issued on the current tile's operands
-// (dead data, in bounds) so that the counts stay compile-time constants; everything is drained before the kernel ends.
-template <int EM, int DMA_EPI>
-__global__ __launch_bounds__(512) void gemm7_f16_kernel(GemmArgs g, int tilesM, int tilesN, int total) {
-    using namespace g2;
-    constexpr int BM = 256, BN = 256, BK = 64;
-    constexpr int ROWB = 128, A_BYTES = BM * ROWB, BUF = 2 * A_BYTES;
-    auto swz = [](int r, int c) -> int { return r * ROWB + ((c ^ ((r >> 1) & 7)) << 4); };
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int r = lane & 31, h = lane >> 5;
-    const int ktiles = g.K / BK;
-    const half_t* const A = (const half_t*)g.A;
-    const int wr = wave >> 2, wc = wave & 3;
-    const int wm = wr * 128, wn = wc * 64;
-    const int groupsN = (tilesN + 7) / 8;
-    // virtual block vb -> tile (the order gemm6 uses for blockIdx.x); false: padding of a 4 x 8 group
-    auto tile_of = [&](int vb, int& bm, int& bn) -> bool {
-        const int q = total / 8, rem = total % 8, xcd = vb % 8;
-        const int seq = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + vb / 8;
-        const int grp = seq / 32, within = seq % 32;
-        const int tm = (grp / groupsN) * 4 + within / 8;
-        const int tn = (grp % groupsN) * 8 + within % 8;
-        bm = tm * BM; bn = tn * BN;
-        return tm < tilesM && tn < tilesN;
-    };
-    auto next_valid = [&](int vb, int& bm, int& bn) -> int {
-        for (; vb < total; vb += (int)gridDim.x)
-            if (tile_of(vb, bm, bn)) return vb;
-        return total;
-    };
-    // half tile s of K tile tau of the tile at (bmx, bnx) -> buffer tau & 1.  s: 0 = A-S0, 1 = B-S0, 2 = B-S1, 3 = A-S1.
-    // Addresses = wave-uniform 64-bit base (tile, K tile, row group: scalar registers) + a 32-bit per-lane byte offset
-    // that depends on the lane only (row inside the 8-row group, swizzled chunk): two VGPRs in all instead of a 64-bit
-    // address pair per DMA (the operand panels are far below 4 GiB).
-    const int lrow = lane >> 3;                               // row inside an 8-row group (every row0 below is a multiple of 8)
-    auto issue = [&](int bmx, int bnx, int tau, int sidx) {
-        const int k = min(tau, ktiles - 1) * BK;              // past the end: re-fetch the last tile into a dead region
-        char* buf = g2_smem + (tau & 1) * BUF;
-        const bool isA = (sidx == 0 || sidx == 3);
-        const int sub = (sidx == 0 || sidx == 1) ? 0 : 1;
-#pragma unroll
-        for (int i = 0; i < 2; i++) {
-            const int gidx = i * 8 + wave;                    // 16 row groups of 8 per half tile
-            int row0;
-            if (isA) row0 = (gidx >> 3) * 128 + sub * 64 + 8 * (gidx & 7);
-            else row0 = 64 * (gidx >> 2) + 32 * sub + 8 * (gidx & 3);
-            // swizzle: chunk ^ (((row0 + lrow) >> 1) & 7); row0 % 8 == 0 -> ((row0 >> 1) & 4) | (lrow >> 1)
-            const int xr = ((row0 >> 1) & 4);                 // uniform part of the XOR mask
-            const uint32_t c = (uint32_t)((lane & 7) ^ (xr | (lrow >> 1)));
-            if (isA) {
-                const char* base = (const char*)(A + (long)(bmx + row0) * g.lda + k);                  // uniform
-                const uint32_t off = (uint32_t)lrow * (uint32_t)(g.lda * 2) + c * 16u;                 // per lane
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + off),
-                                                 (__attribute__((address_space(3))) void*)(buf + row0 * ROWB), 16, 0, 0);
-            } else {
-                const char* base = (const char*)(g.Bt + (long)(bnx + row0) * g.ldb + k);
-                const uint32_t off = (uint32_t)lrow * (uint32_t)(g.ldb * 2) + c * 16u;
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + off),
-                                                 (__attribute__((address_space(3))) void*)(buf + A_BYTES + row0 * ROWB), 16, 0, 0);
-            }
-        }
-    };
-
-    floatx16 acc[4][2];
-    half8 af[4][2], b0a[4], b0b[4], b1[4];                    // A sub-tile fragments [k step][row tile]; B-S0 (two tiles), B-S1
-    auto read_A = [&](const char* As, int sub) {
-#pragma unroll
-        for (int ks = 0; ks < 4; ks++)
-#pragma unroll
-            for (int i2 = 0; i2 < 2; i2++) af[ks][i2] = *(const half8*)(As + swz(wm + sub * 64 + i2 * 32 + r, ks * 2 + h));
-    };
-    auto read_B = [&](const char* Bs, int sub, half8 (&b)[4]) {
-#pragma unroll
-        for (int ks = 0; ks < 4; ks++) b[ks] = *(const half8*)(Bs + swz(wn + sub * 32 + r, ks * 2 + h));
-    };
-    int bm = 0, bn = 0;
-    auto mma = [&](int subA, int subB, const half8 (&b)[4], int tau, int sidx) {
-        __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int ks = 0; ks < 4; ks++)
-#pragma unroll
-            for (int i2 = 0; i2 < 2; i2++)
-                acc[subA * 2 + i2][subB] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[ks][i2], b[ks], acc[subA * 2 + i2][subB], 0, 0, 0);
-        issue(bm, bn, tau, sidx);
-        __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
-        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-        __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
-        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
-        __builtin_amdgcn_s_setprio(0);
-    };
-    auto ktile = [&](int t, half8 (&b0)[4], half8 (&b0n)[4]) {     // phases and waits: see gemm6
-        const char* As = g2_smem + (t & 1) * BUF;
-        const char* Bs = As + A_BYTES;
-        const char* Bn = g2_smem + ((t + 1) & 1) * BUF + A_BYTES;
-        read_A(As, 0);
-        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_barrier();
-        mma(0, 0, b0, t + 1, 3);
-        __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_barrier();
-        read_B(Bs, 1, b1);
-        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_barrier();
-        mma(0, 1, b1, t + 2, 0);
-        __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_barrier();
-        read_A(As, 1);
-        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_barrier();
-        mma(1, 1, b1, t + 2, 1);
-        __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_barrier();
-        read_B(Bn, 0, b0n);
-        __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_barrier();
-        mma(1, 0, b0, t + 2, 2);
-        __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_barrier();
-    };
-
-    int nbm = 0, nbn = 0;
-    int vb = next_valid((int)blockIdx.x, bm, bn);
-    bool pre = false;                                         // half tiles 0..6 of this tile were issued by the previous epilogue
-    while (vb < total) {
-        const int nvb = next_valid(vb + (int)gridDim.x, nbm, nbn);
-        const bool has_next = nvb < total;
-#pragma unroll
-        for (int i = 0; i < 4; i++)
-#pragma unroll
-            for (int j = 0; j < 2; j++)
-#pragma unroll
-                for (int e = 0; e < 16; e++) acc[i][j][e] = 0.f;
-        if (!pre) {
-            // prologue: half tiles 0..6 (tile 0 complete, A-S0 / B-S0 / B-S1 of tile 1); A-S0(0) and B-S0(0) landed
-            issue(bm, bn, 0, 0); issue(bm, bn, 0, 1); issue(bm, bn, 0, 2); issue(bm, bn, 0, 3);
-            issue(bm, bn, 1, 0); issue(bm, bn, 1, 1); issue(bm, bn, 1, 2);
-            asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
-        } else {
-            asm volatile("s_waitcnt vmcnt(40)" ::: "memory");    // ... e1 | e2 st6 e4 st7 e5 e6 : 2 + 16 + 2 + 16 + 4
-        }
-        __builtin_amdgcn_s_barrier();
-        read_B(g2_smem + A_BYTES, 0, b0a);
-        if (wr == 1) __builtin_amdgcn_s_barrier();           // second group: half a phase behind
-        for (int t = 0; t < ktiles; t += 2) {
-            ktile(t, b0a, b0b);
-            if (t + 1 < ktiles) ktile(t + 1, b0b, b0a);
-        }
-        if (wr == 0) __builtin_amdgcn_s_barrier();           // first group waits for the second one's last half phase
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the trailing (redundant) half tiles
-        __builtin_amdgcn_s_barrier();
-        const float alpha = g.alpha;
-        pre = false;
-        if (EM == E_SUB_F32) {
-            const bool full = DMA_EPI && bm + BM <= g.M && bn + BN <= g.N && bn >= g.col_lo;  // uniform over the workgroup
-            if (full) {
-                float* const C = (float*)g.C;
-                const long ldc = g.ldc;
-                const int pbm = has_next ? nbm : bm, pbn = has_next ? nbn : bn;     // whose operands the tail prefetches
-                const char* const ctile = (const char*)(C + (long)bm * ldc + bn);                            // uniform
-                const uint32_t lane16 = 16u * (uint32_t)lane;
-                auto cissue = [&](int c) {
-                    char* base = g2_smem + (c & 3) * 32768 + wave * 4096;
-                    const char* src = ctile + ((long)((wave >> 2) * 128 + (wave & 3) * 4 + 16 * c) * ldc) * 4;   // uniform
-#pragma unroll
-                    for (int q = 0; q < 4; q++)
-                        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (long)q * ldc * 4 + lane16),
-                                                         (__attribute__((address_space(3))) void*)(base + q * 1024), 16, 0, 0);
-                };
-                cissue(0); cissue(1); cissue(2); cissue(3);
-                char* const ptile = (char*)(C + (long)(bm + wr * 128) * ldc + bn + wn);                       // uniform
-                const uint32_t poff = (uint32_t)(4 * h) * (uint32_t)(ldc * 4) + 4u * (uint32_t)r;             // per lane
-#pragma unroll
-                for (int c = 0; c < 8; c++) {
-                    if (c == 0) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");          // [1][2][3]
-                    else if (c == 1) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");     // [2][3] st0
-                    else if (c == 2) asm volatile("s_waitcnt vmcnt(40)" ::: "memory");     // [3] st0 [4] st1
-                    else asm volatile("s_waitcnt vmcnt(56)" ::: "memory");                 // c = 3..5: st [c+1] st [c+2] st;
-                                                                                           // 6: st3 [7] st4 e0 e3 st5; 7: st4 e0 e3 st5 e1 e2 st6
-                    __builtin_amdgcn_s_barrier();              // chunk c landed for every wave; everybody is done reading chunk c-1
-                    if (c >= 1 && c + 3 < 8) cissue(c + 3);    // into the buffer chunk c-1 has just released
-                    if (c == 5) { issue(pbm, pbn, 0, 0); issue(pbm, pbn, 0, 3); }          // A(b0) = buffer of chunk 4
-                    if (c == 6) { issue(pbm, pbn, 0, 1); issue(pbm, pbn, 0, 2); }          // B(b0) = buffer of chunk 5
-                    if (c == 7) { issue(pbm, pbn, 1, 0); }                                 // A(b1) = buffer of chunk 6
-                    const int i = c >> 1, hf = c & 1;
-                    const char* base = g2_smem + (c & 3) * 32768 + (16 * wr + 4 * h) * 1024 + (wn + r) * 4;
-                    float oldv[2][8];
-#pragma unroll
-                    for (int j = 0; j < 2; j++)
-#pragma unroll
-                        for (int ee = 0; ee < 8; ee++)
-                            oldv[j][ee] = *(const float*)(base + ((ee & 3) + 8 * (ee >> 2)) * 1024 + j * 128);
-#pragma unroll
-                    for (int j = 0; j < 2; j++) {
-#pragma unroll
-                        for (int q = 0; q < 2; q++)
-#pragma unroll
-                            for (int e = 0; e < 4; e++) {
-                                char* prow = ptile + ((long)(16 * c + 8 * q + e) * ldc + j * 32) * 4;           // uniform
-                                *(float*)(prow + poff) = oldv[j][q * 4 + e] - alpha * acc[i][j][8 * hf + q * 4 + e];
-                            }
-                    }
-                }
-                __builtin_amdgcn_s_barrier();                  // everybody is done reading chunk 7: B(b1) is free
-                issue(pbm, pbn, 1, 1); issue(pbm, pbn, 1, 2);
-                pre = has_next;
-                if (!has_next) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); }
-            } else {
-                epilogue_sub_f32<4, 2>(acc, (float*)g.C, g.ldc, g.M, g.N, g.col_lo, alpha, bm + wm, bn + wn, r, h, g.Ct, g.ldct, g.ct_scale);
-            }
-        } else {
-#pragma unroll
-            for (int i = 0; i < 4; i++)
-#pragma unroll
-                for (int j = 0; j < 2; j++) {
-                    const int n = bn + wn + j * 32 + r;
-#pragma unroll
-                    for (int e = 0; e < 16; e++) {
-                        const int m = bm + wm + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-                        if (m < g.M && n < g.N) ((float*)g.C)[(long)m * g.ldc + n] = alpha * acc[i][j][e];
-                    }
-                }
-        }
-        vb = nvb; bm = nbm; bn = nbn;
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-}
-
-static int g_stream_cus_default = 0;
-struct StreamCus { hipStream_t s; int cus; };
-static StreamCus g_stream_cus[16];
-static int g_stream_cus_n = 0;
-// the driver tells the GEMM launchers how many CUs a stream may use (CU-masked update stream): persistent grids are sized to it
-void gemm_register_stream_cus(hipStream_t s, int cus) {
-    for (int i = 0; i < g_stream_cus_n; i++) if (g_stream_cus[i].s == s) { g_stream_cus[i].cus = cus; return; }
-    if (g_stream_cus_n < 16) g_stream_cus[g_stream_cus_n++] = StreamCus{s, cus};
-}
-static int stream_cus(hipStream_t s) {
-    for (int i = 0; i < g_stream_cus_n; i++) if (g_stream_cus[i].s == s) return g_stream_cus[i].cus;
-    if (!g_stream_cus_default) {
-        int dev = 0; hipDeviceProp_t p;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess) g_stream_cus_default = p.multiProcessorCount;
-        if (g_stream_cus_default <= 0) g_stream_cus_default = 256;
-    }
-    return g_stream_cus_default;
-}
-
-template <int EM, int DMA_EPI>
-static void launch7(const GemmArgs& g, hipStream_t s) {
-    constexpr int LDS = 2 * 2 * 256 * 128;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)gemm7_f16_kernel<EM, DMA_EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-        attr_set = true;
-    }
-    const int tilesM = (g.M + 255) / 256, tilesN = (g.N + 255) / 256;
-    const int groups = ((tilesM + 3) / 4) * ((tilesN + 7) / 8);
-    const int total = groups * 32;
-    const int grid = std::min(total, stream_cus(s));          // one workgroup per CU (128 KiB of LDS each)
-    hipLaunchKernelGGL((gemm7_f16_kernel<EM, DMA_EPI>), dim3(grid), dim3(512), LDS, s, g, tilesM, tilesN, total);
-}
-
-// gemm4: the same all-DMA pipeline with a 256 x 128 x 32 tile, 256 threads (2 x 2 waves of 128 x 64) and a ring of
-// THREE stages (72 KiB), so that TWO workgroups live on a CU.  The read-modify-write epilogue of C -= V Y^T is a
-// memory phase (HBM round trips, MFMA idle) that takes about as long as the K loop at K = 1024; with one workgroup
-// per CU the two cannot overlap, with two independent workgroups one tile's epilogue runs under the other's K loop.
-template <int EM>
-__global__ __launch_bounds__(256, 2) void gemm4_f16_kernel(GemmArgs g, int tilesM, int tilesN) {
-    using namespace g2;
-    constexpr int BM = 256, BN = 128, BK = 32, NS = 3;
-    constexpr int ROWB = 64, CPR = 4, RB = 4;
-    constexpr int A_BYTES = BM * ROWB, B_BYTES = BN * ROWB, STAGE = A_BYTES + B_BYTES;
-    auto swz = [](int r, int c) -> int { return r * ROWB + ((c ^ ((r / RB) & (CPR - 1))) << 4); };
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int r = lane & 31, h = lane >> 5;
-    const int nwg = gridDim.x, bid = blockIdx.x;
-    const int q = nwg / 8, rem = nwg % 8, xcd = bid % 8;
-    const int seq = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + bid / 8;
-    // 64 concurrent tiles per XCD (two per CU): groups of 4 x 16 tiles = 1024 rows x 2048 columns share an L2
-    const int groupsN = (tilesN + 15) / 16;
-    const int grp = seq / 64, within = seq % 64;
-    const int tm = (grp / groupsN) * 4 + within / 16;
-    const int tn = (grp % groupsN) * 16 + within % 16;
-    if (tm >= tilesM || tn >= tilesN) return;
-    const int bm = tm * BM, bn = tn * BN;
-    const int ktiles = g.K / BK;
-    const half_t* const A = (const half_t*)g.A;
-
-    // one wave-instruction fills 1 KiB = 16 rows; A: 16 of them (4 per wave), B: 8 (2 per wave)
-    auto issue = [&](int kt) {                              // kt past the end re-fetches the last tile into a free stage
-        char* base = g2_smem + (kt % NS) * STAGE;
-        const int k = min(kt, ktiles - 1) * BK;
-#pragma unroll
-        for (int i = 0; i < 4; i++) {
-            const int rb = (i * 4 + wave) * 16;
-            const int rr = rb + (lane >> 2);
-            const int c = (lane & 3) ^ ((rr >> 2) & 3);
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(A + (long)(bm + rr) * g.lda + k + c * 8),
-                                             (__attribute__((address_space(3))) void*)(base + rb * ROWB), 16, 0, 0);
-        }
-#pragma unroll
-        for (int i = 0; i < 2; i++) {
-            const int rb = (i * 4 + wave) * 16;
-            const int rr = rb + (lane >> 2);
-            const int c = (lane & 3) ^ ((rr >> 2) & 3);
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g.Bt + (long)(bn + rr) * g.ldb + k + c * 8),
-                                             (__attribute__((address_space(3))) void*)(base + A_BYTES + rb * ROWB), 16, 0, 0);
-        }
-    };
-
-    floatx16 acc[4][2];
-#pragma unroll
-    for (int i = 0; i < 4; i++)
-#pragma unroll
-        for (int j = 0; j < 2; j++)
-#pragma unroll
-            for (int e = 0; e < 16; e++) acc[i][j][e] = 0.f;
-    const int wm = (wave >> 1) * 128, wn = (wave & 1) * 64;
-
-    issue(0); issue(1);
-    for (int kt = 0; kt < ktiles; kt++) {
-        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");     // exactly two tiles (6 DMAs each) are in flight: kt has landed
-        __builtin_amdgcn_s_barrier();                        // tile kt landed everywhere; stage (kt-1)%3 is free
-        const char* As = g2_smem + (kt % NS) * STAGE;
-        const char* Bs = As + A_BYTES;
-        half8 a[2][4], b[2][2];
-#pragma unroll
-        for (int ks = 0; ks < 2; ks++) {
-#pragma unroll
-            for (int i = 0; i < 4; i++) a[ks][i] = *(const half8*)(As + swz(wm + i * 32 + r, ks * 2 + h));
-#pragma unroll
-            for (int j = 0; j < 2; j++) b[ks][j] = *(const half8*)(Bs + swz(wn + j * 32 + r, ks * 2 + h));
-        }
-        issue(kt + 2);                                       // unconditional: keeps the loop body one basic block
-#pragma unroll
-        for (int ks = 0; ks < 2; ks++)
-#pragma unroll
-            for (int i = 0; i < 4; i++)
-#pragma unroll
-                for (int j = 0; j < 2; j++)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[ks][i], b[ks][j], acc[i][j], 0, 0, 0);
-        __builtin_amdgcn_sched_group_barrier(0x100, 12, 0);
-        // issue order: the 12 fragment reads, then one LDS-DMA after every 2-3 MFMAs (6 DMAs, 16 MFMAs)
-#pragma unroll
-        for (int q2 = 0; q2 < 4; q2++) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
-            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-        }
-#pragma unroll
-        for (int q2 = 0; q2 < 2; q2++) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
-            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-        }
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // the two trailing (redundant) tiles
-    __builtin_amdgcn_s_barrier();
-    const float alpha = g.alpha;
-    if (EM == E_SUB_F32) {
-        epilogue_sub_f32<4, 2>(acc, (float*)g.C, g.ldc, g.M, g.N, g.col_lo, alpha, bm + wm, bn + wn, r, h, g.Ct, g.ldct, g.ct_scale);
-        return;
-    }
-#pragma unroll
-    for (int i = 0; i < 4; i++)
-#pragma unroll
-        for (int j = 0; j < 2; j++) {
-            const int n = bn + wn + j * 32 + r;
-#pragma unroll
-            for (int e = 0; e < 16; e++) {
-                const int m = bm + wm + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-                if (m < g.M && n < g.N) ((float*)g.C)[(long)m * g.ldc + n] = alpha * acc[i][j][e];
-            }
-        }
-}
-
-template <int EM>
-static void launch4(const GemmArgs& g, hipStream_t s) {
-    constexpr int LDS = 3 * (256 + 128) * 64;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)gemm4_f16_kernel<EM>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-        attr_set = true;
-    }
-    const int tilesM = (g.M + 255) / 256, tilesN = (g.N + 127) / 128;
-    const int groups = ((tilesM + 3) / 4) * ((tilesN + 15) / 16);
-    hipLaunchKernelGGL((gemm4_f16_kernel<EM>), dim3(groups * 64), dim3(256), LDS, s, g, tilesM, tilesN);
-}
-
-template <int EM, int DMA_EPI = 0>
-static void launch3(const GemmArgs& g, hipStream_t s) {
-    constexpr int LDS = 4 * 2 * 256 * 64;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)gemm3_f16_kernel<EM, DMA_EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-        attr_set = true;
-    }
-    const int tilesM = (g.M + 255) / 256, tilesN = (g.N + 255) / 256;
-    const int groups = ((tilesM + 3) / 4) * ((tilesN + 7) / 8);
-    hipLaunchKernelGGL((gemm3_f16_kernel<EM, DMA_EPI>), dim3(groups * 32), dim3(512), LDS, s, g, tilesM, tilesN);
-}
-
 // Large-shape path.  Preconditions (checked by the caller, driver.hip): no split-K, K % 64 == 0, and the
 // operand buffers are readable up to the next multiple of 256 rows (tiles are loaded unmasked; rows past M / N
 // only feed outputs that the epilogue masks).  config: 0 = 256x256x64 / 512 threads, 1 = 256x128x32 / 256 threads.
 bool launch_gemm2_f16(AMode am, EMode em, const GemmArgs& g, hipStream_t s, int config) {
     if (am == A_H16 && config != 2 && config != 1) {          // config 2 keeps the register-staged kernel (A/B comparison)
-        static const int use4 = []() { const char* e = getenv("MPQR_GEMM4"); return e ? atoi(e) : 0; }();
-        if (em == E_SUB_F32 && use4) { launch4<E_SUB_F32>(g, s); return true; }
         static const int dma_epi = []() { const char* e = getenv("MPQR_DMA_EPILOGUE"); return e ? atoi(e) : 1; }();
         static const int use6 = []() { const char* e = getenv("MPQR_GEMM6"); return e ? atoi(e) : 1; }();
-        // gemm7 (persistent, next tile's operands prefetched during the epilogue) measured SLOWER than gemm6 (662 vs 749
-        // TFLOP/s at K = 1024, 906 vs 975 at K = 2048): opt-in only
-        static const int use7 = []() { const char* e = getenv("MPQR_GEMM7"); return e ? atoi(e) : 0; }();
-        if (use7 && em == E_SUB_F32 && dma_epi && (g.K % 64) == 0) { launch7<E_SUB_F32, 1>(g, s); return true; }
         if (use6 && (g.K % 64) == 0) {
             if (em == E_SUB_F32) { if (dma_epi) launch6<E_SUB_F32, 1>(g, s); else launch6<E_SUB_F32, 0>(g, s); return true; }
             if (em == E_STORE_F32) { launch6<E_STORE_F32, 0>(g, s); return true; }
             if (em == E_STORE_H16) { launch6<E_STORE_H16, 0>(g, s); return true; }
         }
-        if (em == E_SUB_F32 && dma_epi) { launch3<E_SUB_F32, 1>(g, s); return true; }
-        if (em == E_SUB_F32) { launch3<E_SUB_F32>(g, s); return true; }
-        if (em == E_STORE_F32) { launch3<E_STORE_F32>(g, s); return true; }
     }
 #define MPQR_CASE2(A_, E_)                                                  \
     if (am == A_ && em == E_) {                                             \

@@ -651,307 +651,6 @@ __global__ __launch_bounds__(GH_SOLVE_THREADS) void gh_solve_kernel(LeafArgs a, 
     KT(); KT_DUMP(5, "gh_solve load|loop|out|inverse|cstore");
 }
 
-// ------------------------------------------------------------------ gh_solve2: blocked form of gh_solve
-// Same inputs and outputs as gh_solve_kernel (R, V_top, vdiag, the coefficient matrix C of V_low = A_low C, the flag),
-// computed by Householder RECONSTRUCTION instead of a reflector-by-reflector recursion (128 barrier-separated steps of
-// ~2050 cycles each, one LDS round trip per step).  With G = A^T A over the leaf's rows and B0 its top w x w block:
-//   1. G = Cc^T Cc          Cholesky, fp64 (this is where cond(A)^2 lives), blocked by 16
-//   2. Qt = B0 Cc^-1        the top block of the thin orthogonal factor A Cc^-1
-//   3. Qt - S = L U         LU without pivoting, S = diag(s_k), s_k = -sgn(diagonal entry met at step k) (sgn(0) = +1):
-//                           |pivot| >= 1, so this is stable in fp32 (Ballard et al., "Reconstructing Householder vectors
-//                           from TSQR"); the sign rule is the reference's  R_kk = -sgn(u0) ||u||  (qr.cu:229-235)
-//   4. R = S Cc,  v_kk = sgn(U_kk) sqrt(|U_kk| / 2),  V_top = L diag(v_kk),  C = Cc^-1 U^-1 diag(v_kk)
-// In exact arithmetic these are the reference's Householder vectors (unit 2-norm) and its R.  Sequential steps run
-// inside one wave on a 16 x 16 block held in registers (cross-lane moves by v_readlane, no LDS, no barrier); everything
-// else is a small matrix product.  One workgroup of 1024 threads; LDS: the fp64 Gram matrix during step 1, two fp32
-// 128 x 129 matrices afterwards; Cc and Cc^-1 are parked in a global scratch (2 x 64 KiB, L2 resident).
-constexpr int GD = 130;                                   // LDS row stride (doubles) of the Gram matrix
-// 32 x 32 tile product as lds_mm32, but k runs over [0, kn) in steps of 2 (kn even, any multiple of 2)
-__device__ __forceinline__ floatx16p lds_mm32_k(const float* A, int lda, const float* B, int ldb, int kn, int lane) {
-    const int r = lane & 31, kk = lane >> 5;
-    floatx16p acc;
-#pragma unroll
-    for (int e = 0; e < 16; e++) acc[e] = 0.f;
-    for (int k1 = 0; k1 < kn; k1 += 2) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(A[r * lda + k1 + kk], B[(k1 + kk) * ldb + r], acc, 0, 0, 0);
-    return acc;
-}
-
-__global__ __launch_bounds__(1024) void gh_solve2_kernel(LeafArgs a, const double* __restrict__ G, float* __restrict__ Cv,
-                                                         int* __restrict__ flag, float* __restrict__ Wk /* 2 x 16384 */) {
-    double* Gd = (double*)gh_smem;                         // [128][GD]   (step 1)
-    float* Ss = (float*)gh_smem;                           // [TP][TPS]   (steps 2-4)
-    float* Ts = Ss + TP * TPS;                             // [TP][TPS]
-    __shared__ double col0[GW];
-    __shared__ double rdiag[16];
-    __shared__ float tdiag[GW], sgn_s[GW], udiag[GW], dv[GW];
-    __shared__ int lflag, cmask[GW];
-    float* const W1 = Wk;                                  // Cc (fp32, upper)
-    float* const W2 = Wk + GW * GW;                        // Cc^-1
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int w = a.c1 - a.c0, off = a.c0 - a.cb;
-    const int nb16 = (w + 15) / 16, nb32 = (w + 31) / 32;
-    KT_DECL; KT();
-
-    // ---- load G (identity outside the leaf: the padding decouples)
-    for (int e = tid; e < GW * GW; e += 1024) {
-        const int i = e >> 7, j = e & 127;
-        double g = (i == j) ? 1.0 : 0.0;
-        if (i < w && j < w) g = G[(off + i) * GW + off + j];
-        Gd[i * GD + j] = g;
-        if (i == j) { col0[i] = g; cmask[i] = 1; }
-    }
-    if (tid == 0) lflag = 0;
-    __syncthreads();
-
-    KT();
-    // ---- 1. Cholesky, right-looking, blocks of 16 (upper triangle of Gd becomes Cc; only upper 16 x 16 tiles are maintained)
-    for (int b = 0; b < nb16; b++) {
-        const int k0 = 16 * b;
-        if (wave == 0) {
-            // diagonal block in registers: lane i < 16 holds row i (mirrored from the upper triangle)
-            const int i = lane & 15;
-            double d[16];
-#pragma unroll
-            for (int j = 0; j < 16; j++) d[j] = (j >= i) ? Gd[(k0 + i) * GD + k0 + j] : Gd[(k0 + j) * GD + k0 + i];
-#pragma unroll
-            for (int kk = 0; kk < 16; kk++) {
-                const double p = bcast_lane_d(d[kk], kk);                  // N[k][k] after the earlier steps
-                const bool ok = p > 1e-30 && p < 1e30;
-                const double pd = ok ? p : 1.0;
-                double y = refine_rsqrt(pd, (double)rsqrtf((float)pd));
-                y = ok ? y : 0.0;
-                if (lane == 0) {
-                    if (!ok || p < GH_RHO_MIN * col0[k0 + kk]) lflag = 1;
-                    cmask[k0 + kk] = ok ? 1 : 0;
-                    rdiag[kk] = y;                                          // 1 / Cc[k][k]
-                }
-                const double mi = d[kk] * y;                               // Cc[k][i] by symmetry (lanes i > kk)
-#pragma unroll
-                for (int j = kk; j < 16; j++) {
-                    const double ckj = bcast_lane_d(d[j], kk) * y;         // Cc[k][j]
-                    if (i == kk) d[j] = ckj;                               // row k is final
-                    else if (i > kk && j > kk) d[j] = fma(-mi, ckj, d[j]);
-                }
-            }
-            if (lane < 16) {
-#pragma unroll
-                for (int j = 0; j < 16; j++) if (j >= i) Gd[(k0 + i) * GD + k0 + j] = d[j];
-            }
-        }
-        __syncthreads();
-        // row panel: Cc[blk][j] = Cdd^-T N[blk][j] for the columns right of the block, one thread per column
-        if (tid < GW && tid >= k0 + 16 && tid < 16 * nb16) {
-            const int j = tid;
-            double x[16];
-#pragma unroll
-            for (int i = 0; i < 16; i++) x[i] = Gd[(k0 + i) * GD + j];
-#pragma unroll
-            for (int i = 0; i < 16; i++) {
-                double sacc = x[i];
-#pragma unroll
-                for (int p = 0; p < i; p++) sacc = fma(-Gd[(k0 + p) * GD + k0 + i], x[p], sacc);
-                x[i] = sacc * rdiag[i];
-            }
-#pragma unroll
-            for (int i = 0; i < 16; i++) Gd[(k0 + i) * GD + j] = x[i];
-        }
-        __syncthreads();
-        // trailing update of the upper 16 x 16 tiles (ti <= tj, both right of the block) on v_mfma_f64_16x16x4_f64
-        {
-            typedef double double4g __attribute__((ext_vector_type(4)));
-            const int nt = nb16 - 1 - b;                                     // tile rows / columns right of the block
-            const int ntile = nt * (nt + 1) / 2;
-            const int li = lane & 15, lk = lane >> 4;
-            for (int t = wave; t < ntile; t += 16) {
-                int ti = 0, rem = t;
-                while (rem >= nt - ti) { rem -= nt - ti; ti++; }
-                const int tj = ti + rem;
-                const int I0 = k0 + 16 * (ti + 1), J0 = k0 + 16 * (tj + 1);
-                double4g acc = {0, 0, 0, 0};
-#pragma unroll
-                for (int q = 0; q < 4; q++)
-                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Gd[(k0 + 4 * q + lk) * GD + I0 + li], Gd[(k0 + 4 * q + lk) * GD + J0 + li], acc, 0, 0, 0);
-#pragma unroll
-                for (int v = 0; v < 4; v++) Gd[(I0 + lk + 4 * v) * GD + J0 + li] -= acc[v];     // D[i][j]: lane j + 16 (i % 4), element i / 4
-            }
-        }
-        __syncthreads();
-    }
-    KT();
-    // ---- park Cc (fp32) in the scratch; build the inverse's inputs
-    for (int e = tid; e < GW * GW; e += 1024) {
-        const int i = e >> 7, j = e & 127;
-        W1[e] = (j >= i) ? (float)Gd[i * GD + j] : 0.f;
-    }
-    __syncthreads();                                         // Gd is dead: its LDS becomes Ss / Ts
-    for (int e = tid; e < GW * GW; e += 1024) {
-        const int i = e >> 7, j = e & 127;
-        const float c = W1[e];
-        if (i == j) tdiag[i] = (cmask[i] && c > 0.f) ? 1.0f / c : 0.f;
-        Ss[i * TPS + j] = (j > i) ? c : 0.f;
-        Ts[i * TPS + j] = 0.f;
-    }
-    __syncthreads();
-    KT();
-    tri_inverse_128(Ss, tdiag, Ts, nb32, tid);                // Ts = Cc^-1 (identity on the padding: tdiag = 1)
-    KT();
-    // ---- 2. Qt = B0 Cc^-1
-    for (int e = tid; e < GW * GW; e += 1024) {
-        const int i = e >> 7, j = e & 127;
-        W2[e] = Ts[i * TPS + j];
-        float bv = (i == j) ? 1.f : 0.f;
-        if (i < w && j < w) bv = a.A[(long)(a.c0 + i) * a.lda + a.c0 + j];
-        Ss[i * TPS + j] = bv;
-    }
-    __syncthreads();
-    {
-        const int bi = wave >> 2, bj = wave & 3;
-        const floatx16p acc = lds_mm32(&Ss[32 * bi * TPS], TPS, &Ts[32 * bj], TPS, 0, 32 * (bj + 1), lane);    // Cc^-1 upper
-        __syncthreads();
-        lds_store32(&Ss[32 * bi * TPS + 32 * bj], TPS, acc, 1.f, lane);
-    }
-    __syncthreads();
-    KT();
-    // ---- 3. LU with the sign choice, blocks of 16, in place in Ss (L strictly below the diagonal, U on and above it)
-    for (int b = 0; b < nb16; b++) {
-        const int k0 = 16 * b;
-        const int wa = k0 >> 6;                                // the wave (of waves 0 / 1: lane = row) that holds the block's rows
-        if (wave == wa) {
-            const int row = 64 * wa + lane;
-            float d[16];
-#pragma unroll
-            for (int j = 0; j < 16; j++) d[j] = Ss[row * TPS + k0 + j];
-            const int lp0 = k0 & 63;
-#pragma unroll
-            for (int kk = 0; kk < 16; kk++) {
-                const int lp = lp0 + kk;                                       // lane of the pivot row (uniform)
-                const float qkk = bcast_lane_f(d[kk], lp);
-                const float sk = (qkk >= 0.f) ? -1.f : 1.f;                    // s_k = -sgn(q_kk), sgn(0) = +1
-                const float piv = qkk - sk;                                    // |piv| >= 1
-                const float rp = 1.0f / piv;
-                if (lane == lp) d[kk] = piv;
-                if (lane == 0) { sgn_s[k0 + kk] = sk; udiag[k0 + kk] = piv; }
-                const float l = d[kk] * rp;
-                if (lane > lp) d[kk] = l;
-#pragma unroll
-                for (int j = kk + 1; j < 16; j++) {
-                    const float ukj = bcast_lane_f(d[j], lp);
-                    if (lane > lp) d[j] = fmaf(-l, ukj, d[j]);
-                }
-            }
-#pragma unroll
-            for (int j = 0; j < 16; j++) Ss[row * TPS + k0 + j] = d[j];
-        }
-        __syncthreads();
-        if (wave == 1 && wa == 0) {
-            // the other 64 rows (all below the block): L[i][blk] U_dd = M[i][blk]
-            const int row = 64 + lane;
-            float x[16];
-#pragma unroll
-            for (int j = 0; j < 16; j++) x[j] = Ss[row * TPS + k0 + j];
-#pragma unroll
-            for (int kk = 0; kk < 16; kk++) {
-                const float l = x[kk] / udiag[k0 + kk];
-                x[kk] = l;
-#pragma unroll
-                for (int j = kk + 1; j < 16; j++) x[j] = fmaf(-l, Ss[(k0 + kk) * TPS + k0 + j], x[j]);
-            }
-#pragma unroll
-            for (int j = 0; j < 16; j++) Ss[row * TPS + k0 + j] = x[j];
-        } else if (wave >= 2 && wave < 4) {
-            // U row panel: columns right of the block, one thread per column: U[blk][j] = L_dd^-1 M[blk][j] (unit lower L_dd)
-            const int j = tid - 128;
-            if (j >= k0 + 16 && j < GW) {
-                float y[16];
-#pragma unroll
-                for (int i = 0; i < 16; i++) y[i] = Ss[(k0 + i) * TPS + j];
-#pragma unroll
-                for (int i = 1; i < 16; i++) {
-                    float sacc = y[i];
-#pragma unroll
-                    for (int p = 0; p < i; p++) sacc = fmaf(-Ss[(k0 + i) * TPS + k0 + p], y[p], sacc);
-                    y[i] = sacc;
-                }
-#pragma unroll
-                for (int i = 0; i < 16; i++) Ss[(k0 + i) * TPS + j] = y[i];
-            }
-        }
-        __syncthreads();
-        {   // trailing update M[i][j] -= L[i][blk] U[blk][j] for i, j > k0 + 15, 32 x 32 tiles on the exact-f32 MFMA (K = 16)
-            const int bi = wave >> 2, bj = wave & 3;
-            const int lim = k0 + 15;
-            const bool has = (32 * bi + 31 > lim) && (32 * bj + 31 > lim);
-            floatx16p acc;
-            if (has) acc = lds_mm32_k(&Ss[32 * bi * TPS + k0], TPS, &Ss[k0 * TPS + 32 * bj], TPS, 16, lane);
-            __syncthreads();                                                   // everybody has read the panels
-            if (has) {
-                const int r = lane & 31, kk = lane >> 5;
-                const int j = 32 * bj + r;
-#pragma unroll
-                for (int e = 0; e < 16; e++) {
-                    const int i = 32 * bi + (e & 3) + 8 * (e >> 2) + 4 * kk;
-                    if (i > lim && j > lim) Ss[i * TPS + j] -= acc[e];
-                }
-            }
-        }
-        __syncthreads();
-    }
-    KT();
-    // ---- 4. outputs
-    if (tid < GW) {
-        const float u = udiag[tid];
-        dv[tid] = (tid < 16 * nb16) ? ((u >= 0.f) ? sqrtf(0.5f * u) : -sqrtf(-0.5f * u)) : 1.f;
-        tdiag[tid] = (tid < 16 * nb16) ? 1.0f / u : 1.f;      // for U^-1 (|u| >= 1)
-    }
-    __syncthreads();
-    for (int e = tid; e < GW * GW; e += 1024) {                // k fastest: rows of A and Vh
-        const int i = e >> 7, k = e & 127;
-        if (i < w && k < w) {
-            float v;
-            if (i <= k) v = sgn_s[i] * W1[i * GW + k];                         // R = S Cc
-            else v = Ss[i * TPS + k] * dv[k];                                  // V_top = L diag(v_kk)
-            a.A[(long)(a.c0 + i) * a.lda + a.c0 + k] = v;
-            if (i >= k) a.Vh[(long)(a.c0 + i) * a.ldvh + a.c0 + k] = (half_t)((i == k) ? dv[k] : v);
-        }
-    }
-    for (int e = tid; e < GW * GW; e += 1024) {                // i fastest: rows of V^T
-        const int k = e >> 7, i = e & 127;
-        if (i < w && k < w && i >= k)
-            a.Vt[(long)(a.c0 + k) * a.ldvt + a.c0 + i] = (half_t)((i == k) ? dv[k] : Ss[i * TPS + k] * dv[k]);
-    }
-    if (tid < w) a.vdiag[a.c0 + tid] = dv[tid];
-    if (tid == 0 && lflag) atomicOr(flag, 1);
-    __syncthreads();
-    // U^-1: strictly upper part of U is in place in Ss (tri_inverse_128 never reads the lower triangle), Ts zeroed
-    for (int e = tid; e < TP * TPS; e += 1024) Ts[e] = 0.f;
-    __syncthreads();
-    KT();
-    tri_inverse_128(Ss, tdiag, Ts, nb32, tid);                // Ts = U^-1
-    KT();
-    for (int e = tid; e < GW * GW; e += 1024) Ss[(e >> 7) * TPS + (e & 127)] = W2[e];      // Cc^-1
-    __syncthreads();
-    {   // C = Cc^-1 U^-1 diag(v_kk), upper triangular, window coordinates, flagged reflectors zeroed
-        const int bi = wave >> 2, bj = wave & 3;
-        floatx16p acc;
-#pragma unroll
-        for (int e = 0; e < 16; e++) acc[e] = 0.f;
-        if (bi <= bj) acc = lds_mm32(&Ss[32 * bi * TPS], TPS, &Ts[32 * bj], TPS, 32 * bi, 32 * (bj + 1), lane);
-        const int r = lane & 31, kk = lane >> 5;
-        const int k = 32 * bj + r;
-#pragma unroll
-        for (int e = 0; e < 16; e++) {
-            const int i = 32 * bi + (e & 3) + 8 * (e >> 2) + 4 * kk;
-            const int wi = i + off, wk = k + off;
-            if (wi < GW && wk < GW) Cv[wi * GW + wk] = (i <= k && k < w && cmask[k]) ? acc[e] * dv[k] : 0.f;
-        }
-    }
-    // window entries left of / above the leaf (off > 0) are zero
-    if (off > 0)
-        for (int e = tid; e < GW * GW; e += 1024) { const int wi = e >> 7, wk = e & 127; if (wi < off || wk < off) Cv[e] = 0.f; }
-    KT(); KT_DUMP(2, "gh_solve2 load|chol|park|prep|inv1|qtop|lu|out|inv2|cm");
-}
-
 typedef half_t half8p __attribute__((ext_vector_type(8)));
 // partial Gram of the fp16 reflectors held in Ts ([128 columns][72]: the 64 rows of this workgroup, k contiguous):
 // upper 32 x 32 tiles of Ts Ts^T on v_mfma_f32_32x32x16_f16, written to Sp (fp32, 128 x 128, window coordinates)
@@ -980,10 +679,7 @@ __device__ __forceinline__ void gh_partial_gram(const half_t* Ts, float* __restr
 
 // blockIdx < nlow: rows c1 + 64 b .. of A_low (apply, and the partial Gram when Sp is given);  blockIdx >= nlow:
 // 64 rows of the TOP block (final already, written by gh_solve): partial Gram only.
-// Yg != nullptr (look-ahead): the tall rows (>= c1 + 128) of the NEXT leaf's columns [c1, c1+128) also receive this leaf's
-// update in fp32,  A[row, c1 + c] -= sum_k V[row][k] Yg[k][c]  (exact-f32 MFMA; Y comes from gh_glue).
-__global__ __launch_bounds__(256) void gh_apply_kernel(LeafArgs a, const float* __restrict__ Cv, float* __restrict__ Sp, int nlow,
-                                                       const float* __restrict__ Yg) {
+__global__ __launch_bounds__(256) void gh_apply_kernel(LeafArgs a, const float* __restrict__ Cv, float* __restrict__ Sp, int nlow) {
     float* As = (float*)gh_smem;                         // [64][129] = 8256 floats
     float* Cs = (float*)gh_smem + 8256;                  // [128][GH_TS], 16-B aligned
     half_t* Ts = (half_t*)gh_smem;                       // [128][72] halves, reuses the As region after the MFMAs
@@ -1052,46 +748,9 @@ __global__ __launch_bounds__(256) void gh_apply_kernel(LeafArgs a, const float* 
                 a.Vh[(long)row * a.ldvh + gc] = (half_t)v;
             }
             Ts[(n0 + r) * 72 + lm] = (half_t)v;
-            if (Yg) Cs[lm * 129 + n0 + r] = v;          // fp32 V tile [64][129] for the next leaf's update (Cs is dead)
         }
     }
     __syncthreads();
-    if (Yg && row0 >= a.c1 + GW) {
-        float* Ys = Cs + 8256;                           // [64][GH_TS]: half of Y's rows at a time
-        floatx16p u0, u1;
-#pragma unroll
-        for (int e = 0; e < 16; e++) { u0[e] = 0.f; u1[e] = 0.f; }
-        for (int hk = 0; hk < 2; hk++) {
-#pragma unroll
-            for (int q = 0; q < 8; q++) {
-                const int e4 = tid + 256 * q, k = e4 >> 5, c = (e4 & 31) * 4;
-                *(float4*)&Ys[k * GH_TS + c] = *(const float4*)&Yg[(64 * hk + k) * GW + c];
-            }
-            __syncthreads();
-            for (int k1 = 0; k1 < 64; k1 += 16) {
-                float a0[8], a1[8], b[8];
-#pragma unroll
-                for (int u = 0; u < 8; u++) {
-                    const int k = k1 + 2 * u + kk;
-                    a0[u] = Cs[r * 129 + 64 * hk + k]; a1[u] = Cs[(32 + r) * 129 + 64 * hk + k]; b[u] = Ys[k * GH_TS + n0 + r];
-                }
-#pragma unroll
-                for (int u = 0; u < 8; u++) {
-                    u0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[u], b[u], u0, 0, 0, 0);
-                    u1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[u], b[u], u1, 0, 0, 0);
-                }
-            }
-            __syncthreads();
-        }
-        const int gn = a.c1 + n0 + r;                     // column of the next leaf
-#pragma unroll
-        for (int mt = 0; mt < 2; mt++)
-#pragma unroll
-            for (int e = 0; e < 16; e++) {
-                const int row = row0 + mt * 32 + (e & 3) + 8 * (e >> 2) + 4 * kk;
-                if (row < a.mrows) a.A[(long)row * a.lda + gn] -= (mt == 0 ? u0[e] : u1[e]);
-            }
-    }
     KT();
     if (Sp) gh_partial_gram(Ts, Sp + (long)blockIdx.x * (GW * GW), lane, wave);
     KT();
@@ -1145,286 +804,6 @@ __global__ __launch_bounds__(256) void gh_reduce_f32_kernel(const float* __restr
     if (wave == 0) S[e] = (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
 }
 
-// ------------------------------------------------------------------ Gram-level look-ahead of the panel chain
-// The chain of a block is  gram -> solve -> apply -> (update of the next leaf's columns) -> gram -> ...: four passes over
-// the tall data between two solves.  With the quantities below the NEXT leaf's inputs (N = Gram matrix of its remaining
-// rows, B = its top block) follow from this leaf's small results and a Gram pass over data that does not contain this
-// leaf's update yet, so the chain shrinks to  solve -> glue -> solve -> ...  and every tall pass runs beside it:
-//   leaf j: columns J = [c0, c0+128), rows Rj = [c0, c0+128);  next leaf: columns J+1, rows R' = [c0+128, c0+256)
-//   Glx = A[>= c0+128, J]^T A[>= c0+128, J+1],  Gld = A[>= c0+128, J+1]^T A[>= c0+128, J+1]      (gh_pair_gram, fp64)
-//   E = A[Rj, J+1],  F = A[R', J],  D = A[R', J+1],  B = A[Rj, J] before the solve,  N = Gram of leaf j's rows
-//   S = Vtop^T Vtop + C^T (N - B^T B) C,   T = (striu(S) + diag(S)/2)^-1                       (exact reflectors)
-//   Z = Vtop^T E + C^T Glx  (= V^T A[:, J+1]),   Y = T^T Z
-//   R rows of the next columns   Rx = E - Vtop Y      -> A[Rj, J+1]
-//   next top block               B' = D - (F C) Y     -> A[R', J+1]
-//   next Gram matrix             N' = Gld + E^T E - Rx^T Rx     (the update is orthogonal: column norms over rows >= c0 stay)
-// gh_apply then gives the tall rows of the next leaf's columns exactly this update, A[>= c0+256, J+1] -= V_low Y, in fp32
-// (the prediction has to agree with the data to fp32 level), and the other columns of the block keep the fp16 path.
-
-// rows >= r0 of the 256 adjacent columns [cx, cx+256): partial Glx (64 tiles of 16 x 16) and Gld (36 upper tiles), fp64 MFMA.
-// Workgroup b takes `cpw` consecutive 64-row chunks; partial b = [Glx | Gld] (2 x 16384 doubles).
-constexpr int PG_ROWS = 64, PG_TD = 258;
-__global__ __launch_bounds__(512) void gh_pair_gram_kernel(const float* __restrict__ A, long lda, int mrows, int r0, int cx,
-                                                           int cpw, double* __restrict__ Gp2) {
-    double* tile = (double*)gh_smem;                       // [PG_ROWS][PG_TD]
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, lk = lane >> 4;
-    typedef double double4g __attribute__((ext_vector_type(4)));
-    int ca[13], cbv[13], oi[13], oj[13];                    // operand columns inside the 256-wide tile, output tile origin
-    double4g acc[13];
-#pragma unroll
-    for (int s = 0; s < 13; s++) {
-        int t = wave + 8 * s;
-        if (t < 64) { ca[s] = 16 * (t >> 3); cbv[s] = 128 + 16 * (t & 7); oi[s] = 16 * (t >> 3); oj[s] = 16 * (t & 7); }
-        else if (t < 100) {
-            int u = t - 64, ti = 0;
-            while (u >= 8 - ti) { u -= 8 - ti; ti++; }
-            ca[s] = 128 + 16 * ti; cbv[s] = 128 + 16 * (ti + u); oi[s] = 128 + 16 * ti; oj[s] = 16 * (ti + u);   // oi >= 128: Gld
-        } else { ca[s] = -1; cbv[s] = 0; oi[s] = 0; oj[s] = 0; }
-        acc[s] = double4g{0, 0, 0, 0};
-    }
-    for (int c = 0; c < cpw; c++) {
-        const int row0 = r0 + ((int)blockIdx.x * cpw + c) * PG_ROWS;
-        if (row0 >= mrows) break;
-#pragma unroll
-        for (int i = 0; i < 8; i++) {
-            const int id = tid + 512 * i, lr = id >> 6, c4 = id & 63, row = row0 + lr;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (row < mrows) v = *(const float4*)(A + (long)row * lda + cx + 4 * c4);
-            double* d = &tile[lr * PG_TD + 4 * c4];
-            *(double2*)d = make_double2((double)v.x, (double)v.y);
-            *(double2*)(d + 2) = make_double2((double)v.z, (double)v.w);
-        }
-        __syncthreads();
-        for (int k0 = 0; k0 < PG_ROWS; k0 += 4) {
-            const double* tr = &tile[(k0 + lk) * PG_TD + li];
-#pragma unroll
-            for (int s = 0; s < 13; s++)
-                if (ca[s] >= 0) acc[s] = __builtin_amdgcn_mfma_f64_16x16x4f64(tr[ca[s]], tr[cbv[s]], acc[s], 0, 0, 0);
-        }
-        __syncthreads();
-    }
-    double* out = Gp2 + (long)blockIdx.x * (2 * GW * GW);
-#pragma unroll
-    for (int s = 0; s < 13; s++)
-        if (ca[s] >= 0) {
-#pragma unroll
-            for (int v = 0; v < 4; v++) {
-                const int i = oi[s] + lk + 4 * v, j = oj[s] + li;        // i >= 128 addresses the second matrix
-                out[i * GW + j] = acc[s][v];
-            }
-        }
-}
-// [Glx | Gld] = sum of the partials (fixed order); Gld's lower tiles are mirrored
-__global__ __launch_bounds__(256) void gh_pair_reduce_kernel(const double* __restrict__ Gp2, int nwg, double* __restrict__ G2) {
-    __shared__ double part[4][64];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int e = blockIdx.x * 64 + lane;                   // 0 .. 32767
-    const int m2 = e >> 14, i = (e >> 7) & 127, j = e & 127;
-    const bool act = m2 == 0 || (i >> 4) <= (j >> 4);
-    double s = 0;
-    if (act) {
-        double s0 = 0, s1 = 0;
-        int q = wave;
-        for (; q + 4 < nwg; q += 8) { s0 += Gp2[(long)q * (2 * GW * GW) + e]; s1 += Gp2[(long)(q + 4) * (2 * GW * GW) + e]; }
-        for (; q < nwg; q += 4) s0 += Gp2[(long)q * (2 * GW * GW) + e];
-        s = s0 + s1;
-    }
-    part[wave][lane] = s;
-    __syncthreads();
-    if (wave == 0 && act) {
-        const double g = (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
-        G2[e] = g;
-        if (m2 == 1 && (i >> 4) != (j >> 4)) G2[GW * GW + j * GW + i] = g;
-    }
-}
-void launch_gh_pair_gram(const float* A, long lda, int mrows, int r0, int cx, double* Gp2, int max_wg, double* G2, hipStream_t s) {
-    static bool attr = false;
-    if (!attr) {
-        (void)hipFuncSetAttribute((const void*)gh_pair_gram_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, PG_ROWS * PG_TD * 8);
-        attr = true;
-    }
-    const int nchunk = std::max(0, (mrows - r0 + PG_ROWS - 1) / PG_ROWS);
-    int nwg = std::min(std::max(nchunk, 1), std::min(max_wg, 64));
-    const int cpw = std::max(1, (nchunk + nwg - 1) / nwg);
-    nwg = std::max(1, (nchunk + cpw - 1) / cpw);
-    hipLaunchKernelGGL(gh_pair_gram_kernel, dim3(nwg), dim3(512), PG_ROWS * PG_TD * 8, s, A, lda, mrows, r0, cx, cpw, Gp2);
-    hipLaunchKernelGGL(gh_pair_reduce_kernel, dim3(512), dim3(256), 0, s, Gp2, nwg, G2);
-}
-
-// 32 x 32 tile product accumulated into acc; A read as A[r][k] or (TA) transposed A[k][r]; optionally negated (exact)
-template <bool TA>
-__device__ __forceinline__ void lds_mm32x(floatx16p& acc, const float* A, int lda, const float* B, int ldb, int klo, int khi,
-                                          int lane, bool neg = false) {
-    const int r = lane & 31, kk = lane >> 5;
-    for (int k1 = klo; k1 < khi; k1 += 16) {
-        float av[8], bv[8];
-#pragma unroll
-        for (int u = 0; u < 8; u++) {
-            const int k = k1 + 2 * u + kk;
-            av[u] = TA ? A[k * lda + r] : A[r * lda + k];
-            bv[u] = B[k * ldb + r];
-        }
-        if (neg) {
-#pragma unroll
-            for (int u = 0; u < 8; u++) av[u] = -av[u];
-        }
-#pragma unroll
-        for (int u = 0; u < 8; u++) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u], bv[u], acc, 0, 0, 0);
-    }
-}
-
-__global__ __launch_bounds__(1024) void gh_glue_kernel(GlueArgs g) {
-    float* P = (float*)gh_smem;                            // two 128 x 129 operand slots
-    float* Q = P + TP * TPS;
-    __shared__ float tdiag[GW];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int bi = wave >> 2, bj = wave & 3, r = lane & 31, kk = lane >> 5;
-    const long lda = g.lda;
-    const int c0 = g.c0, c1 = g.c0 + GW;
-    float* const Eg = g.A + (long)c0 * lda + c1;           // rows Rj, columns J+1 (becomes Rx)
-    const float* const Fg = g.A + (long)c1 * lda + c0;     // rows R', columns J
-    float* const Dg = g.A + (long)c1 * lda + c1;           // rows R', columns J+1 (becomes B')
-    auto ldmat = [&](float* slot, const float* src, long ld) {
-#pragma unroll
-        for (int q = 0; q < 4; q++) {
-            const int e4 = tid + 1024 * q, i = e4 >> 5, j = (e4 & 31) * 4;
-            const float4 v = *(const float4*)&src[(long)i * ld + j];
-            float* d = &slot[i * TPS + j];
-            d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
-        }
-    };
-    auto ldvtop = [&](float* slot) {                       // reflector values of the top block: v below, vdiag on, 0 above the diagonal
-#pragma unroll
-        for (int q = 0; q < 4; q++) {
-            const int e4 = tid + 1024 * q, i = e4 >> 5, j = (e4 & 31) * 4;
-            const float4 v = *(const float4*)&g.A[(long)(c0 + i) * lda + c0 + j];
-            const float vd = g.vdiag[c0 + i];
-            float* d = &slot[i * TPS + j];
-            d[0] = i > j ? v.x : (i == j ? vd : 0.f);
-            d[1] = i > j + 1 ? v.y : (i == j + 1 ? vd : 0.f);
-            d[2] = i > j + 2 ? v.z : (i == j + 2 ? vd : 0.f);
-            d[3] = i > j + 3 ? v.w : (i == j + 3 ? vd : 0.f);
-        }
-    };
-    auto zero16 = [](floatx16p& a) {
-#pragma unroll
-        for (int e = 0; e < 16; e++) a[e] = 0.f;
-    };
-#define GLUE_ROW(e) (32 * bi + ((e) & 3) + 8 * ((e) >> 2) + 4 * kk)
-    const int col = 32 * bj + r;
-    floatx16p acc, accS, accZ, accFC, accN;
-    // ---- Glow = N - B^T B
-    ldmat(P, g.Bs, GW);
-    __syncthreads();
-    zero16(acc);
-    lds_mm32x<true>(acc, P + 32 * bi, TPS, P + 32 * bj, TPS, 0, GW, lane);
-#pragma unroll
-    for (int e = 0; e < 16; e++) { const int i = GLUE_ROW(e); Q[i * TPS + col] = (float)(g.N[i * GW + col] - (double)acc[e]); }
-    __syncthreads();
-    // ---- S = C^T (Glow C) + Vtop^T Vtop
-    ldmat(P, g.Cv, GW);
-    __syncthreads();
-    zero16(acc);
-    lds_mm32x<false>(acc, Q + 32 * bi * TPS, TPS, P + 32 * bj, TPS, 0, GW, lane);
-    __syncthreads();
-    lds_store32(&Q[32 * bi * TPS + 32 * bj], TPS, acc, 1.f, lane);
-    __syncthreads();
-    zero16(accS);
-    lds_mm32x<true>(accS, P + 32 * bi, TPS, Q + 32 * bj, TPS, 0, GW, lane);
-    __syncthreads();
-    ldvtop(Q);
-    ldmat(P, Eg, lda);
-    __syncthreads();
-    lds_mm32x<true>(accS, Q + 32 * bi, TPS, Q + 32 * bj, TPS, 0, GW, lane);
-    // ---- Z = Vtop^T E + C^T Glx ;  E^T E
-    zero16(accZ); zero16(accN);
-    lds_mm32x<true>(accZ, Q + 32 * bi, TPS, P + 32 * bj, TPS, 0, GW, lane);
-    lds_mm32x<true>(accN, P + 32 * bi, TPS, P + 32 * bj, TPS, 0, GW, lane);
-    __syncthreads();
-    ldmat(P, g.Cv, GW);
-#pragma unroll
-    for (int q = 0; q < 16; q++) { const int e1 = tid + 1024 * q; Q[(e1 >> 7) * TPS + (e1 & 127)] = (float)g.Glx[e1]; }
-    __syncthreads();
-    lds_mm32x<true>(accZ, P + 32 * bi, TPS, Q + 32 * bj, TPS, 0, GW, lane);
-    __syncthreads();
-    // ---- F C
-    ldmat(Q, Fg, lda);
-    __syncthreads();
-    zero16(accFC);
-    lds_mm32x<false>(accFC, Q + 32 * bi * TPS, TPS, P + 32 * bj, TPS, 0, GW, lane);
-    __syncthreads();
-    // ---- T = (striu(S) + diag(S)/2)^-1
-#pragma unroll
-    for (int e = 0; e < 16; e++) {
-        const int i = GLUE_ROW(e);
-        P[i * TPS + col] = (col > i) ? accS[e] : 0.f;
-        if (i == col) tdiag[i] = 2.0f / accS[e];
-    }
-    for (int e1 = tid; e1 < TP * TPS; e1 += 1024) Q[e1] = 0.f;
-    __syncthreads();
-    tri_inverse_128(P, tdiag, Q, 4, tid);                  // Q = T
-    // ---- Y = T^T Z
-    lds_store32(&P[32 * bi * TPS + 32 * bj], TPS, accZ, 1.f, lane);
-    __syncthreads();
-    zero16(acc);
-    lds_mm32x<true>(acc, Q + 32 * bi, TPS, P + 32 * bj, TPS, 0, GW, lane);
-    __syncthreads();
-    lds_store32(&P[32 * bi * TPS + 32 * bj], TPS, acc, 1.f, lane);       // P = Y
-#pragma unroll
-    for (int e = 0; e < 16; e++) g.Yg[GLUE_ROW(e) * GW + col] = acc[e];
-    ldvtop(Q);
-    __syncthreads();
-    // ---- Rx = E - Vtop Y
-    zero16(acc);
-    lds_mm32x<false>(acc, Q + 32 * bi * TPS, TPS, P + 32 * bj, TPS, 0, GW, lane);
-#pragma unroll
-    for (int e = 0; e < 16; e++) {
-        const long o = (long)GLUE_ROW(e) * lda + col;
-        const float v = Eg[o] - acc[e];
-        Eg[o] = v; acc[e] = v;
-    }
-    __syncthreads();
-    // ---- B' = D - (F C) Y
-    lds_store32(&Q[32 * bi * TPS + 32 * bj], TPS, accFC, 1.f, lane);
-    __syncthreads();
-    zero16(accFC);
-    lds_mm32x<false>(accFC, Q + 32 * bi * TPS, TPS, P + 32 * bj, TPS, 0, GW, lane);
-#pragma unroll
-    for (int e = 0; e < 16; e++) {
-        const int i = GLUE_ROW(e);
-        const float v = Dg[(long)i * lda + col] - accFC[e];
-        Dg[(long)i * lda + col] = v;
-        g.Bn[i * GW + col] = v;
-    }
-    __syncthreads();
-    // ---- N' = Gld + E^T E - Rx^T Rx
-    lds_store32(&Q[32 * bi * TPS + 32 * bj], TPS, acc, 1.f, lane);       // Q = Rx
-    __syncthreads();
-    lds_mm32x<true>(accN, Q + 32 * bi, TPS, Q + 32 * bj, TPS, 0, GW, lane, true);
-#pragma unroll
-    for (int e = 0; e < 16; e++) { const int i = GLUE_ROW(e); g.Nn[i * GW + col] = g.Gld[i * GW + col] + (double)accN[e]; }
-#undef GLUE_ROW
-}
-void launch_gh_glue(const GlueArgs& g, hipStream_t s) {
-    static bool attr = false;
-    if (!attr) {
-        (void)hipFuncSetAttribute((const void*)gh_glue_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * TP * TPS * 4);
-        attr = true;
-    }
-    hipLaunchKernelGGL(gh_glue_kernel, dim3(1), dim3(1024), 2 * TP * TPS * 4, s, g);
-}
-// the top block of a leaf before its solve (the glue of the look-ahead needs it)
-__global__ __launch_bounds__(256) void gh_save_top_kernel(const float* __restrict__ A, long lda, int c0, float* __restrict__ Bs) {
-    for (int e4 = threadIdx.x + 256 * blockIdx.x; e4 < GW * GW / 4; e4 += 256 * gridDim.x) {
-        const int i = e4 >> 5, j = (e4 & 31) * 4;
-        *(float4*)&Bs[i * GW + j] = *(const float4*)&A[(long)(c0 + i) * lda + c0 + j];
-    }
-}
-void launch_gh_save_top(const float* A, long lda, int c0, float* Bs, hipStream_t s) {
-    hipLaunchKernelGGL(gh_save_top_kernel, dim3(16), dim3(256), 0, s, A, lda, c0, Bs);
-}
-
 int gh_num_partials(const LeafArgs& a) {
     return (a.mrows - a.c1 + 63) / 64 + (a.c1 - a.c0 + 63) / 64;
 }
@@ -1436,7 +815,6 @@ static void gh_set_attrs() {
     if (attr) return;
     (void)hipFuncSetAttribute((const void*)gh_gram_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, GH_ROWS * GH_TD * 8);
     (void)hipFuncSetAttribute((const void*)gh_solve_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * TP * TPS * 4);
-    (void)hipFuncSetAttribute((const void*)gh_solve2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, GW * GD * 8);
     (void)hipFuncSetAttribute((const void*)gh_apply_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (8256 + GW * GH_TS) * 4);
     attr = true;
 }
@@ -1451,29 +829,20 @@ void launch_gh_solve(const LeafArgs& a, const double* G, float* Cv, int* flag, h
     gh_set_attrs();
     static const int dbg_skip = []() { const char* e = getenv("MPQR_DBG_NOSOLVE"); return e ? atoi(e) : 0; }();
     if (dbg_skip) return;                                  // timing experiment only (results are garbage): is the chain host-bound?
-    // gh_solve2 (blocked Householder reconstruction) is correct but measured SLOWER than the step-by-step kernel at w = 128
-    // (162 vs 111 us: ~500 cycles per column for the fp64 in-wave Cholesky, ~300 for the LU, plus two triangular inverses
-    // -- in-kernel stamps, make EXTRA=-DMPQR_KTRACE): opt-in only
-    // gh_solve3 (kernels_solve.hip): the same recursion blocked by 16, chains in single waves (bit-identical outputs on the
-    // harness tools/test_solve3.hip); MPQR_SOLVE3=0 selects the step-by-step kernel below
-    static const int solve3 = []() { const char* e = getenv("MPQR_SOLVE3"); return e ? atoi(e) : 1; }();
-    if (solve3) { launch_gh_solve3(a, G, Cv, flag, s); return; }
-    static const int solve2 = []() { const char* e = getenv("MPQR_SOLVE2"); return e ? atoi(e) : 0; }();
-    if (solve2 && a.Wk) hipLaunchKernelGGL(gh_solve2_kernel, dim3(1), dim3(1024), GW * GD * 8, s, a, G, Cv, flag, a.Wk);
-    else hipLaunchKernelGGL(gh_solve_kernel, dim3(1), dim3(GH_SOLVE_THREADS), 2 * TP * TPS * 4, s, a, G, Cv, flag);
+    hipLaunchKernelGGL(gh_solve_kernel, dim3(1), dim3(GH_SOLVE_THREADS), 2 * TP * TPS * 4, s, a, G, Cv, flag);
 }
-void launch_gh_apply(const LeafArgs& a, const float* Cv, float* Sp, const float* Yg, hipStream_t s) {
+void launch_gh_apply(const LeafArgs& a, const float* Cv, float* Sp, hipStream_t s) {
     gh_set_attrs();
     const int nlow = (a.mrows - a.c1 + 63) / 64;
     const int ntop = Sp ? (a.c1 - a.c0 + 63) / 64 : 0;      // extra workgroups: Gram contribution of the top block
     if (nlow + ntop == 0) return;
-    hipLaunchKernelGGL(gh_apply_kernel, dim3(nlow + ntop), dim3(256), (8256 + GW * GH_TS) * 4, s, a, Cv, Sp, nlow, Yg);
+    hipLaunchKernelGGL(gh_apply_kernel, dim3(nlow + ntop), dim3(256), (8256 + GW * GH_TS) * 4, s, a, Cv, Sp, nlow);
 }
 void launch_leaf_gram_householder(const LeafArgs& a, double* Gp, double* G, float* Cv, int* flag, float* Sp, float* S,
                                   hipStream_t s) {
     launch_gh_gram(a, Gp, G, s);
     launch_gh_solve(a, G, Cv, flag, s);
-    launch_gh_apply(a, Cv, Sp, nullptr, s);
+    launch_gh_apply(a, Cv, Sp, s);
     if (Sp && S) launch_gh_reduce_f32(Sp, gh_num_partials(a), S, s);
 }
 

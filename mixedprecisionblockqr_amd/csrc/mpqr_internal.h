@@ -54,11 +54,10 @@ struct GemmArgs {
     const half_t* A2;    // ping-pong kernel: a second A operand (the lo parts) accumulated over the same Bt: C = (A + A2) Bt^T
     int eye_minus;       // E_STORE_F32 (256-wide kernel): store (m == n ? 1 : 0) - alpha*acc  (Q = I - W V^T in one product)
 };
-void launch_gemm_f16(AMode am, EMode em, const GemmArgs& g, hipStream_t s);
+// false: no 128-tile kernel for this (staging, epilogue) pair, or hi + lo operands requested (256-wide kernels only)
+bool launch_gemm_f16(AMode am, EMode em, const GemmArgs& g, hipStream_t s);
 // 256 x 256 x 64 variant for large shapes (no split-K; operands readable up to the next multiple of 256 rows)
 bool launch_gemm2_f16(AMode am, EMode em, const GemmArgs& g, hipStream_t s, int config = 0);
-// number of CUs a stream may use (CU-masked streams): persistent GEMM grids are sized to it
-void gemm_register_stream_cus(hipStream_t s, int cus);
 
 // ------------------------------------------------------------------ fp8 (e4m3) operand path (kernels_fp8.hip)
 // C (-)= alpha A[M][K] Bt[N][K]^T with 1-byte e4m3 operands (g.A / g.Bt point at bytes, lda / ldb in bytes), K % 128 == 0;
@@ -93,7 +92,6 @@ struct LeafArgs {
     float* vdiag;               // diagonal element of each reflector
     float* P;                   // partial dot products, 2 x maxwg x 32
     int maxwg;
-    float* Wk;                  // gh_solve2 scratch, 2 x 16384 floats (nullptr: the step-by-step gh_solve is used)
 };
 void launch_leaf_factor(const LeafArgs& a, hipStream_t s);   // robust path: one workgroup (<=2048 rows) or one launch per column
 // tall leaves (up to 128 columns inside a 128-aligned window, a.cb): Gram-Householder, 4 launches; raises *flag
@@ -104,30 +102,12 @@ void launch_leaf_factor(const LeafArgs& a, hipStream_t s);   // robust path: one
 void launch_leaf_gram_householder(const LeafArgs& a, double* Gp /* nwg x 16384 */, double* G /* 16384 */,
                                   float* Cv /* 16384 */, int* flag, float* Sp, float* S, hipStream_t s);
 int gh_num_partials(const LeafArgs& a);
-// the same leaf in separately launchable steps (Gram-level look-ahead, kernels_panel.hip)
+// the same leaf in separately launchable steps
 void launch_gh_gram(const LeafArgs& a, double* Gp, double* G, hipStream_t s);
 void launch_gh_solve(const LeafArgs& a, const double* G, float* Cv, int* flag, hipStream_t s);
-void launch_gh_apply(const LeafArgs& a, const float* Cv, float* Sp, const float* Yg /* or nullptr */, hipStream_t s);
+void launch_gh_apply(const LeafArgs& a, const float* Cv, float* Sp, hipStream_t s);
 // blocked form of gh_solve (kernels_solve.hip): same inputs and outputs
 void launch_gh_solve3(const LeafArgs& a, const double* G, float* Cv, int* flag, hipStream_t s);
-// look-ahead inputs: rows >= r0 of the 256 columns [cx, cx+256): G2 = [A_x^T A_d | A_d^T A_d] (2 x 16384 doubles);
-// Gp2: max_wg x 32768 doubles of partials
-void launch_gh_pair_gram(const float* A, long lda, int mrows, int r0, int cx, double* Gp2, int max_wg, double* G2, hipStream_t s);
-struct GlueArgs {
-    float* A; long lda;
-    int c0;                     // leaf j = columns [c0, c0+128) (full, 128-aligned); next leaf = [c0+128, c0+256)
-    const float* vdiag;
-    const float* Cv;            // C_j from gh_solve
-    const double* N;            // Gram matrix leaf j was solved from
-    const double* Glx;          // pair Gram of the rows >= c0+128: cross and (Gld) next-diagonal part
-    const double* Gld;
-    const float* Bs;            // leaf j's top block before the solve
-    float* Bn;                  // out: the next leaf's top block (also written into A)
-    double* Nn;                 // out: the next leaf's Gram matrix
-    float* Yg;                  // out: Y_j (reflector x column), for gh_apply's exact update of the next leaf's columns
-};
-void launch_gh_glue(const GlueArgs& g, hipStream_t s);
-void launch_gh_save_top(const float* A, long lda, int c0, float* Bs, hipStream_t s);
 // Y[M1 x 128] (fp16, ld ldy) = fp16(sum of nslab X slabs, M1 x 128 fp32) * T', Bt[n][k] = T'[k][n] (fp16, ld ldb), tri as GemmArgs::tri
 void launch_leaf_xt(const float* X, int nslab, long slab_stride, int M1, const half_t* Bt, long ldb, int tri, half_t* Y, long ldy,
                     const float* cscale, long cscale_ld, hipStream_t s);

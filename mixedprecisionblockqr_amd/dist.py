@@ -70,6 +70,10 @@ class GpuEngine:
         o = _opts(**opt_kw)
         self._chk(L.lib().mpqr_dist_plan(self._h, m, n, r, world, rank, C.byref(o)))
         self._bufs = {}
+        self._payload = [None, None]          # two payload buffers of the largest block's size, reused by every factor() call
+        sp = C.c_void_p()
+        self._chk(L.lib().mpqr_dist_chain_stream(self._h, C.byref(sp)))
+        self._chain = torch.cuda.ExternalStream(sp.value, device=self.device)    # the library's chain stream, as torch sees it
 
     def _chk(self, rc):
         if rc != L.OK:
@@ -109,14 +113,25 @@ class GpuEngine:
             self._bufs[nbytes] = self.torch.empty(nbytes, dtype=self.torch.uint8, device=self.device)
         return self._bufs[nbytes]
 
-    def new_buffer(self, nbytes):
-        return self.torch.empty(nbytes, dtype=self.torch.uint8, device=self.device)
+    def payload(self, slot, nbytes):
+        """View of payload buffer `slot` (0 / 1): block sizes shrink with s, the two buffers are sized once for the largest."""
+        if self._payload[slot] is None:
+            cap = max(self.block_bytes(s) for s in range(self.num_blocks()))
+            self._payload[slot] = self.torch.empty(cap, dtype=self.torch.uint8, device=self.device)
+        return self._payload[slot][:nbytes]
 
-    def pack(self, s, buf): self._chk(L.lib().mpqr_dist_pack_block(self._h, s, C.c_void_p(buf.data_ptr())))
+    # pack / unpack are enqueued on the library's chain stream; torch's current stream (on which torch.distributed orders the
+    # broadcast) is ordered against it with events, the host never waits for a broadcast
+    def pack(self, s, buf):
+        self._chk(L.lib().mpqr_dist_pack_block_async(self._h, s, C.c_void_p(buf.data_ptr())))
+        self.torch.cuda.current_stream(self.device).wait_stream(self._chain)
+
+    def before_broadcast(self):
+        self.torch.cuda.current_stream(self.device).wait_stream(self._chain)      # the buffer's previous contents have been unpacked
 
     def unpack(self, s, buf):
-        self.torch.cuda.current_stream(self.device).synchronize()       # the broadcast has landed
-        self._chk(L.lib().mpqr_dist_unpack_block(self._h, s, C.c_void_p(buf.data_ptr())))
+        self._chain.wait_stream(self.torch.cuda.current_stream(self.device))      # the broadcast has landed
+        self._chk(L.lib().mpqr_dist_unpack_block_async(self._h, s, C.c_void_p(buf.data_ptr())))
 
     def update(self, s): self._chk(L.lib().mpqr_dist_update(self._h, s))
     def update_part(self, s, part): self._chk(L.lib().mpqr_dist_update_part(self._h, s, part))
@@ -152,11 +167,13 @@ def factor(engine, comm, form_q=True, lookahead=True):
     multi = comm.world > 1
     bufs = {}
 
-    def buffer(s):
+    def buffer(s):                                # double-buffered payloads: two buffers, reused (engines without `payload`: tests)
         nbytes = engine.block_bytes(s)
+        if hasattr(engine, "payload"):
+            return engine.payload(s % 2, nbytes)
         key = (s % 2, nbytes)
         if key not in bufs:
-            bufs[key] = engine.new_buffer(nbytes) if hasattr(engine, "new_buffer") else engine.buffer(nbytes)
+            bufs[key] = engine.buffer(nbytes)
         return bufs[key]
 
     if comm.rank == engine.owner(0):
@@ -167,6 +184,8 @@ def factor(engine, comm, form_q=True, lookahead=True):
         owner = engine.owner(s)
         if multi:
             buf = buffer(s)
+            if hasattr(engine, "before_broadcast"):
+                engine.before_broadcast()
             comm.broadcast(buf, owner)
             engine.unpack(s, buf)
         if not lookahead:
@@ -250,7 +269,9 @@ def bench_main(args, m, n, r, world, rank, local_rank, cpu_baseline_fn=None):
     ko = args.outer_block
     if not ko and world > 1:
         ko = max(r, min(1024, (n // (2 * world)) // r * r))
-    eng = GpuEngine(local_rank, m, n, r, world, rank, outer_block=ko, lookahead=not args.no_lookahead)
+    prec_name = getattr(args, "precision", None) or ("fp8" if getattr(args, "config", "") == "c5" else "fp16")
+    precision = {"fp16": L.PREC_FP16, "fp8": L.PREC_FP8, "fp32": L.PREC_FP32}[prec_name]
+    eng = GpuEngine(local_rank, m, n, r, world, rank, outer_block=ko, lookahead=not args.no_lookahead, precision=precision)
     eng.generate(1234)
     eng.sync()
 
@@ -281,14 +302,19 @@ def bench_main(args, m, n, r, world, rank, local_rank, cpu_baseline_fn=None):
         roof = None
         if tm["n_far_launches"] > 0 and tm["ms_far_nn"] > 0:
             ach = tm["flops_far_nn"] / (tm["ms_far_nn"] * 1e-3) / 1e12
-            roof = {"bound": "mfma", "kernel": "gemm6_f16_kernel<E_SUB_F32> (far A2 -= V*Y^T on rank 0's column shard, fp16 x fp16 -> fp32, K = outer block)",
-                    "achieved": ach, "peak": 2500.0, "unit": "TFLOP/s", "frac": ach / 2500.0, "traffic": None,
+            peak = 5000.0 if prec_name == "fp8" else 2500.0
+            kname = ("gemm8_fp8_kernel<E_SUB_F32> (far A2 -= V*Y^T on rank 0's column shard, e4m3 x e4m3 -> fp32, K = outer block)" if prec_name == "fp8" else
+                     "gemm6_f16_kernel<E_SUB_F32> (far A2 -= V*Y^T on rank 0's column shard, fp16 x fp16 -> fp32, K = outer block)")
+            roof = {"bound": "mfma", "kernel": kname,
+                    "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "traffic": None,
                     "launches": tm["n_far_launches"], "avg_launch_ms": tm["ms_far_nn"] / tm["n_far_launches"],
                     "tn_achieved": (tm["flops_far_tn"] / (tm["ms_far_tn"] * 1e-3) / 1e12) if tm["ms_far_tn"] > 0 else None}
         out = {
-            "metric": "GFLOP/s block QR (fp16 MFMA trailing)", "value": fl["geqrf"] / dt / 1e9, "unit": "GFLOP/s",
+            "metric": "GFLOP/s block QR (%s MFMA trailing)" % prec_name, "value": fl["geqrf"] / dt / 1e9, "unit": "GFLOP/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt * 1e3,
-            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f16xf16->f32 (fp32 panel)",
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": {"fp16": "f16xf16->f32 (fp32 panel)", "fp32": "f32 (exact-f32 MFMA)",
+                      "fp8": "e4m3xe4m3->f32 far trailing update (fp32 panel; fp16 in-block updates and Q formation)"}[prec_name],
             "data": "synthetic U[0,1) fp32, seed 1234",
             "config": {"workload": f"{m}x{n} random dense, block={r}, full Q formed", "m": m, "n": n, "block": r,
                        "outer_block": eng.block(),

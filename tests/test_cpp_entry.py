@@ -91,12 +91,39 @@ def test_cpp_multi_gpu_host_driver_on_one_gpu(tmp_path):
     """apps/mpqr_main --gpus N: the C++ host of the distributed schedule (threads + mpqr_dist_* + ncclBroadcast).  The test box
     has one GPU: N = 1, once without communication and once with the RCCL broadcast leg forced on (1-rank communicator)."""
     _build()
-    for env_extra in ({}, {"MPQR_MG_FORCE_BCAST": "1"}):
+    for env_extra, dtype in (({}, "fp16"), ({"MPQR_MG_FORCE_BCAST": "1"}, "fp16"), ({"MPQR_MG_FORCE_BCAST": "1"}, "fp8")):
         env = dict(os.environ, **env_extra)
-        p = subprocess.run([EXE, "--gpus", "1", "--m", "4096", "--n", "3072", "--r", "128", "--steps", "2"], cwd=tmp_path, env=env,
+        p = subprocess.run([EXE, "--gpus", "1", "--m", "4096", "--n", "3072", "--r", "128", "--steps", "2", "--dtype", dtype], cwd=tmp_path, env=env,
                            capture_output=True, text=True, timeout=900)
         assert p.returncode == 0, (p.stdout, p.stderr)
-        mt = re.search(r"multi-GPU block QR: 1 GPU\(s\), 4096 x 3072, r = 128, outer block (\d+): ([0-9.]+) ms per factorisation incl. Q, ([0-9.]+) GFLOP/s", p.stdout)
+        mt = re.search(r"multi-GPU block QR: 1 GPU\(s\), 4096 x 3072, r = 128, outer block (\d+), (\w+): ([0-9.]+) ms per factorisation incl. Q, ([0-9.]+) GFLOP/s", p.stdout)
         assert mt, p.stdout
-        assert float(mt.group(2)) > 0 and float(mt.group(3)) > 100.0
+        assert mt.group(2) == dtype and float(mt.group(3)) > 0 and float(mt.group(4)) > 100.0
 
+
+
+@pytest.mark.gpu
+def test_cpp_entry_point_jacobian_run_list(tmp_path):
+    """The Jacobian leg of the reference's run list (Cuda/qr.cu:1794-1804 test_qr over get_jacobians_test_matrixs, qr.cu:1721-1759):
+    files A_%09d.txt for i = 100, 200, ..., sorted by row count, every second one, at most 30, r = 16, each through the three
+    algorithms.  The real data is an absent git-LFS blob: five synthetic bundle-adjustment Jacobians in the same text format."""
+    import mixedprecisionblockqr_amd as mp
+    _build()
+    d = tmp_path / "jacobians"; d.mkdir()
+    shapes = {}
+    for idx, (cams, pts) in zip((300, 100, 500, 200, 400), ((12, 120), (8, 70), (16, 150), (10, 90), (14, 130))):
+        J = mp.synthetic_jacobian(cams=cams, points=pts, seed=idx)
+        mp.write_euroc_jacobian(str(d / ("A_%09d.txt" % idx)), J)
+        shapes[idx] = J.shape
+    order = sorted(shapes.values(), key=lambda s: s[0])
+    picked = order[::2]                                          # every second file of the row-sorted list
+    assert len(picked) == 3 and all(m >= n for m, n in picked)
+    p = subprocess.run([EXE, "--jacobians", str(d), "--skip-random"], cwd=tmp_path, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr
+    cases = _parse(p.stdout)
+    assert [c[1] for c in cases] == [(m, n, 16) for m, n in picked] * 3, [c[1] for c in cases]
+    for title, shape, crit in cases:
+        assert len(crit) == 3 and all(ok for _, ok in crit.values()), (title, shape, crit)
+    assert sum("householder" in t for t, _, _ in cases) == 3 and sum("mixed" in t for t, _, _ in cases) == 3
+    assert len((tmp_path / "log" / "cpu_householder.txt").read_text().strip().splitlines()) == 4      # header + 3 rows
+    assert len((tmp_path / "log" / "gpu_block.txt").read_text().strip().splitlines()) == 7            # header + 3 fp32 + 3 mixed

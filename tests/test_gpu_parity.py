@@ -593,13 +593,9 @@ def _run_lockstep(mp, engines, lookahead=True):
     for e in engines: e.begin(amax)
     nb = engines[0].num_blocks()
     multi = len(engines) > 1
-    bufs = [[e.new_buffer(e.block_bytes(0)) for _ in range(2)] for e in engines]
 
-    def buf(rk, s):
-        need = engines[rk].block_bytes(s)
-        if bufs[rk][s % 2].numel() != need:
-            bufs[rk][s % 2] = engines[rk].new_buffer(need)
-        return bufs[rk][s % 2]
+    def buf(rk, s):                                  # the engines' own double-buffered payloads (two buffers per rank, reused)
+        return engines[rk].payload(s % 2, engines[rk].block_bytes(s))
 
     o0 = engines[0].owner(0)
     engines[o0].factor_block(0)
@@ -607,9 +603,9 @@ def _run_lockstep(mp, engines, lookahead=True):
     for s in range(nb):
         owner = engines[0].owner(s)
         if multi:
-            for rk, e in enumerate(engines):
+            for rk, e in enumerate(engines):             # "broadcast" on torch's current stream, ordered by events like the real one:
+                e.before_broadcast()                     # pack() / unpack() never synchronise the host
                 if rk != owner: buf(rk, s).copy_(buf(owner, s))
-            torch.cuda.synchronize()
             for rk, e in enumerate(engines): e.unpack(s, buf(rk, s))
         nxt = engines[0].owner(s + 1) if s + 1 < nb else -1
         for rk, e in enumerate(engines):
@@ -660,10 +656,8 @@ def test_distributed_schedule_on_one_gpu(mp, po, m, n, r, ko, world, la):
 # produce the same factorisation.  The switches are read once per process, hence one child interpreter per setting.
 OPT_IN = [
     {},                                            # the default path, the others are compared with it
-    {"MPQR_LA": "1"},                              # Gram-level look-ahead of the panel chain (glue kernel, fp32 next-leaf update)
-    {"MPQR_SOLVE2": "1"},                          # blocked Householder-reconstruction form of the leaf solve
-    {"MPQR_GEMM7": "1"},                           # persistent-workgroup variant of the dominant GEMM
-    {"MPQR_GEMM6": "0"},                           # 4-stage ring GEMM of round 1
+    {"MPQR_SOLVE3": "0"},                          # step-by-step leaf solve of round 2 (one barrier per reflector)
+    {"MPQR_GEMM6": "0"},                           # register-staged 256-tile kernel instead of the LDS-DMA ping-pong one
     {"MPQR_FLAT": "0"},                            # tree schedule inside a block
     {"MPQR_TSTREAM": "0"},                         # compact-WY T on the chain stream
     {"MPQR_EXT_LOOKAHEAD": "0"},                   # block boundary: first leaf of the next block through the far update
@@ -703,13 +697,15 @@ def test_tall_matrix_one_shot_q_formation():
 def test_opt_in_schedules_and_kernels():
     import json, os, subprocess, sys
     child = os.path.join(os.path.dirname(os.path.abspath(__file__)), "optin_child.py")
-    m, n, r = 3072, 2304, 128                      # three 1024-column blocks (the last one partial): look-ahead across boundaries
-    ref = None
+    m, n, r, ob = 3072, 2304, 128, 512             # five 512-column blocks (the last one partial): look-ahead across boundaries AND the
+    ref = None                                     # deferred pairwise far updates, which need at least four blocks
+    far = {}
     for extra in OPT_IN:
         env = dict(os.environ); env.update(extra)
-        p = subprocess.run([sys.executable, child, str(m), str(n), str(r)], env=env, capture_output=True, text=True, timeout=600)
+        p = subprocess.run([sys.executable, child, str(m), str(n), str(r), str(ob)], env=env, capture_output=True, text=True, timeout=600)
         assert p.returncode == 0, (extra, p.stderr[-2000:])
         out = json.loads(p.stdout.strip().splitlines()[-1])
+        far[tuple(sorted(extra.items()))] = out["n_far_launches"]
         assert out["backward_error"] <= 1e-3, (extra, out["backward_error"])          # north_star tolerance
         assert out["orth_max"] <= 2e-3, (extra, out["orth_max"])
         d = np.array(out["absdiag"])
@@ -717,3 +713,34 @@ def test_opt_in_schedules_and_kernels():
             ref = d
         else:                                       # same R up to the fp16-level differences between update orders
             assert np.max(np.abs(d - ref) / ref) <= 2e-2, (extra, float(np.max(np.abs(d - ref) / ref)))
+    # the pairwise schedule really ran: it needs fewer far updates than the block-by-block one
+    assert far[()] < far[(("MPQR_FAR_PAIR", "0"),)], far
+    assert far[(("MPQR_ASHADOW", "1"), ("MPQR_FAR_PAIR", "1"))] == far[()], far
+
+
+@pytest.mark.gpu
+def test_q_identity_columns_fast_path_matches_oracle(po, tmp_path):
+    """Q formation copies the rows of X = Q2^T V that belong to columns of Q which are still identity columns (driver.hip apply_node,
+    `idc`).  At the library's default thresholds only 16384^2-sized runs reach that branch; a child process lowers them
+    (MPQR_GEMM2_MIN_TILES, MPQR_SPLIT_WGS are read once per process) so that an oracle-sized case takes it, and the result is compared
+    element-wise with the oracle's compact-WY block loop (the reference's Q accumulation, Cuda/qr.cu:1109-1207)."""
+    import json, os, subprocess, sys
+    child = os.path.join(os.path.dirname(os.path.abspath(__file__)), "optin_child.py")
+    m, n, r, ob = 1536, 768, 64, 256
+    dump = str(tmp_path / "out.npz")
+    env = dict(os.environ, MPQR_GEMM2_MIN_TILES="1", MPQR_SPLIT_WGS="64")
+    p = subprocess.run([sys.executable, child, str(m), str(n), str(r), str(ob), "1234", dump], env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    out = json.loads(p.stdout.strip().splitlines()[-1])
+    assert out["n_q_ident_rows"] >= 256, out                   # the branch was taken
+    z = np.load(dump); Ao, Q = z["Ab"], z["Q"]
+    A = po.generate(m, n, seed=1234)
+    R = np.triu(Ao[:m])
+    A0, Q0, R0 = po.block_qr(A, r, "compact32", omp=True)
+    V = po.extract_V(Ao, m, n, 0, n); V0 = po.extract_V(A0, m, n, 0, n)
+    D, first = align_pivot_signs(V, V0, R, R0, n)
+    Dm = np.ones(m, np.float32); Dm[:n] = D
+    assert relF(R * Dm[:, None], R0) <= 2e-3 and relF(Q[:, :n] * D[None, :], Q0[:, :n]) <= 3e-3
+    if first == n:
+        assert relF(Q, Q0) <= 3e-3
+    assert out["backward_error"] <= 1e-3 and out["orth_max"] <= 2e-3
