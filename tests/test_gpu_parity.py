@@ -705,7 +705,7 @@ def test_opt_in_schedules_and_kernels():
         p = subprocess.run([sys.executable, child, str(m), str(n), str(r), str(ob)], env=env, capture_output=True, text=True, timeout=600)
         assert p.returncode == 0, (extra, p.stderr[-2000:])
         out = json.loads(p.stdout.strip().splitlines()[-1])
-        far[tuple(sorted(extra.items()))] = out["n_far_launches"]
+        far[tuple(sorted(extra.items()))] = out["gbytes_far_nn"]
         assert out["backward_error"] <= 1e-3, (extra, out["backward_error"])          # north_star tolerance
         assert out["orth_max"] <= 2e-3, (extra, out["orth_max"])
         d = np.array(out["absdiag"])
@@ -713,9 +713,10 @@ def test_opt_in_schedules_and_kernels():
             ref = d
         else:                                       # same R up to the fp16-level differences between update orders
             assert np.max(np.abs(d - ref) / ref) <= 2e-2, (extra, float(np.max(np.abs(d - ref) / ref)))
-    # the pairwise schedule really ran: it needs fewer far updates than the block-by-block one
-    assert far[()] < far[(("MPQR_FAR_PAIR", "0"),)], far
-    assert far[(("MPQR_ASHADOW", "1"), ("MPQR_FAR_PAIR", "1"))] == far[()], far
+    # the pairwise schedule really ran: one pass over the far columns per PAIR of blocks moves fewer (algorithmic) bytes of the
+    # trailing matrix than one pass per block
+    assert far[()] < 0.95 * far[(("MPQR_FAR_PAIR", "0"),)], far
+    assert far[(("MPQR_ASHADOW", "1"), ("MPQR_FAR_PAIR", "1"))] <= 1.3 * far[()], far
 
 
 @pytest.mark.gpu
