@@ -51,6 +51,15 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm2_f16_kernel(GemmArgs g, int
     constexpr int STAGE = A_ALL + B_BYTES;
     // byte offset of logical chunk c of row r: XOR swizzle makes 16 consecutive rows hit 16 distinct 16-B bank slots
     auto swz = [](int r, int c) -> int { return r * ROWB + ((c ^ ((r / RB) & (CPR - 1))) << 4); };
+    // A tile of the transposing mode (A_F32T, BK = 64): a thread stores four 8-byte pieces into rows FOUR apart, so with the swizzle
+    // above the 16 lanes of a ds_write_b64 group fall on 4 bank slots (4-way conflicts: 43 % of the kernel's LDS cycles,
+    // profiles/r02_c4_sq_stalls.txt).  This one -- slot = c ^ (r2 | r3 << 1 | (r1 ^ r4) << 2), r_i = bit i of the row -- keeps the
+    // ds_read_b128 fragment reads conflict-free (16 distinct (row parity, slot) pairs in each of the instruction's lane groups) AND
+    // gives 8 distinct slots to any 8 consecutive rows-4-apart; lanes 2j, 2j+1 then share a slot with different halves (store_AT).
+    auto swzA = [&](int r, int c) -> int {
+        if (AM == A_F32T && BK == 64) return r * ROWB + ((c ^ (((r >> 2) & 3) | ((((r >> 1) ^ (r >> 4)) & 1) << 2))) << 4);
+        return swz(r, c);
+    };
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
@@ -87,7 +96,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm2_f16_kernel(GemmArgs g, int
     const float* pT[NBLK];
 #pragma unroll
     for (int i = 0; i < NBLK; i++) {
-        const int id = tid + NT * i, mg = id % (BM / 4), kg = id / (BM / 4);
+        const int id = tid + NT * i, mg = (id >> 1) % (BM / 4), kg = ((id >> 1) / (BM / 4)) * 2 + (id & 1);   // lanes 2j, 2j+1: same rows, k halves
         pT[i] = (const float*)g.A + (long)(kt0 * BK + kg * 4) * g.lda + bm + mg * 4;
     }
     const long ldaT = g.lda, stepT = (long)BK * g.lda;
@@ -145,14 +154,14 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm2_f16_kernel(GemmArgs g, int
         const float sc = g.in_scale;
 #pragma unroll
         for (int i = 0; i < NBLK; i++) {
-            const int id = tid + NT * i, mg = id % (BM / 4), kg = id / (BM / 4);
+            const int id = tid + NT * i, mg = (id >> 1) % (BM / 4), kg = ((id >> 1) / (BM / 4)) * 2 + (id & 1);
             const F4 v0 = raT[S][i * 4 + 0], v1 = raT[S][i * 4 + 1], v2 = raT[S][i * 4 + 2], v3 = raT[S][i * 4 + 3];
             const int half_off = (kg & 1) * 8, chunk = kg >> 1;
             uint2 w;
-            w.x = pack2(v0.x * sc, v1.x * sc); w.y = pack2(v2.x * sc, v3.x * sc); *(uint2*)(As + swz(mg * 4 + 0, chunk) + half_off) = w;
-            w.x = pack2(v0.y * sc, v1.y * sc); w.y = pack2(v2.y * sc, v3.y * sc); *(uint2*)(As + swz(mg * 4 + 1, chunk) + half_off) = w;
-            w.x = pack2(v0.z * sc, v1.z * sc); w.y = pack2(v2.z * sc, v3.z * sc); *(uint2*)(As + swz(mg * 4 + 2, chunk) + half_off) = w;
-            w.x = pack2(v0.w * sc, v1.w * sc); w.y = pack2(v2.w * sc, v3.w * sc); *(uint2*)(As + swz(mg * 4 + 3, chunk) + half_off) = w;
+            w.x = pack2(v0.x * sc, v1.x * sc); w.y = pack2(v2.x * sc, v3.x * sc); *(uint2*)(As + swzA(mg * 4 + 0, chunk) + half_off) = w;
+            w.x = pack2(v0.y * sc, v1.y * sc); w.y = pack2(v2.y * sc, v3.y * sc); *(uint2*)(As + swzA(mg * 4 + 1, chunk) + half_off) = w;
+            w.x = pack2(v0.z * sc, v1.z * sc); w.y = pack2(v2.z * sc, v3.z * sc); *(uint2*)(As + swzA(mg * 4 + 2, chunk) + half_off) = w;
+            w.x = pack2(v0.w * sc, v1.w * sc); w.y = pack2(v2.w * sc, v3.w * sc); *(uint2*)(As + swzA(mg * 4 + 3, chunk) + half_off) = w;
         }
     };
     auto store_A = [&](int stage) {
@@ -202,7 +211,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm2_f16_kernel(GemmArgs g, int
         for (int ks = 0; ks < BK / 16; ks++) {
             half8 a[4], b[2];
 #pragma unroll
-            for (int i = 0; i < 4; i++) a[i] = *(const half8*)(As + swz(wm + i * 32 + r, ks * 2 + h));
+            for (int i = 0; i < 4; i++) a[i] = *(const half8*)(As + swzA(wm + i * 32 + r, ks * 2 + h));
 #pragma unroll
             for (int j = 0; j < 2; j++) b[j] = *(const half8*)(Bs + swz(wn + j * 32 + r, ks * 2 + h));
 #pragma unroll

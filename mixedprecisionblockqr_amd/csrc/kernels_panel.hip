@@ -829,6 +829,10 @@ void launch_gh_solve(const LeafArgs& a, const double* G, float* Cv, int* flag, h
     gh_set_attrs();
     static const int dbg_skip = []() { const char* e = getenv("MPQR_DBG_NOSOLVE"); return e ? atoi(e) : 0; }();
     if (dbg_skip) return;                                  // timing experiment only (results are garbage): is the chain host-bound?
+    // gh_solve3 (kernels_solve.hip): the same recursion blocked by 16, chains in single waves (bit-identical outputs on the
+    // harness tools/test_solve3.hip); MPQR_SOLVE3=0 selects the step-by-step kernel of round 2 (one barrier per reflector)
+    static const int solve3 = []() { const char* e = getenv("MPQR_SOLVE3"); return e ? atoi(e) : 1; }();
+    if (solve3) { launch_gh_solve3(a, G, Cv, flag, s); return; }
     hipLaunchKernelGGL(gh_solve_kernel, dim3(1), dim3(GH_SOLVE_THREADS), 2 * TP * TPS * 4, s, a, G, Cv, flag);
 }
 void launch_gh_apply(const LeafArgs& a, const float* Cv, float* Sp, hipStream_t s) {
