@@ -92,9 +92,10 @@ typedef struct mpqr_timings {
     float ms_host_enqueue;/* host time to enqueue the factorisation's launches (before its one synchronisation)    */
     double gbytes_far_nn; /* algorithmic HBM bytes (1e9) of the far A2 -= V Y^T launches: fp32 C read + write, fp16 operands once */
     double gbytes_q_nn;   /* the same for Q formation's Q2 -= V Y^T launches (+ the fp16 shadow they write)          */
-    int   n_gh_leaves;    /* Gram-Householder leaves (gram / solve / apply launches) of the last block-loop pass     */
+    int   n_gh_leaves;    /* Gram-Householder leaves (gram / solve / apply launches) of the last mpqr_factor, all passes */
     float us_gh_solve;    /* one gh_solve launch at this plan's leaf width, timed alone (mpqr_bench_leaf_solve; 0 = not measured) */
     int   n_q_ident_rows; /* Q formation: rows of X = Q2^T V copied from V because their columns of Q were still identity columns */
+    int   restart_block;  /* the top-level block the LAST pass started from (n_passes > 1: a flagged leaf's block; the blocks left of it were kept) */
 } mpqr_timings;
 
 typedef struct mpqr_handle_s* mpqr_handle_t;

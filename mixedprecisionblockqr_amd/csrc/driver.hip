@@ -109,8 +109,13 @@ struct mpqr_handle_s {
     bool robust = false;          // true: EVERY tall leaf is factored column by column instead of by Gram-Householder
     std::vector<char> leaf_robust;   // per tree node: this tall leaf was flagged by gh_solve and takes the robust path
     int nflag = 0;                // ints in dflag: one flag per tree node (gh_solve raises dflag[node id])
+    int* hflag_host = nullptr;    // one word of mapped host memory: a flagged Gram-Householder leaf raises it as well, the thread that
+    int* hflag_dev = nullptr;     // enqueues the block loop polls it before every leaf and stops enqueuing (run_block_loop)
+    bool watch_flags = false;     // only mpqr_factor's block loop reacts to the word
+    bool pass_aborted = false;    // the last pass of the block loop stopped enqueuing at a flagged leaf
     int n_passes = 0, n_robust_leaves = 0;   // of the last mpqr_factor
-    int n_gh_leaves = 0;                     // Gram-Householder leaves launched by the last block-loop pass
+    int n_gh_leaves = 0;                     // Gram-Householder leaves launched by the last mpqr_factor (all passes)
+    int restart_block = 0;                   // top-level block the last pass of mpqr_factor started from
     int n_q_ident_rows = 0;                  // rows of X copied from V in the last Q formation (identity columns of Q)
     float us_gh_solve = 0.f;                 // mpqr_bench_leaf_solve's last result
     float* rbTf = nullptr; half_t* rbTh = nullptr; half_t* rbTth = nullptr; size_t rb_elems = 0;   // T arena of a robust leaf's sub-tree
@@ -205,6 +210,8 @@ void free_plan(mpqr_handle_t h) {
                     h->rbTf, h->rbTh, h->rbTth, h->Sleaf, h->V8n, h->V8t, h->A8t, h->Y8,
                     h->S2, h->tmp1b, h->tmp2b, h->Qt, h->At, h->Xh, h->Wh, h->Xl, h->Xh1, h->Xl1};
     for (void* p : ptrs) if (p) (void)hipFree(p);
+    if (h->hflag_host) (void)hipHostFree(h->hflag_host);
+    h->hflag_host = h->hflag_dev = nullptr;
     h->S2 = h->tmp1b = h->tmp2b = nullptr; h->s2_elems = 0; h->Qt = nullptr; h->shadow = nullptr; h->At = nullptr; h->at_read = false; h->Xh = nullptr; h->Xl = h->Xh1 = h->Xl1 = nullptr; h->Wh = nullptr; h->qroot = -1; h->qmerge_after.clear(); h->qpair.clear(); h->pairs_ready = false;
     h->dA = h->dA0 = h->dQ = nullptr; h->Vh = h->Vt = nullptr; h->vdiag = nullptr; h->Xt = nullptr; h->Yt = nullptr;
     h->S = nullptr; h->P = nullptr; h->tmp1 = h->tmp2 = nullptr; h->Tf = nullptr; h->Th = h->Tth = nullptr;
@@ -502,6 +509,14 @@ int factor_node(mpqr_handle_t h, int id, bool do_panel);
 int factor_rec(mpqr_handle_t h, int id, bool do_panel);
 int robust_tall_leaf(mpqr_handle_t h, const Node nd, bool do_panel);
 
+// A Gram-Householder leaf that finds its columns too ill conditioned raises its device flag AND a word in mapped host memory.  The
+// thread that enqueues mpqr_factor's block loop reads that word before every leaf (a plain load, nothing on the device) and stops
+// enqueuing: everything downstream of the flagged leaf is redone anyway, so the sooner the queue ends the less is wasted.
+constexpr int MPQR_ABORT_PASS = -1000;                   // internal: factor_node's "stop enqueuing", never returned to callers
+static inline bool pass_is_flagged(mpqr_handle_t h) {
+    return h->watch_flags && h->hflag_host && __atomic_load_n(h->hflag_host, __ATOMIC_RELAXED) != 0;
+}
+
 // Robust path for a tall (<=128-column) leaf: factor it through a temporary sub-tree of 32-column leaves
 // (column-by-column kernels + MFMA updates inside the leaf) and keep only the sub-tree's root T.  The sub-tree's T
 // arena is part of the plan (rbTf/rbTh/rbTth): no allocation, no host synchronisation here.
@@ -547,6 +562,7 @@ int factor_rec(mpqr_handle_t h, int id, bool do_panel) {
     const bool tq = h->tq_on && id < (int)h->ev_T.size();
     hipStream_t st = tq ? h->sT : h->s0;
     if (nd.left < 0) {
+        if (do_panel && pass_is_flagged(h)) return MPQR_ABORT_PASS;
         const bool tall = leaf_width(h, nd.c0) == 128;
         const bool robust_leaf = h->robust || (id < (int)h->leaf_robust.size() && h->leaf_robust[id]);
         if (do_panel && robust_leaf && !h->force32 && tall) {
@@ -560,7 +576,7 @@ int factor_rec(mpqr_handle_t h, int id, bool do_panel) {
             Range rg("mpqr:panel");
             a.A = h->Aeff; a.lda = h->lda; a.mrows = h->m; a.cb = rdown(nd.c0, tall ? 128 : 32); a.c0 = nd.c0; a.c1 = nd.c1;
             a.Vh = h->Vh; a.ldvh = h->ldvh; a.Vt = h->Vt; a.ldvt = h->ldvt; a.vdiag = h->vdiag;
-            a.P = h->P; a.maxwg = h->maxwg;
+            a.P = h->P; a.maxwg = h->maxwg; a.hostflag = h->hflag_dev;
             const bool fused = tall && !h->Vf;    // fp16 mode: the Gram of the rounded reflectors comes out of gh_apply
             int* flag = h->dflag + (id < h->nflag ? id : 0);
             if (tall) { launch_leaf_gram_householder(a, h->Gp, h->Gs, h->Cv, flag, fused ? h->Sp : nullptr, nullptr, h->s0); h->n_gh_leaves++; }
@@ -679,6 +695,7 @@ int factor_block_flat(mpqr_handle_t h, int top, const std::vector<int>& leaves) 
     };
     Node prev{}; int prev_o = -1;                         // leaf whose column block of T is still to be built
     for (size_t j = 0; j < leaves.size(); j++) {
+        if (pass_is_flagged(h)) return MPQR_ABORT_PASS;
         const int id = leaves[j];
         Node lf = h->nodes[id];
         const int o = lf.c0 - tp.c0;                       // reflectors of the block before this leaf
@@ -698,7 +715,7 @@ int factor_block_flat(mpqr_handle_t h, int top, const std::vector<int>& leaves) 
             LeafArgs a{};
             a.A = h->Aeff; a.lda = h->lda; a.mrows = h->m; a.cb = rdown(lf.c0, 128); a.c0 = lf.c0; a.c1 = lf.c1;
             a.Vh = h->Vh; a.ldvh = h->ldvh; a.Vt = h->Vt; a.ldvt = h->ldvt; a.vdiag = h->vdiag;
-            a.P = h->P; a.maxwg = h->maxwg;
+            a.P = h->P; a.maxwg = h->maxwg; a.hostflag = h->hflag_dev;
             launch_leaf_gram_householder(a, h->Gp, h->Gs, h->Cv, h->dflag + (id < h->nflag ? id : 0), h->Sp, nullptr, h->s0);
             h->n_gh_leaves++;
             if (h->wait_after_first_leaf && !tq) {       // look-ahead: the block's other columns arrive with this event
@@ -773,11 +790,19 @@ int factor_node(mpqr_handle_t h, int id, bool do_panel) {
     return rc;
 }
 
-int clear_reflectors(mpqr_handle_t h) {
-    HIPCHK(h, hipMemsetAsync(h->Vh, 0, (size_t)(h->m_pad + 256) * h->ldvh * sizeof(half_t), h->s0));
-    HIPCHK(h, hipMemsetAsync(h->Vt, 0, (size_t)(h->n_pad + 256) * h->ldvt * sizeof(half_t), h->s0));
-    HIPCHK(h, hipMemsetAsync(h->vdiag, 0, (size_t)h->n_pad * sizeof(float), h->s0));
-    if (h->Vf) HIPCHK(h, hipMemsetAsync(h->Vf, 0, (size_t)(h->m_pad + 256) * h->n_pad * sizeof(float), h->s0));
+// zero the reflector stores from reflector c0 on (c0 = 0: everything; a restart keeps the reflectors of the blocks left of c0)
+int clear_reflectors(mpqr_handle_t h, int c0 = 0) {
+    if (c0 <= 0) {
+        HIPCHK(h, hipMemsetAsync(h->Vh, 0, (size_t)(h->m_pad + 256) * h->ldvh * sizeof(half_t), h->s0));
+        HIPCHK(h, hipMemsetAsync(h->Vt, 0, (size_t)(h->n_pad + 256) * h->ldvt * sizeof(half_t), h->s0));
+        HIPCHK(h, hipMemsetAsync(h->vdiag, 0, (size_t)h->n_pad * sizeof(float), h->s0));
+        if (h->Vf) HIPCHK(h, hipMemsetAsync(h->Vf, 0, (size_t)(h->m_pad + 256) * h->n_pad * sizeof(float), h->s0));
+        return MPQR_OK;
+    }
+    HIPCHK(h, hipMemset2DAsync(h->Vh + c0, (size_t)h->ldvh * sizeof(half_t), 0, (size_t)(h->ldvh - c0) * sizeof(half_t), (size_t)h->m_pad + 256, h->s0));
+    HIPCHK(h, hipMemsetAsync(h->Vt + (size_t)c0 * h->ldvt, 0, (size_t)(h->n_pad + 256 - c0) * h->ldvt * sizeof(half_t), h->s0));
+    HIPCHK(h, hipMemsetAsync(h->vdiag + c0, 0, (size_t)(h->n_pad - c0) * sizeof(float), h->s0));
+    if (h->Vf) HIPCHK(h, hipMemset2DAsync(h->Vf + c0, (size_t)h->n_pad * sizeof(float), 0, (size_t)(h->n_pad - c0) * sizeof(float), (size_t)h->m_pad + 256, h->s0));
     return MPQR_OK;
 }
 
@@ -1199,6 +1224,13 @@ static int plan_common(mpqr_handle_t h, int m, int n, int r, const mpqr_opts* op
     if ((rc = dalloc(h, &h->Cv, (size_t)16384))) return rc;
     h->nflag = (int)h->nodes.size() + 1024;               // one flag per tree node (+ room for the stage calls' private trees)
     if ((rc = dalloc(h, &h->dflag, (size_t)h->nflag))) return rc;
+    {   // the flag word the enqueuing thread polls: mapped, coherent host memory (a flagged leaf stores 1 into it, system scope)
+        void* hp = nullptr; void* dp = nullptr;
+        if (hipHostMalloc(&hp, 64, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess) { h->err = "hipHostMalloc failed"; return MPQR_ERR_ALLOC; }
+        h->hflag_host = (int*)hp; *h->hflag_host = 0;
+        HIPCHK(h, hipHostGetDevicePointer(&dp, hp, 0));
+        h->hflag_dev = (int*)dp;
+    }
     h->leaf_robust.assign(h->nodes.size(), 0);
     // T arena of a robustly factored tall leaf (sub-tree of 32-column leaves over <= 128 columns: 7 nodes, ldt <= 192)
     h->rb_elems = (size_t)8 * 192 * 192;
@@ -1301,15 +1333,34 @@ int mpqr_generate_matrix(mpqr_handle_t h, uint64_t seed) {
 }
 
 // enqueue copy-in + the whole block loop; flags[id] != 0: the Gram-Householder leaf `id` was too ill-conditioned
-static int run_block_loop(mpqr_handle_t h, std::vector<int>& flags) {
+// start > 0 (restart after a flagged leaf): blocks [0, start) of the previous pass are kept -- their reflectors, T's and columns of
+// R -- and the columns right of them are brought back to the state in which block `start` found them: the input with the far
+// updates of the kept blocks applied again (GEMM work only, no panel chain).  The pass then runs blocks start .. end.
+static int run_block_loop(mpqr_handle_t h, std::vector<int>& flags, int start = 0) {
     int rc;
-    h->far_used = 0; h->far_flops.clear(); h->far_bytes.clear(); h->chain_used = 0; h->v8_node = -1;
+    h->v8_node = -1;
     h->pairs_ready = false; h->q_first = (size_t)-1;
     const auto host_t0 = std::chrono::steady_clock::now();  // host time to enqueue the block loop (ms_host_enqueue)
-    HIPCHK(h, hipEventRecord(h->ev[0], h->s0));
-    HIPCHK(h, hipMemcpyAsync(h->dA, h->dA0, (size_t)h->m_pad * h->lda * sizeof(float), hipMemcpyDeviceToDevice, h->s0));
+    if (start <= 0) {
+        start = 0;
+        h->far_used = 0; h->far_flops.clear(); h->far_bytes.clear(); h->chain_used = 0;
+        HIPCHK(h, hipEventRecord(h->ev[0], h->s0));
+        HIPCHK(h, hipMemcpyAsync(h->dA, h->dA0, (size_t)h->m_pad * h->lda * sizeof(float), hipMemcpyDeviceToDevice, h->s0));
+        if ((rc = clear_reflectors(h))) return rc;
+    } else {
+        Range rg("mpqr:restart_replay");
+        const int cs = h->nodes[h->tops[start]].c0;
+        HIPCHK(h, hipMemcpy2DAsync(h->dA + cs, (size_t)h->lda * sizeof(float), h->dA0 + cs, (size_t)h->lda * sizeof(float),
+                                   (size_t)(h->lda - cs) * sizeof(float), (size_t)h->m_pad, hipMemcpyDeviceToDevice, h->s0));
+        if ((rc = clear_reflectors(h, cs))) return rc;
+        h->at_read = false;                                 // (the fp16 shadow of the trailing matrix is stale)
+        for (int s = 0; s < start; s++) apply_node(h, h->nodes[h->tops[s]], h->dA, h->lda, cs, h->n, true, h->a_scale, false, 0, true);
+    }
     HIPCHK(h, hipMemsetAsync(h->dflag, 0, (size_t)h->nflag * sizeof(int), h->s0));
-    if ((rc = clear_reflectors(h))) return rc;
+    static const int watch_env = []() { const char* e = getenv("MPQR_WATCH_FLAGS"); return e ? atoi(e) : 1; }();   // 0: never stop a pass early (round 2)
+    __atomic_store_n(h->hflag_host, 0, __ATOMIC_RELAXED);   // (no kernel of an earlier pass is still running: every pass ends synchronised)
+    h->watch_flags = watch_env != 0;
+    bool aborted = false;
     const bool la = h->Xt1 != nullptr;                    // look-ahead: far updates on s1, panel chain on s0
     if (la) {
         // s1 must see the copy-in / clears issued on s0
@@ -1341,7 +1392,7 @@ static int run_block_loop(mpqr_handle_t h, std::vector<int>& flags) {
     static const int fp_env = []() { const char* e = getenv("MPQR_FAR_PAIR"); return e ? atoi(e) : 1; }();
     const bool far_pair = la && fp_env && h->opts.precision == MPQR_PREC_FP16 && h->opts.form_q && h->S2 && h->qroot < 0;
     bool deferred = false, pair_merged = false;
-    for (size_t t = 0; t < nt; t++) {
+    for (size_t t = (size_t)start; t < nt; t++) {
         const Node nd = h->nodes[h->tops[t]];
         if (la && t > 0) {
             if (!ext[t - 1]) HIPCHK(h, hipStreamWaitEvent(h->s0, h->ev_cols[t], 0));
@@ -1352,7 +1403,12 @@ static int run_block_loop(mpqr_handle_t h, std::vector<int>& flags) {
         if (timed) HIPCHK(h, hipEventRecord(h->chain_ev[h->chain_used], h->s0));
         rc = factor_node(h, h->tops[t], true);
         h->ext_c1 = 0;
-        if (rc) { h->defer_join = false; return rc; }
+        if (rc == MPQR_ABORT_PASS) {          // a leaf of this pass is flagged: nothing enqueued from here on would be kept
+            aborted = true;
+            h->wait_after_first_leaf = nullptr; h->op1_stream = nullptr;
+            break;
+        }
+        if (rc) { h->defer_join = false; h->watch_flags = false; return rc; }
         if (h->wait_after_first_leaf) {       // (no leaf launched: cannot happen, but never leave the wait pending)
             HIPCHK(h, hipStreamWaitEvent(h->s0, h->wait_after_first_leaf, 0));
             h->wait_after_first_leaf = nullptr;
@@ -1365,7 +1421,7 @@ static int run_block_loop(mpqr_handle_t h, std::vector<int>& flags) {
             if (h->opts.form_q && h->qroot >= 0) for (int id : h->qmerge_after[t]) merge_prefix(h, id, h->s0);
             continue;
         }
-        h->at_read = t >= 1;                                // far update t-1 wrote the shadow of every column this one reads
+        h->at_read = t >= 1 && !(start > 0 && (int)t == start);   // far update t-1 wrote the shadow of every column this one reads (not after a restart)
         HIPCHK(h, hipEventRecord(h->ev_node[t], h->node_done_stream ? h->node_done_stream : h->s0));
         HIPCHK(h, hipStreamWaitEvent(h->s1, h->ev_node[t], 0));
         if (t + 1 < nt) {
@@ -1398,7 +1454,8 @@ static int run_block_loop(mpqr_handle_t h, std::vector<int>& flags) {
         pair_merged = false;
         if (h->opts.form_q && h->qroot >= 0) for (int id : h->qmerge_after[t]) merge_prefix(h, id, h->s1);   // ... or the T of all blocks so far
     }
-    h->pairs_ready = h->opts.form_q && h->S2 != nullptr;     // (pairs or the whole tree)
+    h->watch_flags = false; h->pass_aborted = aborted;
+    h->pairs_ready = !aborted && h->opts.form_q && h->S2 != nullptr;     // (pairs or the whole tree)
     if (h->defer_join) {                                    // the T stream's work of every block, once
         h->defer_join = false;
         HIPCHK(h, hipEventRecord(h->ev_join, h->sT));
@@ -1422,20 +1479,37 @@ int mpqr_factor(mpqr_handle_t h) {
     if (!h->have_input) return fail(h, MPQR_ERR_STATE, "no input matrix has been set");
     if ((rc = compute_scale(h, h->dA0))) return rc;
     // Gram-Householder leaves that gh_solve flags (a column that cannot be reflected, or rho < 1e-8) are redone on the
-    // column-by-column kernels: the pass is repeated with THOSE leaves on the robust path (results downstream of a flagged
-    // leaf are not trusted, so a pass can reveal further leaves); after three passes every tall leaf goes robust.
+    // column-by-column kernels.  A flagged leaf also raises a word in mapped host memory that the enqueuing thread reads before
+    // every leaf: the pass stops being enqueued there (run_block_loop), the queue drains, and the next pass RESTARTS at the
+    // top-level block that holds the flagged leaf, with that leaf on the robust path (everything left of the block is final).
+    // Only the FIRST flagged leaf (in column order) is believed: the leaves behind it worked on columns it had spoiled, so their
+    // flags say nothing.  Six restarts at most; after that every tall leaf goes robust and the pass runs from block 0.
+    // n_passes counts passes (stopped ones included), restart_block is the block the last pass started from.
     std::vector<int> flags;
     h->n_passes = 0;
-    for (int pass = 0; pass < 5; pass++) {
+    int start = 0, gh_total = 0;
+    for (int pass = 0; pass < 8; pass++) {
         h->n_passes++;
         h->n_gh_leaves = 0;
-        if ((rc = run_block_loop(h, flags))) return rc;
-        int fresh = 0;
+        h->restart_block = start;
+        if ((rc = run_block_loop(h, flags, start))) return rc;
+        gh_total += h->n_gh_leaves;
+        int bad = -1;                                     // the flagged leaf with the smallest first column
         for (size_t id = 0; id < flags.size(); id++)
-            if (flags[id] && !h->leaf_robust[id]) { h->leaf_robust[id] = 1; fresh++; }
-        if (!fresh || h->robust) break;
-        if (pass >= 2) h->robust = true;
+            if (flags[id] && !h->leaf_robust[id] && (bad < 0 || h->nodes[id].c0 < h->nodes[bad].c0)) bad = (int)id;
+        if (bad < 0 && h->pass_aborted) return fail(h, MPQR_ERR_STATE, "the block loop stopped at a flagged leaf, but no leaf flag is set");
+        if (bad < 0 || h->robust) break;
+        h->leaf_robust[bad] = 1;
+        int first = 0;
+        for (int t = 0; t < (int)h->tops.size(); t++) {
+            const Node& tp = h->nodes[h->tops[t]];
+            if (h->nodes[bad].c0 >= tp.c0 && h->nodes[bad].c0 < tp.c1) { first = t; break; }
+        }
+        static const int restart_env = []() { const char* e = getenv("MPQR_RESTART"); return e ? atoi(e) : 1; }();   // 0: every pass from block 0 (round 2)
+        start = restart_env ? first : 0;
+        if (pass >= 5) { h->robust = true; start = 0; }
     }
+    h->n_gh_leaves = gh_total;
     h->n_robust_leaves = 0;
     for (char c : h->leaf_robust) h->n_robust_leaves += c ? 1 : 0;
     h->factored = true;
@@ -1502,6 +1576,7 @@ int mpqr_get_timings(mpqr_handle_t h, mpqr_timings* t) {
     t->n_gh_leaves = h->n_gh_leaves;
     t->us_gh_solve = h->us_gh_solve;
     t->n_q_ident_rows = h->n_q_ident_rows;
+    t->restart_block = h->restart_block;
     h->last_t = *t;
     return MPQR_OK;
 }

@@ -636,7 +636,10 @@ __global__ __launch_bounds__(GH_SOLVE_THREADS) void gh_solve_kernel(LeafArgs a, 
             a.Vt[(long)k * a.ldvt + k] = (half_t)vd;
         }
     }
-    if (tid == 0 && lflag) atomicOr(flag, 1);
+    if (tid == 0 && lflag) {
+        atomicOr(flag, 1);
+        if (a.hostflag) __hip_atomic_store(a.hostflag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // the enqueuing host thread polls this word
+    }
     __syncthreads();
     for (int e = tid; e < TP * TPS; e += GH_SOLVE_THREADS) Ts[e] = 0.f;
     __syncthreads();

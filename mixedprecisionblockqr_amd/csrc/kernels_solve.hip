@@ -661,7 +661,10 @@ __global__ __launch_bounds__(S3_THREADS) void gh_solve3_kernel(LeafArgs a, const
             a.Vt[(long)k * a.ldvt + k] = (half_t)vd;
         }
     }
-    if (tid == 0 && lflag) atomicOr(flag, 1);
+    if (tid == 0 && lflag) {
+        atomicOr(flag, 1);
+        if (a.hostflag) __hip_atomic_store(a.hostflag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // the enqueuing host thread polls this word
+    }
     __syncthreads();                                       // the panels are dead: their LDS becomes Ts
     for (int e = tid; e < TP * TPS; e += S3_THREADS) Ts[e] = 0.f;
     __syncthreads();

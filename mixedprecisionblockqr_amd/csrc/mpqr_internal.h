@@ -92,6 +92,7 @@ struct LeafArgs {
     float* vdiag;               // diagonal element of each reflector
     float* P;                   // partial dot products, 2 x maxwg x 32
     int maxwg;
+    int* hostflag;              // Gram-Householder leaves: word in mapped host memory that a flagged leaf also raises (or nullptr)
 };
 void launch_leaf_factor(const LeafArgs& a, hipStream_t s);   // robust path: one workgroup (<=2048 rows) or one launch per column
 // tall leaves (up to 128 columns inside a 128-aligned window, a.cb): Gram-Householder, 4 launches; raises *flag
