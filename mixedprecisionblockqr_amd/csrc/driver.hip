@@ -69,6 +69,7 @@ struct mpqr_handle_s {
     bool defer_join = false;            // block loop with look-ahead: the chain does not wait for a block's T (its users wait on ev_T)
     std::vector<hipEvent_t> ev_cols2;
     bool tq_on = false;         // this plan builds its T's on sT (fp16 mode)
+    std::function<int()> far_hook;          // run_block_loop: the previous block's far update, enqueued behind the next block's first gh_gram
     hipStream_t node_done_stream = nullptr;   // stream on which the last factor_node left the block's reflectors complete
     hipStream_t inblock_stream = nullptr;     // apply_node, lane 0: run on this stream instead of s0
     hipStream_t op1_stream = nullptr;   // set by factor_block_flat: X = C2^T V (+ its slab sum) of the next apply runs there
@@ -100,6 +101,9 @@ struct mpqr_handle_s {
     float* Xt = nullptr;   size_t xt_elems = 0;
     half_t* Yt = nullptr;  size_t yt_elems = 0;
     float* Xt1 = nullptr;  half_t* Yt1 = nullptr;      // scratch of the far-update stream (look-ahead)
+    float* Xt2 = nullptr;  half_t* Yt2 = nullptr; size_t xt2_elems = 0;   // scratch of the deferred in-block updates (apply_node lane 2, T stream)
+    int pre_leaves = 0;                 // flat block: its first pre_leaves leaves were brought up to date by the previous block (run_block_loop)
+    hipEvent_t ev_def = nullptr;        // chain -> T stream: a pre-updated leaf's reflectors and T are complete (deferred update may start)
     std::vector<hipEvent_t> ev_node, ev_cols;          // per top-level node: reflectors ready / columns up to date
     float* S = nullptr;    size_t s_elems = 0;
     float* Sleaf = nullptr;       // 128 x 128 Gram of a leaf's fp16 reflectors (chain stream; S itself is used by the T stream)
@@ -207,7 +211,7 @@ int dalloc(mpqr_handle_t h, T** p, size_t elems) {
 void free_plan(mpqr_handle_t h) {
     void* ptrs[] = {h->dA, h->dA0, h->dQ, h->Vh, h->Vt, h->vdiag, h->Xt, h->Yt, h->S, h->P, h->tmp1, h->tmp2,
                     h->Tf, h->Th, h->Tth, h->dstage, h->Gp, h->Gs, h->Cv, h->dflag, h->Vf, h->Yf, h->Xt1, h->Yt1, h->Sp,
-                    h->rbTf, h->rbTh, h->rbTth, h->Sleaf, h->V8n, h->V8t, h->A8t, h->Y8,
+                    h->rbTf, h->rbTh, h->rbTth, h->Sleaf, h->V8n, h->V8t, h->A8t, h->Y8, h->Xt2, h->Yt2,
                     h->S2, h->tmp1b, h->tmp2b, h->Qt, h->At, h->Xh, h->Wh, h->Xl, h->Xh1, h->Xl1};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (h->hflag_host) (void)hipHostFree(h->hflag_host);
@@ -217,7 +221,7 @@ void free_plan(mpqr_handle_t h) {
     h->S = nullptr; h->P = nullptr; h->tmp1 = h->tmp2 = nullptr; h->Tf = nullptr; h->Th = h->Tth = nullptr;
     h->dstage = nullptr; h->stage_elems = 0;
     h->Gp = nullptr; h->Gs = nullptr; h->Cv = nullptr; h->dflag = nullptr; h->Vf = nullptr; h->Yf = nullptr;
-    h->Xt1 = nullptr; h->Yt1 = nullptr; h->Sp = nullptr;
+    h->Xt1 = nullptr; h->Yt1 = nullptr; h->Sp = nullptr; h->Xt2 = nullptr; h->Yt2 = nullptr; h->xt2_elems = 0;
     h->rbTf = nullptr; h->rbTh = h->rbTth = nullptr; h->rb_elems = 0; h->nflag = 0; h->leaf_robust.clear(); h->Sleaf = nullptr;
     h->V8n = h->V8t = h->A8t = h->Y8 = nullptr; h->v8_node = -1;
     for (hipEvent_t e : h->chain_ev) (void)hipEventDestroy(e);
@@ -347,9 +351,10 @@ void apply_node(mpqr_handle_t h, const Node& nd, float* C, long ldc, int clo, in
     if (chi <= clo) return;
     static const int dbg_nofar = []() { const char* e = getenv("MPQR_DBG_NOFAR"); return e ? atoi(e) : 0; }();
     if (dbg_nofar && lane == 1) return;                     // timing experiment only (results are garbage): the chain without far updates beside it
-    hipStream_t st = lane ? h->s1 : (h->inblock_stream ? h->inblock_stream : h->s0);   // lane 1: far-update stream with its own scratch
-    float* const Xt = lane ? h->Xt1 : h->Xt;
-    half_t* const Yt = lane ? h->Yt1 : h->Yt;
+    // lane 1: far-update stream with its own scratch; lane 2: a deferred in-block update, all of it on the T stream, own scratch
+    hipStream_t st = lane == 1 ? h->s1 : lane == 2 ? h->sT : (h->inblock_stream ? h->inblock_stream : h->s0);
+    float* const Xt = lane == 1 ? h->Xt1 : lane == 2 ? h->Xt2 : h->Xt;
+    half_t* const Yt = lane == 1 ? h->Yt1 : lane == 2 ? h->Yt2 : h->Yt;
     const int rlo = rdown(nd.c0, 64);
     const int Kw = h->m_pad - rlo;
     if (h->opts.precision == MPQR_PREC_FP32) {            // dev_block_qr_wy twin: every product on the exact-f32 MFMA
@@ -390,7 +395,7 @@ void apply_node(mpqr_handle_t h, const Node& nd, float* C, long ldc, int clo, in
     g1.M = M1; g1.N = Kr; g1.K = Kw;
     g1.in_scale = in_scale; g1.alpha = 1.f;
     const long slab = (long)M1 * Kr;
-    g1.nsplit = choose_split(M1, Kr, Kw, h->xt_elems, slab);
+    g1.nsplit = choose_split(M1, Kr, Kw, lane == 2 ? h->xt2_elems : h->xt_elems, slab);
     g1.slab_out_stride = slab;
     if (record) (void)hipEventRecord(e0, st);
     hipStream_t st1 = (h->op1_stream && lane == 0) ? h->op1_stream : st;     // flat schedule: X on the side stream, T on the chain
@@ -403,17 +408,17 @@ void apply_node(mpqr_handle_t h, const Node& nd, float* C, long ldc, int clo, in
     static const int xsplit = []() { const char* e = getenv("MPQR_XSPLIT"); return e ? atoi(e) : 1; }();
     static const int x16_env = []() { const char* e = getenv("MPQR_X16"); return e ? atoi(e) : 1; }();
     // big unsplit updates: X goes from its GEMM to the next one as fp16 (hi, and lo when xsplit) instead of fp32
-    half_t* const Xhi = lane ? h->Xh1 : h->Xh;
+    half_t* const Xhi = lane == 1 ? h->Xh1 : lane == 2 ? nullptr : h->Xh;
     // (Q formation: Q has no dominant component, the lo part buys 1.5 % of backward error and 7 % of ||Q^T Q - I|| for
     // 0.7 ms at 16384^2 -- MPQR_QSPLIT=1 turns it on there as well)
     static const int qsplit = []() { const char* e = getenv("MPQR_QSPLIT"); return e ? atoi(e) : 0; }();
     const bool q_apply = h->shadow && lane == 0 && !far;
-    half_t* const Xlo = (xsplit && (!q_apply || qsplit)) ? (lane ? h->Xl1 : h->Xl) : nullptr;
+    half_t* const Xlo = (xsplit && (!q_apply || qsplit)) ? (lane == 1 ? h->Xl1 : lane == 2 ? nullptr : h->Xl) : nullptr;
     const bool x16 = x16_env && Xhi && (!xsplit || Xlo || q_apply) && !f8 && g1.nsplit == 1 && M1 >= 256 && Kr >= 256 && (Kr % 64) == 0 &&
                      (long)(M1 / 256) * (Kr / 256) >= gemm2_min_tiles() && h->opts.precision != MPQR_PREC_FP32;
     // one leaf (128 reflectors) onto a few columns: slab sum and Y = X T' in one small kernel (leaf_xt_kernel)
     static const int fuse_env = []() { const char* e = getenv("MPQR_FUSE_XT"); return e ? atoi(e) : 1; }();
-    const bool fuse_xt = fuse_env && !f8 && !far && lane == 0 && Kr == 128 && M1 <= 4096 && !(h->shadow && lane == 0);
+    const bool fuse_xt = fuse_env && !f8 && !far && lane != 1 && Kr == 128 && M1 <= 4096 && !(h->shadow && lane == 0);
     if (f8) {
         if (h->v8_node != nd.id) {                          // the block's reflectors, once per block: 2^8 V in both layouts
             launch_quant_h16_fp8(h->Vh + (long)rlo * h->ldvh + nd.a0, h->ldvh, h->V8n, h->ld8k, Kw, Kr, 256.f, st);
@@ -703,6 +708,7 @@ int factor_block_flat(mpqr_handle_t h, int top, const std::vector<int>& leaves) 
         lf.tld = ld;
         const bool robust_leaf = h->robust || (id < (int)h->leaf_robust.size() && h->leaf_robust[id]);
         if (robust_leaf) {
+            if (h->far_hook) { auto fh = std::move(h->far_hook); h->far_hook = nullptr; if ((rc = fh())) return rc; }   // (see below)
             // column-by-column kernels through a private sub-tree; its root T (contiguous, ldt^2) goes into the diagonal block
             const size_t keep = h->nodes[id].toff;
             if ((rc = robust_tall_leaf(h, h->nodes[id], true))) return rc;
@@ -716,7 +722,12 @@ int factor_block_flat(mpqr_handle_t h, int top, const std::vector<int>& leaves) 
             a.A = h->Aeff; a.lda = h->lda; a.mrows = h->m; a.cb = rdown(lf.c0, 128); a.c0 = lf.c0; a.c1 = lf.c1;
             a.Vh = h->Vh; a.ldvh = h->ldvh; a.Vt = h->Vt; a.ldvt = h->ldvt; a.vdiag = h->vdiag;
             a.P = h->P; a.maxwg = h->maxwg; a.hostflag = h->hflag_dev;
-            launch_leaf_gram_householder(a, h->Gp, h->Gs, h->Cv, h->dflag + (id < h->nflag ? id : 0), h->Sp, nullptr, h->s0);
+            launch_gh_gram(a, h->Gp, h->Gs, h->s0);
+            // the previous block's far update is enqueued HERE (run_block_loop): its stream starts when this leaf's gh_solve does,
+            // so its first GEMMs fill the other 255 CUs during the solve instead of holding them while gh_gram wants them
+            if (h->far_hook) { auto fh = std::move(h->far_hook); h->far_hook = nullptr; if ((rc = fh())) return rc; }
+            launch_gh_solve(a, h->Gs, h->Cv, h->dflag + (id < h->nflag ? id : 0), h->s0);
+            launch_gh_apply(a, h->Cv, h->Sp, h->s0);
             h->n_gh_leaves++;
             if (h->wait_after_first_leaf && !tq) {       // look-ahead: the block's other columns arrive with this event
                 (void)hipStreamWaitEvent(h->s0, h->wait_after_first_leaf, 0);
@@ -735,21 +746,40 @@ int factor_block_flat(mpqr_handle_t h, int top, const std::vector<int>& leaves) 
                           h->Tth + lf.toff, lf.ldt, h->s0, ld);
         }
         // the chain: this leaf alone onto the rest of the block -- and, under look-ahead, onto the next block's first
-        // leaf as well (ext_c1): that leaf then needs nothing from this block's far update and the chain crosses the block
+        // leaves as well (ext_c1): those leaves then need nothing from this block's far update and the chain crosses the block
         // boundary without waiting for the block's T and a skinny far update (~350 us per boundary at 16384^2)
         const int upd_end = std::max(tp.c1, h->ext_c1);
-        if (h->wait_after_first_leaf) {
-            // The block's other columns become valid with this event (far update of the previous block).  Only X = C2^T V_j
-            // reads them first, and it runs on the side stream: that stream waits, the chain stream goes on with T_j and
-            // meets the dependency through the X event (the robust leaf path, which works on the chain stream, waits there)
-            (void)hipStreamWaitEvent(tq && !robust_leaf ? h->sT : h->s0, h->wait_after_first_leaf, 0);
-            h->wait_after_first_leaf = nullptr;
+        // The first P leaves of this block are already up to date (the previous block's in-block updates reached them); the
+        // block's other columns become valid with the event wait_after_first_leaf (part (a) of the previous block's far update).
+        // Leaves before the last pre-updated one update only the other pre-updated leaves on the chain; their update of the rest is
+        // DEFERRED: it runs on the T stream (apply_node lane 2: X, Y and the update there, own scratch) as soon as the event has
+        // fired, beside the chain's work on the next leaf.  The last pre-updated leaf's own update follows them in that stream's
+        // order (its X GEMM runs there), so the chain first meets the far update's columns one leaf later than the block boundary.
+        const int P = std::min<int>(h->pre_leaves, (int)leaves.size());
+        const int cpre = P > 0 ? h->nodes[leaves[P - 1]].c1 : lf.c1;
+        const bool split = tq && P >= 2 && (int)j < P - 1 && cpre < upd_end;
+        if ((int)j == P - 1 || P == 0 || !tq) {
+            if (h->wait_after_first_leaf) {
+                // Only X = C2^T V_j reads those columns first, and it runs on the side stream: that stream waits, the chain stream goes
+                // on with T_j and meets the dependency through the X event (the robust leaf path, which works on the chain stream, waits there)
+                (void)hipStreamWaitEvent(tq && !robust_leaf ? h->sT : h->s0, h->wait_after_first_leaf, 0);
+                if (tq && robust_leaf && P >= 2) (void)hipStreamWaitEvent(h->sT, h->wait_after_first_leaf, 0);
+                h->wait_after_first_leaf = nullptr;
+            }
         }
-        if (lf.c1 < upd_end) {
+        const int own_end = split ? cpre : upd_end;
+        if (lf.c1 < own_end) {
             Range rg("mpqr:in_block_update");
             h->op1_stream = tq ? h->sT : nullptr;
-            apply_node(h, lf, h->Aeff, h->lda, lf.c1, upd_end, true, h->a_scale, false);
+            apply_node(h, lf, h->Aeff, h->lda, lf.c1, own_end, true, h->a_scale, false);
             h->op1_stream = nullptr;
+        }
+        if (split) {                                       // the deferred part: the T stream has this leaf's V and T from here on
+            Range rg("mpqr:in_block_update_deferred");
+            (void)hipEventRecord(h->ev_def, h->s0);
+            (void)hipStreamWaitEvent(h->sT, h->ev_def, 0);
+            if (h->wait_after_first_leaf) (void)hipStreamWaitEvent(h->sT, h->wait_after_first_leaf, 0);   // (kept: the last pre-updated leaf waits too)
+            apply_node(h, lf, h->Aeff, h->lda, cpre, upd_end, true, h->a_scale, false, 2);
         }
         // background, behind this leaf's X GEMM in the side stream's queue: the PREVIOUS leaf's column block of T
         if (prev_o >= 0) t_column_block(prev, prev_o);
@@ -1019,6 +1049,7 @@ int mpqr_create(mpqr_handle_t* out, int device) {
         hipEventCreateWithFlags(&h->ev_v, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&h->ev_x, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&h->ev_def, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&h->ev_dist_chain, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&h->ev_dist_far, hipEventDisableTiming) != hipSuccess) {
         g_create_err = "hipSetDevice/hipStreamCreate failed";
@@ -1050,6 +1081,7 @@ int mpqr_destroy(mpqr_handle_t h) {
     if (h->ev_v) (void)hipEventDestroy(h->ev_v);
     if (h->ev_join) (void)hipEventDestroy(h->ev_join);
     if (h->ev_x) (void)hipEventDestroy(h->ev_x);
+    if (h->ev_def) (void)hipEventDestroy(h->ev_def);
     if (h->ev_dist_chain) (void)hipEventDestroy(h->ev_dist_chain);
     if (h->ev_dist_far) (void)hipEventDestroy(h->ev_dist_far);
     (void)hipStreamDestroy(h->s0);
@@ -1205,6 +1237,15 @@ static int plan_common(mpqr_handle_t h, int m, int n, int r, const mpqr_opts* op
         if ((rc = dalloc(h, &h->Yt1, h->yt_elems + (size_t)256 * x_ldt))) return rc;
         HIPCHK(h, hipMemsetAsync(h->Xt1, 0, (h->xt_elems + (size_t)256 * x_ldt) * sizeof(float), h->s0));
         HIPCHK(h, hipMemsetAsync(h->Yt1, 0, (h->yt_elems + (size_t)256 * x_ldt) * sizeof(half_t), h->s0));
+        {   // one leaf (128 reflectors) onto at most a block's columns + the next block's pre-updated leaves, <= 32 split-K slabs
+            int wmax = 0;
+            for (int tp : h->tops) wmax = std::max(wmax, h->nodes[tp].c1 - h->nodes[tp].c0);
+            h->xt2_elems = (size_t)(wmax + 1024) * 128 * 32;
+            if ((rc = dalloc(h, &h->Xt2, h->xt2_elems + (size_t)256 * 128))) return rc;
+            if ((rc = dalloc(h, &h->Yt2, h->xt2_elems + (size_t)256 * 128))) return rc;
+            HIPCHK(h, hipMemsetAsync(h->Xt2, 0, (h->xt2_elems + (size_t)256 * 128) * sizeof(float), h->s0));
+            HIPCHK(h, hipMemsetAsync(h->Yt2, 0, (h->xt2_elems + (size_t)256 * 128) * sizeof(half_t), h->s0));
+        }
         for (size_t t = 0; t < h->tops.size(); t++) {
             hipEvent_t e1, e2;
             HIPCHK(h, hipEventCreateWithFlags(&e1, hipEventDisableTiming));
@@ -1373,16 +1414,25 @@ static int run_block_loop(mpqr_handle_t h, std::vector<int>& flags, int start = 
     // plus the first leaf of block t+2 (when that block is flat too), waited for after block t+1's first leaf is enqueued.
     // Tree-scheduled blocks keep the older split: first leaf of block t+1 first (ev_cols, waited for before the block).
     const size_t nt = h->tops.size();
-    std::vector<char> ext(nt + 1, 0);
-    std::vector<int> cfirst(nt + 2, h->n);                  // end of block t's first leaf
+    // MPQR_EXT_LEAVES (default 2): how many leading leaves of block t+1 the in-block updates of a flat block t reach.  With 2 the
+    // chain meets the columns of part (a) one leaf after the boundary: the first leaf's update of the rest of its block is deferred
+    // to the T stream (factor_block_flat), and part (a) -- which needs the block's complete T -- has a whole leaf to arrive in.
+    std::vector<char> ext(nt + 1, 0), flat(nt + 1, 0);
+    std::vector<int> cfirst(nt + 2, h->n);                  // end of the leaves of block t that the previous block's updates reach
+    std::vector<int> npre(nt + 2, 0);                       // ... and how many they are (1: the first leaf only, also for tree blocks)
     {
         std::vector<int> lv;
+        static const int ext_on = []() { const char* e = getenv("MPQR_EXT_LOOKAHEAD"); return e ? atoi(e) : 1; }();
+        static const int ext_leaves = []() { const char* e = getenv("MPQR_EXT_LEAVES"); return e ? std::max(1, atoi(e)) : 2; }();
         for (size_t t = 0; t < nt; t++) {
-            int fl = h->tops[t];
-            while (h->nodes[fl].left >= 0) fl = h->nodes[fl].left;
-            cfirst[t] = h->nodes[fl].c1;
-            static const int ext_on = []() { const char* e = getenv("MPQR_EXT_LOOKAHEAD"); return e ? atoi(e) : 1; }();
-            ext[t] = la && ext_on && h->tq_on && t + 1 < nt && flat_block_ok(h, h->tops[t], lv);
+            flat[t] = flat_block_ok(h, h->tops[t], lv);
+            ext[t] = la && ext_on && h->tq_on && t + 1 < nt && flat[t];
+        }
+        for (size_t t = 0; t < nt; t++) {
+            std::vector<int> leaves_t;
+            collect_leaves(h, h->tops[t], leaves_t);
+            npre[t] = (t > 0 && ext[t - 1] && flat[t]) ? std::min<int>(ext_leaves, (int)leaves_t.size()) : 1;
+            cfirst[t] = h->nodes[leaves_t[npre[t] - 1]].c1;
         }
     }
     std::vector<int> lvtmp;
@@ -1392,35 +1442,10 @@ static int run_block_loop(mpqr_handle_t h, std::vector<int>& flags, int start = 
     static const int fp_env = []() { const char* e = getenv("MPQR_FAR_PAIR"); return e ? atoi(e) : 1; }();
     const bool far_pair = la && fp_env && h->opts.precision == MPQR_PREC_FP16 && h->opts.form_q && h->S2 && h->qroot < 0;
     bool deferred = false, pair_merged = false;
-    for (size_t t = (size_t)start; t < nt; t++) {
+    int pending_far = -1;                                   // block whose far update waits for the next block's first leaf
+    auto far_update = [&](size_t t) -> int {
         const Node nd = h->nodes[h->tops[t]];
-        if (la && t > 0) {
-            if (!ext[t - 1]) HIPCHK(h, hipStreamWaitEvent(h->s0, h->ev_cols[t], 0));
-            h->wait_after_first_leaf = h->ev_cols2[t];
-        }
-        h->ext_c1 = ext[t] ? cfirst[t + 1] : 0;
-        const bool timed = h->chain_used + 2 <= h->chain_ev.size();
-        if (timed) HIPCHK(h, hipEventRecord(h->chain_ev[h->chain_used], h->s0));
-        rc = factor_node(h, h->tops[t], true);
-        h->ext_c1 = 0;
-        if (rc == MPQR_ABORT_PASS) {          // a leaf of this pass is flagged: nothing enqueued from here on would be kept
-            aborted = true;
-            h->wait_after_first_leaf = nullptr; h->op1_stream = nullptr;
-            break;
-        }
-        if (rc) { h->defer_join = false; h->watch_flags = false; return rc; }
-        if (h->wait_after_first_leaf) {       // (no leaf launched: cannot happen, but never leave the wait pending)
-            HIPCHK(h, hipStreamWaitEvent(h->s0, h->wait_after_first_leaf, 0));
-            h->wait_after_first_leaf = nullptr;
-        }
-        if (timed) { HIPCHK(h, hipEventRecord(h->chain_ev[h->chain_used + 1], h->s0)); h->chain_used += 2; }
         Range rg("mpqr:far_update");
-        if (!la) {
-            apply_node(h, nd, h->dA, h->lda, nd.c1, h->n, true, h->a_scale, true, 0, true);
-            if (h->opts.form_q && h->qpair[t] >= 0 && h->S2) merge_pair(h, h->qpair[t], h->s0);
-            if (h->opts.form_q && h->qroot >= 0) for (int id : h->qmerge_after[t]) merge_prefix(h, id, h->s0);
-            continue;
-        }
         h->at_read = t >= 1 && !(start > 0 && (int)t == start);   // far update t-1 wrote the shadow of every column this one reads (not after a restart)
         HIPCHK(h, hipEventRecord(h->ev_node[t], h->node_done_stream ? h->node_done_stream : h->s0));
         HIPCHK(h, hipStreamWaitEvent(h->s1, h->ev_node[t], 0));
@@ -1453,8 +1478,49 @@ static int run_block_loop(mpqr_handle_t h, std::vector<int>& flags, int start = 
         if (h->opts.form_q && h->qpair[t] >= 0 && h->S2 && !pair_merged) merge_pair(h, h->qpair[t], h->s1);
         pair_merged = false;
         if (h->opts.form_q && h->qroot >= 0) for (int id : h->qmerge_after[t]) merge_prefix(h, id, h->s1);   // ... or the T of all blocks so far
+        return MPQR_OK;
+    };
+    for (size_t t = (size_t)start; t < nt; t++) {
+        const Node nd = h->nodes[h->tops[t]];
+        if (la && t > 0) {
+            if (!ext[t - 1]) HIPCHK(h, hipStreamWaitEvent(h->s0, h->ev_cols[t], 0));
+            h->wait_after_first_leaf = h->ev_cols2[t];
+        }
+        h->ext_c1 = ext[t] ? cfirst[t + 1] : 0;
+        h->pre_leaves = (la && t > (size_t)start) ? npre[t] : 0;    // (the first block of a pass finds all of its columns up to date)
+        const bool timed = h->chain_used + 2 <= h->chain_ev.size();
+        if (timed) HIPCHK(h, hipEventRecord(h->chain_ev[h->chain_used], h->s0));
+        if (pending_far >= 0) { const size_t tp = (size_t)pending_far; pending_far = -1; h->far_hook = [&far_update, tp]() { return far_update(tp); }; }
+        rc = factor_node(h, h->tops[t], true);
+        h->ext_c1 = 0;
+        if (rc == MPQR_ABORT_PASS) {          // a leaf of this pass is flagged: nothing enqueued from here on would be kept
+            aborted = true;
+            h->wait_after_first_leaf = nullptr; h->op1_stream = nullptr; h->far_hook = nullptr;
+            break;
+        }
+        if (!rc && h->far_hook) { auto fh = std::move(h->far_hook); h->far_hook = nullptr; rc = fh(); }   // (no Gram-Householder leaf took it)
+        h->far_hook = nullptr;
+        if (rc) { h->defer_join = false; h->watch_flags = false; return rc; }
+        if (h->wait_after_first_leaf) {       // (no leaf launched: cannot happen, but never leave the wait pending)
+            HIPCHK(h, hipStreamWaitEvent(h->s0, h->wait_after_first_leaf, 0));
+            h->wait_after_first_leaf = nullptr;
+        }
+        if (timed) { HIPCHK(h, hipEventRecord(h->chain_ev[h->chain_used + 1], h->s0)); h->chain_used += 2; }
+        if (!la) {
+            apply_node(h, nd, h->dA, h->lda, nd.c1, h->n, true, h->a_scale, true, 0, true);
+            if (h->opts.form_q && h->qpair[t] >= 0 && h->S2) merge_pair(h, h->qpair[t], h->s0);
+            if (h->opts.form_q && h->qroot >= 0) for (int id : h->qmerge_after[t]) merge_prefix(h, id, h->s0);
+            continue;
+        }
+        // look-ahead: the far update of block t.  When the chain runs on into the next block (ext[t]) it is enqueued from inside that
+        // block's first leaf, behind its gh_gram (factor_block_flat, far_hook): ev_node[t] is then recorded on the chain stream
+        // behind that launch, the far stream's first GEMMs start together with the leaf's gh_solve and fill the CUs the solve
+        // leaves idle, instead of taking every CU while gh_gram (139 KB of LDS per workgroup: whole CUs) wants them.
+        static const int defer_env = []() { const char* e = getenv("MPQR_DEFER_FAR"); return e ? atoi(e) : 1; }();
+        if (defer_env && ext[t] && t + 1 < nt && flat[t + 1]) { pending_far = (int)t; continue; }   // (a flat block takes the hook in its first leaf)
+        if ((rc = far_update(t))) { h->defer_join = false; h->watch_flags = false; return rc; }
     }
-    h->watch_flags = false; h->pass_aborted = aborted;
+    h->watch_flags = false; h->pass_aborted = aborted; h->pre_leaves = 0;
     h->pairs_ready = !aborted && h->opts.form_q && h->S2 != nullptr;     // (pairs or the whole tree)
     if (h->defer_join) {                                    // the T stream's work of every block, once
         h->defer_join = false;
@@ -1568,6 +1634,12 @@ int mpqr_get_timings(mpqr_handle_t h, mpqr_timings* t) {
         float x = 0;
         HIPCHK(h, hipEventElapsedTime(&x, h->chain_ev[i], h->chain_ev[i + 1]));
         ch += x;
+        static const int dbg_blocks = []() { const char* e = getenv("MPQR_DBG_BLOCKS"); return e ? atoi(e) : 0; }();
+        if (dbg_blocks) {                                  // measurement aid: chain time of every top-level block + the gap before the next one
+            float gap = 0;
+            if (i + 2 < h->chain_used) (void)hipEventElapsedTime(&gap, h->chain_ev[i + 1], h->chain_ev[i + 2]);
+            fprintf(stderr, "mpqr: block %2zu chain %8.1f us, then %6.1f us before the next block\n", i / 2, x * 1e3f, gap * 1e3f);
+        }
     }
     t->ms_panel = ch;
     t->ms_chain_wait = t->ms_factor - ch;

@@ -9,7 +9,9 @@ rocprofv3 --kernel-trace --stats -d $out/ks -o c4 --output-format csv -- python3
 cd $root
 KT=$(find $out/ks -name "c4_kernel_trace.csv" | head -1)
 cp $(find $out/ks -name "c4_kernel_stats.csv" | head -1) $out/${tag}_c4_kernel_stats.csv
-python3 tools/trace_leaf.py $KT 60 61 64 > $out/${tag}_c4_leaf_timeline.txt
+python3 tools/trace_leaf.py $KT 60 61 63 64 65 > $out/${tag}_c4_leaf_timeline.txt
 python3 tools/trace_gaps.py $KT > $out/${tag}_c4_stream_gaps.txt
+python3 tools/trace_chain.py $KT > $out/${tag}_c4_chain.txt
+gzip -c $KT > $out/${tag}_c4_kernel_trace.csv.gz
 rm -rf $out/ks
 cat $out/${tag}_c4_leaf_timeline.txt
