@@ -100,7 +100,7 @@ struct mpqr_handle_s {
     float* vdiag = nullptr;
     float* Xt = nullptr;   size_t xt_elems = 0;
     half_t* Yt = nullptr;  size_t yt_elems = 0;
-    float* Xt1 = nullptr;  half_t* Yt1 = nullptr;      // scratch of the far-update stream (look-ahead)
+    float* Xt1 = nullptr;  half_t* Yt1 = nullptr; size_t xt1_elems = 0;     // scratch of the far-update stream (look-ahead)
     float* Xt2 = nullptr;  half_t* Yt2 = nullptr; size_t xt2_elems = 0;   // scratch of the deferred in-block updates (apply_node lane 2, T stream)
     int pre_leaves = 0;                 // flat block: its first pre_leaves leaves were brought up to date by the previous block (run_block_loop)
     hipEvent_t ev_def = nullptr;        // chain -> T stream: a pre-updated leaf's reflectors and T are complete (deferred update may start)
@@ -288,6 +288,10 @@ static long gemm2_min_tiles() {
     static const long v = []() { const char* e = getenv("MPQR_GEMM2_MIN_TILES"); return e ? atol(e) : 48L; }();
     return v;
 }
+static int far_tn_split() {   // tuning hook, see apply_node
+    static const int v = []() { const char* e = getenv("MPQR_FAR_TN_SPLIT"); return e ? atoi(e) : 0; }();
+    return v;
+}
 // set when a GEMM found no kernel: mpqr_factor / form_q report it instead of returning garbage
 static std::atomic<int> g_dispatch_error{0};
 void gemm_dispatch(AMode am, EMode em, const GemmArgs& g, hipStream_t s) {
@@ -396,6 +400,14 @@ void apply_node(mpqr_handle_t h, const Node& nd, float* C, long ldc, int clo, in
     g1.in_scale = in_scale; g1.alpha = 1.f;
     const long slab = (long)M1 * Kr;
     g1.nsplit = choose_split(M1, Kr, Kw, lane == 2 ? h->xt2_elems : h->xt_elems, slab);
+    // big far updates: X = C2^T V runs K = all rows per workgroup (256 x 256 tiles: ~500 us per workgroup at 16384 rows), and while
+    // those workgroups sit on every CU the chain's own GEMMs wait for them.  MPQR_FAR_TN_SPLIT=n splits K over n slabs (fp32, summed
+    // by slab_reduce): n times shorter workgroups for n x (M1 x Kr x 4 B) of slab traffic
+    if (far && lane == 1 && far_tn_split() > 1 && g1.nsplit == 1 && (long)(M1 / 256) * (Kr / 256) >= gemm2_min_tiles() && Kw >= 4096) {
+        int ns = std::min(far_tn_split(), Kw / 2048);
+        while (ns > 1 && (size_t)ns * (size_t)slab > h->xt1_elems) ns--;
+        g1.nsplit = std::max(ns, 1);
+    }
     g1.slab_out_stride = slab;
     if (record) (void)hipEventRecord(e0, st);
     hipStream_t st1 = (h->op1_stream && lane == 0) ? h->op1_stream : st;     // flat schedule: X on the side stream, T on the chain
@@ -1233,9 +1245,10 @@ static int plan_common(mpqr_handle_t h, int m, int n, int r, const mpqr_opts* op
     HIPCHK(h, hipMemsetAsync(h->Xt, 0, (h->xt_elems + (size_t)256 * x_ldt) * sizeof(float), h->s0));
     HIPCHK(h, hipMemsetAsync(h->Yt, 0, (h->yt_elems + (size_t)256 * x_ldt) * sizeof(half_t), h->s0));
     if (o.lookahead && o.precision != MPQR_PREC_FP32) {
-        if ((rc = dalloc(h, &h->Xt1, h->xt_elems + (size_t)256 * x_ldt))) return rc;
+        h->xt1_elems = h->xt_elems * (size_t)std::max(1, far_tn_split());
+        if ((rc = dalloc(h, &h->Xt1, h->xt1_elems + (size_t)256 * x_ldt))) return rc;
         if ((rc = dalloc(h, &h->Yt1, h->yt_elems + (size_t)256 * x_ldt))) return rc;
-        HIPCHK(h, hipMemsetAsync(h->Xt1, 0, (h->xt_elems + (size_t)256 * x_ldt) * sizeof(float), h->s0));
+        HIPCHK(h, hipMemsetAsync(h->Xt1, 0, (h->xt1_elems + (size_t)256 * x_ldt) * sizeof(float), h->s0));
         HIPCHK(h, hipMemsetAsync(h->Yt1, 0, (h->yt_elems + (size_t)256 * x_ldt) * sizeof(half_t), h->s0));
         {   // one leaf (128 reflectors) onto at most a block's columns + the next block's pre-updated leaves, <= 32 split-K slabs
             int wmax = 0;
@@ -1619,6 +1632,9 @@ int mpqr_get_timings(mpqr_handle_t h, mpqr_timings* t) {
             continue;
         }
         if (i / 4 < h->far_bytes.size()) t->gbytes_far_nn += h->far_bytes[i / 4] * 1e-9;
+        static const int dbg_far = []() { const char* e = getenv("MPQR_DBG_BLOCKS"); return e ? atoi(e) : 0; }();
+        if (dbg_far) fprintf(stderr, "mpqr: far update %2zu: %7.1f GFLOP per GEMM, tn %7.1f us (%6.0f TFLOP/s), nn %7.1f us (%6.0f TFLOP/s), whole %7.1f us\n",
+                             i / 4, h->far_flops[i / 4] * 1e-9, a * 1e3f, h->far_flops[i / 4] / (a * 1e9), b * 1e3f, h->far_flops[i / 4] / (b * 1e9), x * 1e3f);
         t->ms_far_tn += a; t->ms_far_nn += b; tr += x;
         f += h->far_flops[i / 4];
         t->n_far_launches++;

@@ -6,4 +6,4 @@ for l in open("gpurun_out/r3/exp_$tag.json"):
         d=json.loads(l); b=d["breakdown_ms"]; print("$tag", round(d["ms_per_step"],2), "factor", round(b["ms_factor"],2), "panel", round(b["ms_panel"],2), "formq", round(b["ms_form_q"],2), "far tn/nn", round(b["ms_far_tn"],2), round(b["ms_far_nn"],2), "passes", b["n_passes"], "err", d["error"]["backward_error"], d["error"]["q_error_fro"])
 PY
 }
-run ext2 A=1 && run ext1 MPQR_EXT_LEAVES=1 && run ext2_nodefer MPQR_DEFER_FAR=0 && run ext3 MPQR_EXT_LEAVES=3
+run base A=1 && run tns4 MPQR_FAR_TN_SPLIT=4 && run tns8 MPQR_FAR_TN_SPLIT=8 && run tns2 MPQR_FAR_TN_SPLIT=2

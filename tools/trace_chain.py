@@ -8,10 +8,8 @@ rows = list(csv.DictReader(open(sys.argv[1])))
 for r in rows:
     r['s'] = int(r['Start_Timestamp']); r['e'] = int(r['End_Timestamp'])
 rows.sort(key=lambda r: r['s'])
-gen = [i for i, r in enumerate(rows) if 'generate_kernel' in r['Kernel_Name']]
-lo = gen[-1]
-hi = next((i for i in range(lo, len(rows)) if 'lower_norm' in rows[i]['Kernel_Name'] or 'strip_r' in rows[i]['Kernel_Name']), len(rows))
-run = rows[lo + 1:hi]
+ab = [i for i, r in enumerate(rows) if 'absmax' in r['Kernel_Name']]          # compute_scale opens every mpqr_factor
+run = rows[ab[-1]:]
 def short(n):
     n = re.sub(r'^void ', '', n); n = n.replace('mpqr::', ''); n = re.sub(r'^_ZN4mpqr\d+', '', n)
     n = re.sub(r'\(.*', '', n); n = re.sub(r'EP[KfD].*', '', n)
@@ -40,8 +38,12 @@ print("%-30s %6s %9s %9s %9s" % ("kernel", "calls", "busy ms", "idle ms", "avg i
 for n in sorted(busy, key=lambda k: -(busy[k] + gap[k])):
     print("%-30s %6d %9.2f %9.2f %9.1f" % (n, cnt[n], busy[n] / 1e3, gap[n] / 1e3, gap[n] / cnt[n]))
 print("total busy %.2f ms, idle %.2f ms" % (sum(busy.values()) / 1e3, sum(gap.values()) / 1e3))
-nl = (leaf + 1) / 8
-print("per leaf by position in block (busy / idle us):", ["%.0f/%.0f" % (pos_busy[k] / nl, pos_gap[k] / nl) for k in range(8)])
+grams = [r for r in chain if 'gh_gram' in r['Kernel_Name']]
+per = [(b['s'] - a['s']) / 1e3 for a, b in zip(grams, grams[1:])]
+print("leaf periods (gh_gram to gh_gram, us) per top-level block of 8 leaves:")
+for blk in range(0, (len(per) + 7) // 8):
+    p8 = per[8 * blk:8 * blk + 8]
+    print("  block %2d: %s  sum %.0f" % (blk, " ".join("%4.0f" % x for x in p8), sum(p8)))
 print("idle stretches > 25 us: %d, total %.2f ms" % (len(gaps), sum(g[0] for g in gaps) / 1e3))
 for g, lf, n, a, b in sorted(gaps, reverse=True)[:6]:
     print(f"--- {g:.0f} us idle before {n} of leaf {lf} (position {lf % 8}); other queues meanwhile:")
