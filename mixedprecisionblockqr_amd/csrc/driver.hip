@@ -62,6 +62,7 @@ struct mpqr_handle_s {
     hipStream_t s0 = nullptr;   // panel chain (high priority)
     hipStream_t s1 = nullptr;   // far trailing updates / Q formation when opts.lookahead (low priority)
     hipStream_t sT = nullptr;   // compact-WY T construction (leaf T, merges): runs beside the chain's next V-only GEMM
+    hipStream_t sD = nullptr;   // the drop-in call's read-back of R / V, beside Q formation (created on first use)
     std::vector<hipEvent_t> ev_T;     // per node: T of that node is complete (recorded on sT)
     hipEvent_t ev_v = nullptr, ev_join = nullptr;   // chain -> T stream (reflectors written), T stream -> chain (join)
     hipEvent_t wait_after_first_leaf = nullptr;     // look-ahead: the rest of the block's columns become valid with this event
@@ -1092,6 +1093,7 @@ int mpqr_destroy(mpqr_handle_t h) {
     for (hipEvent_t e : h->ev_T) (void)hipEventDestroy(e);
     if (h->ev_v) (void)hipEventDestroy(h->ev_v);
     if (h->ev_join) (void)hipEventDestroy(h->ev_join);
+    if (h->sD) (void)hipStreamDestroy(h->sD);
     if (h->ev_x) (void)hipEventDestroy(h->ev_x);
     if (h->ev_def) (void)hipEventDestroy(h->ev_def);
     if (h->ev_dist_chain) (void)hipEventDestroy(h->ev_dist_chain);
@@ -1907,9 +1909,17 @@ int mpqr_block_qr_f32(mpqr_handle_t h, float* A, float* Q, int m, int n, int r, 
     if ((rc = mpqr_plan(h, m, n, r, &o))) return rc;
     if ((rc = mpqr_set_matrix_host(h, A, n))) return rc;
     if ((rc = mpqr_factor(h))) return rc;
-    if ((rc = mpqr_get_factor_host(h, A))) return rc;
-    if (o.form_q && (rc = mpqr_get_q_host(h, Q))) return rc;
-    return MPQR_OK;
+    if (!o.form_q) return mpqr_get_factor_host(h, A);
+    // mpqr_factor has enqueued Q formation and returned: R and the reflectors are final since the event behind the block loop, so
+    // their read-back (1 GB at 16384^2, ~19 ms of PCIe) runs on a stream of its own beside Q formation (~9 ms) instead of after it
+    if (!h->sD) HIPCHK(h, hipStreamCreateWithFlags(&h->sD, hipStreamNonBlocking));
+    const size_t el = (size_t)(h->m + 1) * h->n;
+    if ((rc = ensure_stage(h, el))) return rc;
+    HIPCHK(h, hipStreamWaitEvent(h->sD, h->ev[1], 0));
+    launch_pack_factor(h->dA, h->lda, h->vdiag, h->dstage, h->m, h->n, h->sD);
+    HIPCHK(h, hipMemcpyAsync(A, h->dstage, el * sizeof(float), hipMemcpyDeviceToHost, h->sD));
+    HIPCHK(h, hipStreamSynchronize(h->sD));
+    return mpqr_get_q_host(h, Q);
 }
 
 static int default_handle(mpqr_handle_t* out) {
