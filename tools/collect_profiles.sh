@@ -2,7 +2,7 @@
 # Collects everything profiles/ holds for one round, on the GPU box:  bash tools/collect_profiles.sh <tag>
 # (kernel stats, stream gaps, HBM counters in two separate PMC passes, SQ stall counters, L2 hit rates, bench lines).
 # Outputs: gpurun_out/final/ ; copy what is to be judged into profiles/.
-tag=${1:-r02}
+tag=${1:-r03}
 root=${GRAFT_REPO_ROOT:-/root/repo}
 out=$root/gpurun_out/final
 mkdir -p $out
@@ -16,7 +16,8 @@ bash tools/pmc_l2.sh $tag > $out/${tag}_c4_l2_hit.txt 2>&1 && echo "l2 ok"
 cp $(find $out/ks -name "c4_kernel_stats.csv" | head -1) $out/${tag}_c4_kernel_stats.csv
 KT=$(find $out/ks -name "c4_kernel_trace.csv" | head -1)
 python3 tools/trace_gaps.py $KT > $out/${tag}_c4_stream_gaps.txt
-python3 tools/trace_leaf.py $KT 60 61 64 > $out/${tag}_c4_leaf_timeline.txt      # steady-state panels and one beside a far update
+python3 tools/trace_leaf.py $KT 60 61 63 64 65 > $out/${tag}_c4_leaf_timeline.txt      # steady-state panels and a block boundary
+python3 tools/trace_chain.py $KT > $out/${tag}_c4_chain.txt                          # chain queue: busy / idle per kernel, leaf periods per block
 python3 tools/trace_qphase.py $KT > $out/${tag}_c4_q_phase.txt
 F=$(find $out/fetch -name "c4_counter_collection.csv" | head -1); W=$(find $out/write -name "c4_counter_collection.csv" | head -1)
 grep -E "Kernel_Name|gemm6_f16|gemm2_f16" $F > $out/${tag}_c4_pmc_FETCH_SIZE_gemm.csv
@@ -30,6 +31,8 @@ python3 bench.py --config c3 --no-cpu-baseline > $out/${tag}_c3_bench.json 2> $o
 python3 bench.py --config c5 --no-cpu-baseline --steps 3 --warmup 1 > $out/${tag}_c5_bench.json 2> $out/bench_c5.err && echo "bench c5 (fp8) ok"
 python3 bench.py --config c5 --precision fp16 --no-cpu-baseline --steps 3 --warmup 1 > $out/${tag}_c5_fp16_bench.json 2> $out/bench_c5b.err && echo "bench c5 (fp16) ok"
 MPQR_FORCE_DIST=1 python3 bench.py --no-cpu-baseline > $out/${tag}_c4_forced_dist_n1_bench.json 2> $out/bench_dist.err && echo "bench forced dist ok"
+python3 -m pytest tests/test_gpu_parity.py -q -m gpu -s -k "rank_deficient or flagged" 2>&1 | grep -E "ratio|passed|failed" > $out/${tag}_restart_cost.txt && echo "restart cost ok"
+MPQR_DBG_BLOCKS=1 python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-dropin 2>&1 | grep "mpqr:" > $out/${tag}_c4_blocks_unprofiled.txt && echo "blocks ok"
 python3 tools/precision_study.py $out/${tag}_precision_study.md > /dev/null 2>&1 && echo "precision study ok"
 rm -rf $out/ks $out/fetch $out/write
 ls -la $out

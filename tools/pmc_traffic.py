@@ -19,10 +19,14 @@ def per_launch(path, counter, needle, big_only=False):
     solve = [r for r in rows if "gh_solve" in r["Kernel_Name"]]
     chain_q = solve[0]["Queue_Id"] if solve else None
     last_solve = max(int(r["Dispatch_Id"]) for r in solve) if solve else -1
+    tcol = [r for r in rows if "t_colblock_h16" in r["Kernel_Name"]]      # the T stream (round 3: it also runs the deferred in-block updates)
+    t_q = tcol[0]["Queue_Id"] if tcol else None
     vals = []
     for row in rows:
         if needle in row["Kernel_Name"] and row["Counter_Name"] == counter:
             if big_only and chain_q is not None and row["Queue_Id"] == chain_q and int(row["Dispatch_Id"]) < last_solve:
+                continue
+            if big_only and t_q is not None and t_q != chain_q and row["Queue_Id"] == t_q:
                 continue
             vals.append(float(row["Counter_Value"]))
     return vals

@@ -6,12 +6,11 @@ rows = list(csv.DictReader(open(sys.argv[1])))
 for r in rows:
     r['s'] = int(r['Start_Timestamp']); r['e'] = int(r['End_Timestamp'])
 rows.sort(key=lambda r: r['s'])
-gen = [i for i, r in enumerate(rows) if 'generate_kernel' in r['Kernel_Name']]
-lo = gen[-1]
-hi = next((i for i in range(lo, len(rows)) if 'lower_norm' in rows[i]['Kernel_Name'] or 'strip_r' in rows[i]['Kernel_Name']), len(rows))
-run = rows[lo + 1:hi]
-last = max(i for i, r in enumerate(run) if 'gh_solve' in r['Kernel_Name'] or 'leaf_wg' in r['Kernel_Name'])
-ident = next(i for i in range(last, len(run)) if 'identity' in run[i]['Kernel_Name'])
+ab = [i for i, r in enumerate(rows) if 'absmax' in r['Kernel_Name']]          # compute_scale opens every mpqr_factor
+lo = ab[-1]
+hi = next((i for i in range(lo, len(rows)) if 'lower_norm' in rows[i]['Kernel_Name'] or 'strip_r' in rows[i]['Kernel_Name'] or 'pack_factor' in rows[i]['Kernel_Name']), len(rows))
+run = rows[lo:hi]
+ident = next(i for i, r in enumerate(run) if 'identity' in r['Kernel_Name'])
 q = run[ident:]
 t0, t1 = q[0]['s'], max(r['e'] for r in q)
 print("Q phase %.2f ms, %d dispatches" % ((t1 - t0) / 1e6, len(q)))
