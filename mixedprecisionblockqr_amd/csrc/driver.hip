@@ -708,8 +708,19 @@ int factor_block_flat(mpqr_handle_t h, int top, const std::vector<int>& leaves) 
         s2.A = h->Tf + tp.toff; s2.lda = ld; s2.transA = 0; s2.nslab_a = 1;
         s2.B = h->tmp1; s2.ldb = lf.ldt; s2.transB = 0;
         s2.C = h->Tf + tp.toff + o; s2.ldc = ld; s2.M = o; s2.N = lf.ldt; s2.K = o; s2.alpha = -1.f; s2.beta = 0.f; s2.upperA = 1;
-        launch_sgemm(s2, st);
-        launch_t_colblock_h16(h->Tf + tp.toff, h->Th + tp.toff, h->Tth + tp.toff, ld, o, o, lf.ldt, st);
+        // K = o (up to 896) in one workgroup per 64 x 64 tile is a 70 us latency chain of 56 load / barrier / MFMA steps, and the
+        // last leaf's column block sits on the path to the block's far update: K is cut into ranges of 128, the partial products
+        // (S is free again: tmp1 = S T_j has been formed) are summed by t_colblock_h16 on its way to the fp16 copies
+        static const int ks_env = []() { const char* e = getenv("MPQR_TCOL_KSPLIT"); return e ? atoi(e) : 1; }();
+        const int nz = ks_env ? std::min(8, o / 128) : 1;
+        if (nz > 1 && (size_t)nz * o * lf.ldt <= h->s_elems) {
+            s2.C = h->S; s2.ldc = lf.ldt; s2.ksplit = nz; s2.slab_c = (long)o * lf.ldt;
+            launch_sgemm(s2, st);
+            launch_t_colblock_h16(h->Tf + tp.toff, h->Th + tp.toff, h->Tth + tp.toff, ld, o, o, lf.ldt, st, h->S, nz, s2.slab_c, lf.ldt);
+        } else {
+            launch_sgemm(s2, st);
+            launch_t_colblock_h16(h->Tf + tp.toff, h->Th + tp.toff, h->Tth + tp.toff, ld, o, o, lf.ldt, st);
+        }
     };
     Node prev{}; int prev_o = -1;                         // leaf whose column block of T is still to be built
     for (size_t j = 0; j < leaves.size(); j++) {

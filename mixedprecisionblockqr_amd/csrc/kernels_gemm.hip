@@ -242,6 +242,12 @@ __global__ __launch_bounds__(256) void sgemm_mfma_kernel(SgemmArgs g) {
     int k_lo = 0, k_hi = g.K;
     if (g.upperA) k_lo = (bm / SK) * SK;                  // op(A)[i][k] = 0 for k < i
     if (g.upperB) k_hi = min(g.K, bn + TB);               // op(B)[k][j] = 0 for k > j
+    float* Cz = g.C;
+    if (g.ksplit > 1) {                                   // split K: this workgroup's range and its own output slab
+        const int per = ((g.K + g.ksplit - 1) / g.ksplit + SK - 1) / SK * SK;
+        k_lo = max(k_lo, (int)blockIdx.z * per); k_hi = min(k_hi, ((int)blockIdx.z + 1) * per);
+        Cz += (long)blockIdx.z * g.slab_c;
+    }
 
     const bool a_vec = ((g.lda & 3) == 0) && ((((uintptr_t)g.A) & 15) == 0) && ((g.slab_a & 3) == 0);
     const bool b_vec = ((g.ldb & 3) == 0) && ((((uintptr_t)g.B) & 15) == 0);
@@ -345,9 +351,9 @@ __global__ __launch_bounds__(256) void sgemm_mfma_kernel(SgemmArgs g) {
             for (int e = 0; e < 16; e++) {
                 const int m = bm + wm + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
                 if (m < g.M && n < g.N) {
-                    float* p = g.C + (long)m * g.ldc + n;
+                    float* p = Cz + (long)m * g.ldc + n;
                     float v = g.alpha * acc[i][j][e];
-                    if (g.beta != 0.f) v += g.beta * (*p);
+                    if (g.beta != 0.f && g.ksplit <= 1) v += g.beta * (*p);
                     *p = v;
                 }
             }
@@ -359,11 +365,12 @@ void launch_sgemm(const SgemmArgs& g, hipStream_t s) {
     SgemmArgs a = g;
     if (a.nslab_a < 1) a.nslab_a = 1;
     const long tiles128 = (long)((g.M + 127) / 128) * ((g.N + 127) / 128);
+    if (a.ksplit < 1) a.ksplit = 1;
     if (tiles128 >= 256) {
-        dim3 grid((g.N + 127) / 128, (g.M + 127) / 128);
+        dim3 grid((g.N + 127) / 128, (g.M + 127) / 128, a.ksplit);
         hipLaunchKernelGGL(sgemm_mfma_kernel<128>, grid, dim3(256), 0, s, a);
     } else {
-        dim3 grid((g.N + 63) / 64, (g.M + 63) / 64);
+        dim3 grid((g.N + 63) / 64, (g.M + 63) / 64, a.ksplit);
         hipLaunchKernelGGL(sgemm_mfma_kernel<64>, grid, dim3(256), 0, s, a);
     }
 }

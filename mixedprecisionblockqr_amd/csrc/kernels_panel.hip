@@ -1134,8 +1134,11 @@ void launch_t_leaf(const float* S, int nslab, long slab_stride, int lds_, int a0
 }
 
 // fp16 copies of one column block of a block-level T: Th[0:rows, c:c+w] = T[0:rows, c:c+w], Tth[c:c+w, 0:rows] = its transpose
-__global__ __launch_bounds__(256) void t_colblock_h16_kernel(const float* __restrict__ T, half_t* __restrict__ Th,
-                                                             half_t* __restrict__ Tth, int ld, int rows, int c, int w) {
+// P != nullptr: the column block itself arrives as nz partial sums (slabs of `slab` floats, row stride ldp: a split-K product);
+// they are summed here and written to T first
+__global__ __launch_bounds__(256) void t_colblock_h16_kernel(float* __restrict__ T, half_t* __restrict__ Th,
+                                                             half_t* __restrict__ Tth, int ld, int rows, int c, int w,
+                                                             const float* __restrict__ P, int nz, long slab, int ldp) {
     __shared__ float tile[32][33];
     const int i0 = blockIdx.y * 32, j0 = blockIdx.x * 32;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;          // 32 x 8
@@ -1144,7 +1147,10 @@ __global__ __launch_bounds__(256) void t_colblock_h16_kernel(const float* __rest
         const int i = i0 + ty + 8 * q, j = j0 + tx;
         float v = 0.f;
         if (i < rows && j < w) {
-            v = T[(long)i * ld + c + j];
+            if (P) {
+                for (int z = 0; z < nz; z++) v += P[(long)z * slab + (long)i * ldp + j];
+                T[(long)i * ld + c + j] = v;
+            } else v = T[(long)i * ld + c + j];
             const float tii = T[(long)i * ld + i];                      // tau_i: the fp16 copies carry row n / tau_n
             Th[(long)i * ld + c + j] = (half_t)(tii != 0.f ? v / tii : 0.f);
         }
@@ -1160,9 +1166,11 @@ __global__ __launch_bounds__(256) void t_colblock_h16_kernel(const float* __rest
         }
     }
 }
-void launch_t_colblock_h16(const float* T, half_t* Th, half_t* Tth, int ld, int rows, int c, int w, hipStream_t s) {
+void launch_t_colblock_h16(float* T, half_t* Th, half_t* Tth, int ld, int rows, int c, int w, hipStream_t s,
+                           const float* P, int nz, long slab, int ldp) {
     if (rows <= 0 || w <= 0) return;
-    hipLaunchKernelGGL(t_colblock_h16_kernel, dim3((w + 31) / 32, (rows + 31) / 32), dim3(256), 0, s, T, Th, Tth, ld, rows, c, w);
+    hipLaunchKernelGGL(t_colblock_h16_kernel, dim3((w + 31) / 32, (rows + 31) / 32), dim3(256), 0, s, T, Th, Tth, ld, rows, c, w,
+                       P, nz, slab, ldp);
 }
 
 // parent T = [[T_L, T_LR], [0, T_R]] placed inside the parent's 64-aligned reflector range

@@ -78,6 +78,7 @@ struct SgemmArgs {
     float alpha, beta;
     int nslab_a; long slab_a;
     int upperA, upperB;   // operand is upper triangular (op(A)[i][k]=0 for k<i / op(B)[k][j]=0 for k>j): zero K tiles skipped
+    int ksplit; long slab_c;   // ksplit > 1: K is cut into ksplit ranges (blockIdx.z), range z writes alpha * its partial product to C + z * slab_c (beta ignored)
 };
 void launch_sgemm(const SgemmArgs& g, hipStream_t s);
 
@@ -119,7 +120,8 @@ void launch_gh_reduce_f32(const float* Sp, int nslab, float* S, hipStream_t s);
 void launch_t_leaf(const float* S, int nslab, long slab_stride, int lds_, int a0, int c0, int c1,
                    float* T, half_t* Th, half_t* Tth, int ldt, hipStream_t s, int ld = 0);
 // fp16 copies (plain and transposed) of column block [c, c+w) x rows [0, rows) of a T with leading dimension ld
-void launch_t_colblock_h16(const float* T, half_t* Th, half_t* Tth, int ld, int rows, int c, int w, hipStream_t s);
+void launch_t_colblock_h16(float* T, half_t* Th, half_t* Tth, int ld, int rows, int c, int w, hipStream_t s,
+                           const float* P = nullptr, int nz = 0, long slab = 0, int ldp = 0);   // P: split-K partials of the column block, summed into T first
 // assemble a parent T from its children and T_LR
 // one diagonal block of the back substitution R X = Y (in place in Y), kb <= 128
 void launch_trsm_diag(const float* R, long ldr, int k0, int kb, float* Y, long ldy, int nrhs, hipStream_t s);
