@@ -146,7 +146,7 @@ struct mpqr_handle_s {
     std::vector<std::vector<int>> qmerge_after;   // per top index t: prefix nodes that can be completed once block t is factored
     half_t* Wh = nullptr;                         // W = V T, fp16 [row][reflector]
     size_t q_first = (size_t)-1;  // first far_ev slot used by Q formation (its applies are timed like the far updates)
-    float* S2 = nullptr; size_t s2_elems = 0; float* tmp1b = nullptr; float* tmp2b = nullptr;
+    float* S2 = nullptr; size_t s2_elems = 0; float* tmp1b = nullptr; float* tmp2b = nullptr; size_t tmpb_elems = 0;
     // transposed fp16 shadow of Q, Qt[column][row], kept up to date by the epilogue of Q -= V Y^T: the next X = Q2^T V
     // reads it with LDS-DMA like any fp16 operand (the fp32 operand path converts and transposes in registers: 620 TFLOP/s)
     half_t* Qt = nullptr; long ldqt = 0;
@@ -892,14 +892,22 @@ static void merge_pair(mpqr_handle_t h, int pid, hipStream_t st) {
     s1.A = h->S2; s1.lda = R.ldt; s1.transA = 0; s1.nslab_a = nslab; s1.slab_a = slab;
     s1.B = h->Tf + R.toff; s1.ldb = R.ldt; s1.transB = 0;
     s1.C = h->tmp1b; s1.ldc = R.ldt; s1.M = L.ldt; s1.N = R.ldt; s1.K = R.ldt; s1.alpha = 1.f; s1.beta = 0.f; s1.upperB = 1;
+    // both products are 1024^3 on 256 workgroups whose K loops (64 load / barrier / MFMA steps) take ~85 us each: K is cut into
+    // ranges of 256, the partial slabs are summed by the next consumer's operand staging / by t_assemble (MPQR_TCOL_KSPLIT=0: whole K)
+    static const int ks_env = []() { const char* e = getenv("MPQR_TCOL_KSPLIT"); return e ? atoi(e) : 1; }();
+    const long zs = (long)L.ldt * R.ldt;
+    int nz = ks_env ? std::min(4, std::min(L.ldt, R.ldt) / 256) : 1;
+    if ((size_t)nz * (size_t)zs > h->tmpb_elems) nz = 1;
+    if (nz > 1) { s1.ksplit = nz; s1.slab_c = zs; }
     launch_sgemm(s1, st);
     SgemmArgs s2{};
     s2.A = h->Tf + L.toff; s2.lda = L.ldt; s2.transA = 0; s2.nslab_a = 1;
     s2.B = h->tmp1b; s2.ldb = R.ldt; s2.transB = 0;
     s2.C = h->tmp2b; s2.ldc = R.ldt; s2.M = L.ldt; s2.N = R.ldt; s2.K = L.ldt; s2.alpha = -1.f; s2.beta = 0.f; s2.upperA = 1;
+    if (nz > 1) { s2.nslab_b = nz; s2.slab_b = zs; s2.ksplit = nz; s2.slab_c = zs; }
     launch_sgemm(s2, st);
     launch_t_assemble(h->Tf + nd.toff, h->Th + nd.toff, h->Tth + nd.toff, nd.ldt, nd.a0, h->Tf + L.toff, L.ldt, L.a0,
-                      nd.c0, L.c1, h->Tf + R.toff, R.ldt, R.a0, nd.c1, h->tmp2b, R.ldt, st);
+                      nd.c0, L.c1, h->Tf + R.toff, R.ldt, R.a0, nd.c1, h->tmp2b, R.ldt, st, nz, zs);
     if (h->tq_on && nd.id < (int)h->ev_T.size()) (void)hipEventRecord(h->ev_T[nd.id], st);
 }
 
@@ -1334,7 +1342,8 @@ static int plan_common(mpqr_handle_t h, int m, int n, int r, const mpqr_opts* op
     if (q_ldt || h->qroot >= 0) {                         // scratch of the pair / tree merges (they run on the far-update stream)
         const size_t half = std::max(q_half, (size_t)max_ldt * max_ldt);
         h->s2_elems = std::max((size_t)16 * max_ldt * max_ldt, 2 * half);
-        if ((rc = dalloc(h, &h->S2, h->s2_elems)) || (rc = dalloc(h, &h->tmp1b, half)) || (rc = dalloc(h, &h->tmp2b, half))) return rc;
+        h->tmpb_elems = 4 * half;                          // (up to four split-K slabs of a pair merge's products)
+        if ((rc = dalloc(h, &h->S2, h->s2_elems)) || (rc = dalloc(h, &h->tmp1b, h->tmpb_elems)) || (rc = dalloc(h, &h->tmp2b, h->tmpb_elems))) return rc;
     }
     if (h->qroot >= 0) {
         if ((rc = dalloc(h, &h->Wh, (size_t)(h->m_pad + 256) * h->n_pad))) return rc;

@@ -250,7 +250,8 @@ __global__ __launch_bounds__(256) void sgemm_mfma_kernel(SgemmArgs g) {
     }
 
     const bool a_vec = ((g.lda & 3) == 0) && ((((uintptr_t)g.A) & 15) == 0) && ((g.slab_a & 3) == 0);
-    const bool b_vec = ((g.ldb & 3) == 0) && ((((uintptr_t)g.B) & 15) == 0);
+    const bool b_vec = ((g.ldb & 3) == 0) && ((((uintptr_t)g.B) & 15) == 0) && ((g.slab_b & 3) == 0);
+    const int nsb = g.nslab_b > 1 ? g.nslab_b : 1;
 
     float4 ra[NL], rb[NL];
     // operand element (row index x in [0,TB), k) ; "kcontig": storage [x][k] (k contiguous) else [k][x]
@@ -315,14 +316,14 @@ __global__ __launch_bounds__(256) void sgemm_mfma_kernel(SgemmArgs g) {
     const bool a_kc = !g.transA, b_kc = g.transB;
     if (k_lo < k_hi) {
         load_op(g.A, g.lda, a_kc, bm, g.M, k_lo, a_vec, g.nslab_a, g.slab_a, ra);
-        load_op(g.B, g.ldb, b_kc, bn, g.N, k_lo, b_vec, 1, 0, rb);
+        load_op(g.B, g.ldb, b_kc, bn, g.N, k_lo, b_vec, nsb, g.slab_b, rb);
         store_op(As, a_kc, ra); store_op(Bs, b_kc, rb);
         __syncthreads();
         for (int k0 = k_lo; k0 < k_hi; k0 += SK) {
             const bool more = k0 + SK < k_hi;
             if (more) {
                 load_op(g.A, g.lda, a_kc, bm, g.M, k0 + SK, a_vec, g.nslab_a, g.slab_a, ra);
-                load_op(g.B, g.ldb, b_kc, bn, g.N, k0 + SK, b_vec, 1, 0, rb);
+                load_op(g.B, g.ldb, b_kc, bn, g.N, k0 + SK, b_vec, nsb, g.slab_b, rb);
             }
 #pragma unroll
             for (int ks = 0; ks < SK / 2; ks++) {

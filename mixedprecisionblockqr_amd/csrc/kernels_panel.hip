@@ -1178,7 +1178,9 @@ __global__ __launch_bounds__(256) void t_assemble_kernel(float* __restrict__ T, 
                                                          half_t* __restrict__ Tth, int ldt, int A0,
                                                          const float* __restrict__ TL, int ldl, int aL0, int c0, int cm,
                                                          const float* __restrict__ TR, int ldr, int aR0, int c1,
-                                                         const float* __restrict__ TLR, int ldlr) {
+                                                         const float* __restrict__ TLR, int ldlr, int nz, long zslab) {
+    // TLR may arrive as nz partial sums (split-K product), zslab floats apart
+    auto tlr = [&](long off) { float s = 0.f; for (int z = 0; z < nz; z++) s += TLR[(long)z * zslab + off]; return s; };
     const long e = (long)blockIdx.x * 256 + threadIdx.x;
     if (e >= (long)ldt * ldt) return;
     const int i = (int)(e / ldt), j = (int)(e % ldt);
@@ -1188,7 +1190,7 @@ __global__ __launch_bounds__(256) void t_assemble_kernel(float* __restrict__ T, 
     const bool iR = gi >= cm && gi < c1, jR = gj >= cm && gj < c1;
     if (iL && jL) v = TL[(long)(gi - aL0) * ldl + (gj - aL0)];
     else if (iR && jR) v = TR[(long)(gi - aR0) * ldr + (gj - aR0)];
-    else if (iL && jR) v = TLR[(long)(gi - aL0) * ldlr + (gj - aR0)];
+    else if (iL && jR) v = tlr((long)(gi - aL0) * ldlr + (gj - aR0));
     T[(long)i * ldt + j] = v;
     float dii = 0.f;                                      // tau_i = T[i][i]: both fp16 copies carry their row i divided by it
     if (gi >= c0 && gi < cm) dii = TL[(long)(gi - aL0) * ldl + (gi - aL0)];
@@ -1202,16 +1204,17 @@ __global__ __launch_bounds__(256) void t_assemble_kernel(float* __restrict__ T, 
         const bool iR2 = gi2 >= cm && gi2 < c1, jR2 = gj2 >= cm && gj2 < c1;
         if (iL2 && jL2) u = TL[(long)(gi2 - aL0) * ldl + (gj2 - aL0)];
         else if (iR2 && jR2) u = TR[(long)(gi2 - aR0) * ldr + (gj2 - aR0)];
-        else if (iL2 && jR2) u = TLR[(long)(gi2 - aL0) * ldlr + (gj2 - aR0)];
+        else if (iL2 && jR2) u = tlr((long)(gi2 - aL0) * ldlr + (gj2 - aR0));
         Tth[(long)i * ldt + j] = (half_t)(u * rdi);
     }
 }
 
 void launch_t_assemble(float* T, half_t* Th, half_t* Tth, int ldt, int A0, const float* TL, int ldl, int aL0, int c0,
-                       int cm, const float* TR, int ldr, int aR0, int c1, const float* TLR, int ldlr, hipStream_t s) {
+                       int cm, const float* TR, int ldr, int aR0, int c1, const float* TLR, int ldlr, hipStream_t s, int nz,
+                       long zslab) {
     const long tot = (long)ldt * ldt;
     hipLaunchKernelGGL(t_assemble_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, T, Th, Tth, ldt, A0,
-                       TL, ldl, aL0, c0, cm, TR, ldr, aR0, c1, TLR, ldlr);
+                       TL, ldl, aL0, c0, cm, TR, ldr, aR0, c1, TLR, ldlr, nz < 1 ? 1 : nz, zslab);
 }
 
 }  // namespace mpqr

@@ -77,6 +77,7 @@ struct SgemmArgs {
     int M, N, K;
     float alpha, beta;
     int nslab_a; long slab_a;
+    int nslab_b; long slab_b;   // op(B) arrives as nslab_b partial slabs (0 / 1: plain), summed while staged like A's
     int upperA, upperB;   // operand is upper triangular (op(A)[i][k]=0 for k<i / op(B)[k][j]=0 for k>j): zero K tiles skipped
     int ksplit; long slab_c;   // ksplit > 1: K is cut into ksplit ranges (blockIdx.z), range z writes alpha * its partial product to C + z * slab_c (beta ignored)
 };
@@ -130,7 +131,7 @@ void launch_t_merge(const float* S, int ldl, int ldr, const float* TL, const flo
 void launch_t_assemble(float* T, half_t* Th, half_t* Tth, int ldt, int A0,
                        const float* TL, int ldl, int aL0, int c0, int cm,
                        const float* TR, int ldr, int aR0, int c1,
-                       const float* TLR, int ldlr, hipStream_t s);
+                       const float* TLR, int ldlr, hipStream_t s, int nz = 1, long zslab = 0);   // TLR as nz partial slabs
 
 // ------------------------------------------------------------------ misc kernels
 void launch_generate(float* A, long lda, int m, int n, uint64_t seed, int nglob, int block, int world, int rank,
