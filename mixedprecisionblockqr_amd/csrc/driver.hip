@@ -781,29 +781,43 @@ int factor_block_flat(mpqr_handle_t h, int top, const std::vector<int>& leaves) 
         // order (its X GEMM runs there), so the chain first meets the far update's columns one leaf later than the block boundary.
         const int P = std::min<int>(h->pre_leaves, (int)leaves.size());
         const int cpre = P > 0 ? h->nodes[leaves[P - 1]].c1 : lf.c1;
-        const bool split = tq && P >= 2 && (int)j < P - 1 && cpre < upd_end;
-        if ((int)j == P - 1 || P == 0 || !tq) {
+        // Leaf-level look-ahead (opt-in, MPQR_LEAF_LA=1; measured slower): on the chain a leaf updates only the NEXT
+        // leaf's columns (what the next gh_gram reads); its update of everything else (`rest`) runs on the T stream (lane 2) as soon
+        // as T_j exists, i.e. beside the next leaf's gh_solve.  Order: the T stream runs X_urgent(j), rest(j), X_urgent(j+1), ...
+        // so rest(j) has written the columns X_urgent(j+1) reads, and the chain's own update of them waits for that X (ev_x).
+        static const int leaf_la = []() { const char* e = getenv("MPQR_LEAF_LA"); return e ? atoi(e) : 0; }();
+        const int next_c1 = j + 1 < leaves.size() ? h->nodes[leaves[j + 1]].c1 : lf.c1 + 128;
+        const bool la_split = tq && leaf_la && lf.c1 < upd_end && std::min(next_c1, upd_end) < upd_end;
+        const bool pre_split = tq && P >= 2 && (int)j < P - 1 && cpre < upd_end;      // a pre-updated leaf before the last one
+        if ((int)j == P - 1 || P == 0 || (int)j >= P || !tq) {
             if (h->wait_after_first_leaf) {
                 // Only X = C2^T V_j reads those columns first, and it runs on the side stream: that stream waits, the chain stream goes
                 // on with T_j and meets the dependency through the X event (the robust leaf path, which works on the chain stream, waits there)
                 (void)hipStreamWaitEvent(tq && !robust_leaf ? h->sT : h->s0, h->wait_after_first_leaf, 0);
-                if (tq && robust_leaf && P >= 2) (void)hipStreamWaitEvent(h->sT, h->wait_after_first_leaf, 0);
+                if (tq && robust_leaf) (void)hipStreamWaitEvent(h->sT, h->wait_after_first_leaf, 0);
                 h->wait_after_first_leaf = nullptr;
             }
         }
-        const int own_end = split ? cpre : upd_end;
+        const int own_end = la_split ? std::min(next_c1, upd_end) : (pre_split ? cpre : upd_end);
+        const bool have_rest = (la_split || pre_split) && own_end < upd_end;
+        if (have_rest && la_split) (void)hipEventRecord(h->ev_def, h->s0);   // T_j and V_j are complete here: the rest may start beside the urgent part
         if (lf.c1 < own_end) {
             Range rg("mpqr:in_block_update");
             h->op1_stream = tq ? h->sT : nullptr;
             apply_node(h, lf, h->Aeff, h->lda, lf.c1, own_end, true, h->a_scale, false);
             h->op1_stream = nullptr;
         }
-        if (split) {                                       // the deferred part: the T stream has this leaf's V and T from here on
+        if (have_rest) {                                   // the rest, on the T stream
             Range rg("mpqr:in_block_update_deferred");
-            (void)hipEventRecord(h->ev_def, h->s0);
+            if (!la_split) (void)hipEventRecord(h->ev_def, h->s0);
             (void)hipStreamWaitEvent(h->sT, h->ev_def, 0);
-            if (h->wait_after_first_leaf) (void)hipStreamWaitEvent(h->sT, h->wait_after_first_leaf, 0);   // (kept: the last pre-updated leaf waits too)
-            apply_node(h, lf, h->Aeff, h->lda, cpre, upd_end, true, h->a_scale, false, 2);
+            int lo = own_end;
+            if (pre_split && lo < cpre) {                   // columns the previous block already brought up to date: no far update to wait for
+                apply_node(h, lf, h->Aeff, h->lda, lo, cpre, true, h->a_scale, false, 2);
+                lo = cpre;
+            }
+            if (pre_split && h->wait_after_first_leaf) (void)hipStreamWaitEvent(h->sT, h->wait_after_first_leaf, 0);   // (kept: the last pre-updated leaf waits too)
+            apply_node(h, lf, h->Aeff, h->lda, lo, upd_end, true, h->a_scale, false, 2);
         }
         // background, behind this leaf's X GEMM in the side stream's queue: the PREVIOUS leaf's column block of T
         if (prev_o >= 0) t_column_block(prev, prev_o);

@@ -7,9 +7,9 @@ root=${GRAFT_REPO_ROOT:-/root/repo}
 out=$root/gpurun_out/final
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats -d $out/ks -o c4 --output-format csv -- python3 $root/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $out/ks.log 2>&1 && echo "kernel stats ok"
-rocprofv3 --pmc FETCH_SIZE -d $out/fetch -o c4 --output-format csv -- python3 $root/bench.py --steps 1 --warmup 0 --no-cpu-baseline > $out/fetch.log 2>&1 && echo "fetch ok"
-rocprofv3 --pmc WRITE_SIZE -d $out/write -o c4 --output-format csv -- python3 $root/bench.py --steps 1 --warmup 0 --no-cpu-baseline > $out/write.log 2>&1 && echo "write ok"
+rocprofv3 --kernel-trace --stats -d $out/ks -o c4 --output-format csv -- python3 $root/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-dropin > $out/ks.log 2>&1 && echo "kernel stats ok"
+rocprofv3 --pmc FETCH_SIZE -d $out/fetch -o c4 --output-format csv -- python3 $root/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-dropin > $out/fetch.log 2>&1 && echo "fetch ok"
+rocprofv3 --pmc WRITE_SIZE -d $out/write -o c4 --output-format csv -- python3 $root/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-dropin > $out/write.log 2>&1 && echo "write ok"
 cd $root
 bash tools/pmc_sq.sh c4 > $out/${tag}_c4_sq_stalls.txt 2>&1 && echo "sq ok"
 bash tools/pmc_l2.sh $tag > $out/${tag}_c4_l2_hit.txt 2>&1 && echo "l2 ok"
