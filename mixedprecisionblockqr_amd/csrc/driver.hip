@@ -117,6 +117,7 @@ struct mpqr_handle_s {
     int* hflag_host = nullptr;    // one word of mapped host memory: a flagged Gram-Householder leaf raises it as well, the thread that
     int* hflag_dev = nullptr;     // enqueues the block loop polls it before every leaf and stops enqueuing (run_block_loop)
     bool watch_flags = false;     // only mpqr_factor's block loop reacts to the word
+    bool copied_in = false;       // mpqr_factor has just copied the input into the working matrix (together with the scale pass)
     bool pass_aborted = false;    // the last pass of the block loop stopped enqueuing at a flagged leaf
     int n_passes = 0, n_robust_leaves = 0;   // of the last mpqr_factor
     int n_gh_leaves = 0;                     // Gram-Householder leaves launched by the last mpqr_factor (all passes)
@@ -876,8 +877,10 @@ int clear_reflectors(mpqr_handle_t h, int c0 = 0) {
 
 // power-of-two scale so that fp16 operands stay in range (and out of the subnormal range): column norms are
 // bounded by sqrt(m) max|a|, which the scale brings to [2^7, 2^8)
-int compute_scale(mpqr_handle_t h, const float* src) {
-    launch_absmax(src, h->lda, h->m, h->n, h->dscalar, h->s0);
+// copy_to != nullptr: the same pass also copies the whole padded buffer there (the factorisation's copy-in)
+int compute_scale(mpqr_handle_t h, const float* src, float* copy_to = nullptr) {
+    if (copy_to) launch_copy_absmax(src, copy_to, h->lda, h->m_pad, h->m, h->n, h->dscalar, h->s0);
+    else launch_absmax(src, h->lda, h->m, h->n, h->dscalar, h->s0);
     float mx = 0.f;
     HIPCHK(h, hipMemcpyAsync(&mx, h->dscalar, sizeof(float), hipMemcpyDeviceToHost, h->s0));
     HIPCHK(h, hipStreamSynchronize(h->s0));
@@ -1434,8 +1437,9 @@ static int run_block_loop(mpqr_handle_t h, std::vector<int>& flags, int start = 
     if (start <= 0) {
         start = 0;
         h->far_used = 0; h->far_flops.clear(); h->far_bytes.clear(); h->chain_used = 0;
-        HIPCHK(h, hipEventRecord(h->ev[0], h->s0));
-        HIPCHK(h, hipMemcpyAsync(h->dA, h->dA0, (size_t)h->m_pad * h->lda * sizeof(float), hipMemcpyDeviceToDevice, h->s0));
+        if (!h->copied_in)                                  // (a later pass from block 0; the first one found the copy made by mpqr_factor)
+            HIPCHK(h, hipMemcpyAsync(h->dA, h->dA0, (size_t)h->m_pad * h->lda * sizeof(float), hipMemcpyDeviceToDevice, h->s0));
+        h->copied_in = false;
         if ((rc = clear_reflectors(h))) return rc;
     } else {
         Range rg("mpqr:restart_replay");
@@ -1592,7 +1596,10 @@ static int run_block_loop(mpqr_handle_t h, std::vector<int>& flags, int start = 
 int mpqr_factor(mpqr_handle_t h) {
     int rc = need_plan(h); if (rc) return rc;
     if (!h->have_input) return fail(h, MPQR_ERR_STATE, "no input matrix has been set");
-    if ((rc = compute_scale(h, h->dA0))) return rc;
+    // timing starts here; the copy-in of the resident input and the maximum behind the power-of-two scale are one pass over it
+    HIPCHK(h, hipEventRecord(h->ev[0], h->s0));
+    if ((rc = compute_scale(h, h->dA0, h->dA))) return rc;
+    h->copied_in = true;
     // Gram-Householder leaves that gh_solve flags (a column that cannot be reflected, or rho < 1e-8) are redone on the
     // column-by-column kernels.  A flagged leaf also raises a word in mapped host memory that the enqueuing thread reads before
     // every leaf: the pass stops being enqueued there (run_block_loop), the queue drains, and the next pass RESTARTS at the

@@ -235,6 +235,35 @@ void launch_absmax(const float* A, long lda, int m, int n, float* out, hipStream
     hipLaunchKernelGGL(absmax_kernel, dim3(2048), dim3(256), 0, s, A, lda, m, n, out);
 }
 
+// dst = src over the whole padded buffer (rows x ld floats, ld % 4 == 0) and out[0] = max |src[i][j]| over i < m, j < n, in one
+// pass: the factorisation's copy-in of the resident input and the maximum its power-of-two scale needs (mpqr_factor)
+__global__ __launch_bounds__(256) void copy_absmax_kernel(const float* __restrict__ src, float* __restrict__ dst, long ld, int rows,
+                                                          int m, int n, float* out) {
+    float mx = 0.f;
+    const int ld4 = (int)(ld >> 2);
+    for (int r = blockIdx.x; r < rows; r += gridDim.x) {
+        const float4* s4 = (const float4*)(src + (long)r * ld);
+        float4* d4 = (float4*)(dst + (long)r * ld);
+        for (int c4 = threadIdx.x; c4 < ld4; c4 += 256) {
+            const float4 v = s4[c4];
+            d4[c4] = v;
+            if (r < m) {
+                const int c = 4 * c4;
+                if (c + 0 < n) mx = fmaxf(mx, fabsf(v.x));
+                if (c + 1 < n) mx = fmaxf(mx, fabsf(v.y));
+                if (c + 2 < n) mx = fmaxf(mx, fabsf(v.z));
+                if (c + 3 < n) mx = fmaxf(mx, fabsf(v.w));
+            }
+        }
+    }
+    mx = wave_max(mx);
+    if ((threadIdx.x & 63) == 0) atomicMax((unsigned int*)out, __float_as_uint(mx));
+}
+void launch_copy_absmax(const float* src, float* dst, long ld, int rows, int m, int n, float* out, hipStream_t s) {
+    (void)hipMemsetAsync(out, 0, sizeof(float), s);
+    hipLaunchKernelGGL(copy_absmax_kernel, dim3(std::min(rows, 4096)), dim3(256), 0, s, src, dst, ld, rows, m, n, out);
+}
+
 // out[0] += sum (A-B)^2 ; out[1] += sum A^2   (double accumulation)
 __global__ void diff_norms_kernel(const float* A, long lda, const float* B, long ldb, int m, int n, double* out) {
     double d2 = 0, a2 = 0;

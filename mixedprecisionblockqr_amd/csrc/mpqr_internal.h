@@ -150,6 +150,7 @@ void launch_pack_factor_cyclic(const float* A, long lda, const float* vdiag, flo
                                int world, int rank, hipStream_t s);
 void launch_transpose_h16(const half_t* src, long lds_, half_t* dst, long ldd, int rows, int cols, hipStream_t s);
 void launch_absmax(const float* A, long lda, int m, int n, float* out /*1*/, hipStream_t s);
+void launch_copy_absmax(const float* src, float* dst, long ld, int rows, int m, int n, float* out /*1*/, hipStream_t s);
 // metrics reductions: out[0] += sum (A - B)^2, out[1] += sum A^2
 void launch_diff_norms(const float* A, long lda, const float* B, long ldb, int m, int n, double* out, hipStream_t s);
 // out[0] += sum (G - I)^2, out[1] = max signed (G - I)

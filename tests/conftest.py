@@ -13,6 +13,21 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+@pytest.fixture(scope="session", autouse=True)
+def _torch_gpu_first():
+    """On a GPU box: bring torch's HIP context up before the first test.  The distributed-schedule tests wrap the library's chain
+    stream in a torch stream; when torch's lazy initialisation happened for the first time AFTER the 50 GB config-5 test of the same
+    process (`pytest tests/test_gpu_parity.py -k "config5 or distributed"`) it reported "No HIP GPUs are available" on every box
+    tried, while the same sequence in a plain script (tools/dbg_c5_then_torch.py) initialises fine.  Order-independent this way."""
+    try:
+        import torch
+        if torch.cuda.is_available():
+            torch.cuda.init()
+    except Exception:
+        pass
+    yield
+
+
 @pytest.fixture(scope="session")
 def golden():
     return np.load(os.path.join(ROOT, "tests", "golden", "pyref_qr.npz"))

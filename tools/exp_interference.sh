@@ -6,4 +6,4 @@ for l in open("gpurun_out/r3/exp_$tag.json"):
         d=json.loads(l); b=d["breakdown_ms"]; print("$tag", round(d["ms_per_step"],2), "factor", round(b["ms_factor"],2), "panel", round(b["ms_panel"],2), "formq", round(b["ms_form_q"],2), "far tn/nn", round(b["ms_far_tn"],2), round(b["ms_far_nn"],2), "passes", b["n_passes"], "err", d["error"]["backward_error"], d["error"]["q_error_fro"])
 PY
 }
-run default A=1 && run leafla MPQR_LEAF_LA=1
+run fusedcopy A=1
