@@ -721,6 +721,14 @@ OPT_IN = [
     {"MPQR_X16": "0"},                             # fp32 X through memory, split while staged (gemm2 A_F32S)
     {"MPQR_FAR_PAIR": "0"},                        # far updates block by block (K = outer block) instead of pairwise
     {"MPQR_ASHADOW": "1", "MPQR_FAR_PAIR": "1"},   # pairwise far updates reading the fp16 shadow of the trailing matrix
+    # round 3
+    {"MPQR_EXT_LEAVES": "1"},                      # block boundary: the in-block updates reach ONE leaf of the next block (round 2)
+    {"MPQR_EXT_LEAVES": "3"},                      # ... three leaves (two deferred updates on the T stream per boundary)
+    {"MPQR_DEFER_FAR": "0"},                       # far update enqueued at the block's end instead of behind the next block's first gh_gram
+    {"MPQR_LEAF_LA": "1"},                         # leaf-level look-ahead: every leaf's update of the rest of its block on the T stream
+    {"MPQR_TCOL_KSPLIT": "0"},                     # exact-f32 products of the block T and of the pair merges in one K range
+    {"MPQR_FAR_TN_SPLIT": "4"},                    # big far X = C2^T V GEMMs split over four K slabs
+    {"MPQR_RESTART": "0", "MPQR_WATCH_FLAGS": "0"},   # robust fallback as in round 2 (no early stop, every pass from block 0)
 ]
 
 
