@@ -21,6 +21,7 @@ first = next(i for i, r in enumerate(chain) if 'gh_gram' in r['Kernel_Name'])
 last = max(i for i, r in enumerate(chain) if 'gh_apply' in r['Kernel_Name'])
 chain = chain[first:last + 1]
 span = (chain[-1]['e'] - chain[0]['s']) / 1e3
+solves = [r for r in chain if 'gh_solve' in r['Kernel_Name']]      # (bench.py's stand-alone solve timing comes after the slice)
 print(f"chain queue {cq}: {len(chain)} dispatches, {len(solves)} leaves, span {span / 1e3:.2f} ms = {span / len(solves):.1f} us per leaf")
 busy = collections.defaultdict(float); gap = collections.defaultdict(float); cnt = collections.defaultdict(int)
 pos_gap = collections.defaultdict(float); pos_busy = collections.defaultdict(float)

@@ -14,6 +14,8 @@ ident = next(i for i, r in enumerate(run) if 'identity' in r['Kernel_Name'])
 q = run[ident:]
 cut = next((i for i, r in enumerate(q) if 'gh_solve' in r['Kernel_Name'] or 'absmax' in r['Kernel_Name']), len(q))   # (bench.py's stand-alone solve timing follows)
 q = q[:cut]
+lastg = max((i for i, r in enumerate(q) if 'gemm' in r['Kernel_Name']), default=len(q) - 1)      # (memsets of the metric pass may follow)
+q = q[:lastg + 1]
 t0, t1 = q[0]['s'], max(r['e'] for r in q)
 print("Q phase %.2f ms, %d dispatches" % ((t1 - t0) / 1e6, len(q)))
 d = collections.Counter(); c = collections.Counter()
