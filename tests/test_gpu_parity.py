@@ -119,6 +119,39 @@ def test_wy_transform(mp, h, po, m, n, go, pw):
     assert np.abs(Qp.T @ Qp - np.eye(m - go)).max() < 3e-3
 
 
+def test_reference_wy_sweep(mp, h, po):
+    """The loop nest of the reference's own WY sweep (Cuda/main.cu:14 -> Cuda/qr.cu:1925-1941 test_iterator_dev_wy_funcs ->
+    test_dev_wy_transform, :1610-1669): m = 40 .. 1280 (x2), n = m/4 .. < m (x2), global_offset = n/4 .. < n (x2), panel width 16
+    (m < 500) or 8, or what is left of the matrix.  The reference feeds its two WY routines the same random array and compares
+    them with each other; here the panel is a factored one (h_householder_qr conventions: the compact-WY T of this library is
+    defined for reflectors with v^T v = 2), the dense Q_panel = I - V T V^T comes back through the C ABI and is compared with
+    the oracle's h_wy_transform (W / Y recurrence, qr.cu:337-426) element-wise."""
+    worst = 0.0
+    cases = 0
+    m = 40
+    while m < 2000:
+        n = m // 4
+        while n < m:
+            go = n // 4
+            while go < n:
+                pw = n - go if n - go < 16 else (16 if m < 500 else 8)
+                A = po.generate(m, n, seed=1000 + cases)
+                Ac = po.padded(A)
+                po.lib().orc_householder_qr(Ac, m, n, go, pw)
+                T, Qp = mp.wy_transform(Ac, m, n, go, pw, dense=True, handle=h)
+                Qp0 = po.wy_transform(Ac, m, n, go, pw)
+                err = float(np.abs(Qp - Qp0).max())
+                worst = max(worst, err)
+                assert err <= 3e-3, (m, n, go, pw, err)
+                assert np.abs(Qp.T @ Qp - np.eye(m - go)).max() < 3e-3, (m, n, go, pw)
+                cases += 1
+                go *= 2
+            n *= 2
+        m *= 2
+    assert cases == 25
+    print(f"WY sweep: {cases} cases, max |Q_panel - oracle| = {worst:.2e}")
+
+
 @pytest.mark.parametrize("m,n", [(6, 4), (60, 40), (129, 80), (400, 300)])
 def test_q_backward_accumulation(mp, h, po, m, n):
     """a-6: h_q_backward_accumulation (Cuda/qr.cu:296-335)."""
