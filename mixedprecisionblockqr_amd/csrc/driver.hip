@@ -935,9 +935,9 @@ static void merge_prefix(mpqr_handle_t h, int pid, hipStream_t st) {
     const Node L = h->nodes[nd.left], R = h->nodes[nd.right];
     const int ld = nd.tld, o = L.ldt, w = R.ldt;
     float* const Tr = h->Tf + nd.toff; half_t* const Thr = h->Th + nd.toff; half_t* const Tthr = h->Tth + nd.toff;
-    if (h->tq_on) {
-        (void)hipStreamWaitEvent(st, h->ev_T[L.id], 0);
-        (void)hipStreamWaitEvent(st, h->ev_T[R.id], 0);
+    if (h->tq_on) {                                       // (a distributed rank that has not factored a block yet has no T events)
+        if (L.id < (int)h->ev_T.size()) (void)hipStreamWaitEvent(st, h->ev_T[L.id], 0);
+        if (R.id < (int)h->ev_T.size()) (void)hipStreamWaitEvent(st, h->ev_T[R.id], 0);
     }
     if (L.tld != ld) {                                    // first step: block 0's own T becomes the leading block
         (void)hipMemcpy2DAsync(Tr, (size_t)ld * 4, h->Tf + L.toff, (size_t)L.tld * 4, (size_t)o * 4, o, hipMemcpyDeviceToDevice, st);
@@ -1202,7 +1202,7 @@ static int plan_common(mpqr_handle_t h, int m, int n, int r, const mpqr_opts* op
         }
         h->qmerge_after.assign(h->tops.size(), std::vector<int>());
         const char* g6 = getenv("MPQR_GEMM6");             // the I - W V^T epilogue lives in the ping-pong kernel only
-        if (one_on && aligned && world == 1 && o.form_q && o.precision != MPQR_PREC_FP32 && (long)m >= 3L * n && m >= 2048 &&
+        if (one_on && aligned && o.form_q && o.precision != MPQR_PREC_FP32 && (long)m >= 3L * n && m >= 2048 &&
             !(g6 && atoi(g6) == 0)) {
             // prefix nodes P_k = blocks 0..k, all in ONE arena of the full width (P_k's T is the leading principal block of
             // the root's): step k adds the column block  T[0:o, o:o+w] = -T_{P_{k-1}} (V_P^T V_k) T_k  (LAPACK larft order, as
@@ -2463,6 +2463,14 @@ int mpqr_dist_update_part(mpqr_handle_t h, int s, int part) {
         merge_pair(h, h->qpair[s], ms);
         if (ms == h->s1) (void)hipEventRecord(h->ev_dist_far, h->s1);
     }
+    if (part != 0 && h->opts.form_q && h->S2 && h->qroot >= 0 && s < (int)h->qmerge_after.size() && !h->qmerge_after[s].empty()) {
+        // tall matrices: T of blocks 0..s from T of blocks 0..s-1 (every rank builds the whole T itself: it holds every block's V and T),
+        // for the one-shot Q formation of its column shard (mpqr_dist_form_q)
+        hipStream_t ms = (part == 1 && two_streams) ? h->s1 : h->s0;
+        if (ms == h->s1) { (void)hipEventRecord(h->ev_dist_chain, h->s0); (void)hipStreamWaitEvent(h->s1, h->ev_dist_chain, 0); }
+        for (int id : h->qmerge_after[s]) merge_prefix(h, id, ms);
+        if (ms == h->s1) (void)hipEventRecord(h->ev_dist_far, h->s1);
+    }
     if (last && part != 0) {
         h->pairs_ready = h->opts.form_q && h->S2 != nullptr;
         if (two_streams) (void)hipStreamWaitEvent(h->s0, h->ev_dist_far, 0);
@@ -2483,6 +2491,37 @@ int mpqr_dist_form_q(mpqr_handle_t h) {
         HIPCHK(h, hipMemsetAsync(h->Qt, 0, (size_t)(h->ldq + 256) * h->ldqt * sizeof(half_t), h->s0));
         launch_identity_cyclic_h16(h->Qt, h->ldqt, h->m, h->qloc, h->Ko, h->world, h->rank, h->s0);
         h->shadow = h->Qt; h->ldshadow = h->ldqt;
+    }
+    if (h->qroot >= 0 && h->pairs_ready) {
+        // Tall matrices (m >= 3n), as on one GPU: Q = I - (V T) V^T over all reflectors at once instead of the backward accumulation.
+        // Every rank forms W = V T itself (m x n, 4 ms at 65536 x 8192) and then, for each of its column superblocks J of Q,
+        // Q[:, J] -= W V[J, :]^T into the identity it already holds (read-modify-write: every GEMM kernel of the library has that epilogue).
+        const Node rt = h->nodes[h->qroot];
+        const int Kr = rt.ldt;
+        if (h->tq_on && rt.id < (int)h->ev_T.size()) (void)hipStreamWaitEvent(h->s0, h->ev_T[rt.id], 0);
+        GemmArgs w{};                                       // W[m x Kr] = V T   (T upper triangular: k <= n)
+        w.A = h->Vh + rt.a0; w.lda = h->ldvh;
+        w.Bt = h->Tth + rt.toff; w.ldb = rt.tld;
+        w.C = h->Wh; w.ldc = h->n_pad;
+        w.M = h->m_pad; w.N = Kr; w.K = Kr; w.alpha = 1.f; w.in_scale = 1.f; w.nsplit = 1; w.tri = 2;
+        w.cscale = h->Tf + rt.toff; w.cscale_ld = (long)rt.tld + 1;
+        gemm_dispatch(A_H16, E_STORE_H16, w, h->s0);
+        for (int l0 = 0; l0 < h->qloc; l0 += h->Ko) {
+            const int gc0 = mpqr_part_global_index(l0, h->Ko, h->world, h->rank);      // global column of Q = row of V
+            const int nc = std::min(h->Ko, h->qloc - l0);
+            GemmArgs q{};
+            q.A = h->Wh; q.lda = h->n_pad;
+            q.Bt = h->Vh + (long)gc0 * h->ldvh + rt.a0; q.ldb = h->ldvh;
+            q.C = h->dQ + l0; q.ldc = h->ldq;
+            q.M = h->m_pad; q.N = nc; q.K = Kr; q.alpha = 1.f; q.in_scale = 1.f; q.nsplit = 1;   // (padded rows: W is zero there)
+            gemm_dispatch(A_H16, E_SUB_F32, q, h->s0);
+        }
+        h->shadow = nullptr; h->shadow_write = true;
+        h->q_formed = true;
+        HIPCHK(h, hipEventRecord(h->ev[2], h->s0));
+        HIPCHK(h, hipGetLastError());
+        if (g_dispatch_error.exchange(0)) return fail(h, MPQR_ERR_STATE, "a GEMM of the Q formation found no kernel for its operand staging / epilogue");
+        return MPQR_OK;
     }
     const bool pairs = h->pairs_ready && h->qpair.size() == h->tops.size();
     for (int t = (int)h->tops.size() - 1; t >= 0; t--) {
