@@ -11,6 +11,16 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "baseline(rank): oracle / property comparison of a BASELINE.json config; collected first")
+
+
+def pytest_collection_modifyitems(config, items):
+    """The driver runs the GPU suite with -x: the comparisons on BASELINE.json's own configurations (C1 .. C5) come first, in config
+    order, so that no later failure can leave one of them unexercised.  Stable for everything else."""
+    def rank(item):
+        mk = item.get_closest_marker("baseline")
+        return (0, mk.args[0] if mk and mk.args else 0) if mk else (1, 0)
+    items.sort(key=rank)
 
 
 @pytest.fixture(scope="session", autouse=True)
