@@ -6,7 +6,7 @@
 // for f in { householder + backward accumulation, fp32 block QR, mixed-precision block QR }, printing the three
 // error lines and appending the reference's CSV log rows (log/cpu_householder.txt, log/gpu_block.txt).
 //
-//   usage: mpqr_main [--jacobians DIR [--skip-random]] [--m M --n N --r R] [--seed S] [--dtype fp16|fp32|fp8] [--gpus N]
+//   usage: mpqr_main [--jacobians DIR [--skip-random]] [--m M --n N --r R] [--seed S] [--dtype fp16|fp32|fp8] [--gpus N [--steps K] [--no-check]]
 //   --gpus N (with --m --n --r): the multi-GPU host driver -- one host thread per GPU of this node, column superblocks dealt
 //            round-robin (mpqr_dist_* step functions of the C ABI), V,T of every block broadcast with ncclBroadcast (RCCL over
 //            xGMI) on a communication stream of its own, look-ahead schedule of SURVEY.md 8e.  The reference is single-GPU.
@@ -130,7 +130,7 @@ struct HostBarrier {
 };
 }  // namespace
 
-static int run_multi_gpu(int world, int m, int n, int r, uint64_t seed, int steps, const char* dtype) {
+static int run_multi_gpu(int world, int m, int n, int r, uint64_t seed, int steps, const char* dtype, bool check) {
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < world) { fprintf(stderr, "error: %d GPUs requested, %d visible\n", world, ndev); return 1; }
     std::vector<int> devs(world);
@@ -142,6 +142,10 @@ static int run_multi_gpu(int world, int m, int n, int r, uint64_t seed, int step
     std::vector<float> amax(world, 0.f);
     std::vector<double> ms(world, 0.0);
     std::atomic<bool> failed{false};
+    // --check (default): every rank hands its column shards of the input, of the factor and of Q to the host after the timed loop;
+    // the three reference criteria (Cuda/qr.cu:115-196) are then evaluated on the assembled matrices like in the single-GPU testers
+    std::vector<float> Ain, Fac, Qfull;
+    if (check) { Ain.assign((size_t)m * n, 0.f); Fac.assign((size_t)(m + 1) * n, 0.f); Qfull.assign((size_t)m * m, 0.f); }
     mpqr_opts o; mpqr_default_opts(&o);
     o.precision = !strcmp(dtype, "fp32") ? MPQR_PREC_FP32 : (!strcmp(dtype, "fp8") ? MPQR_PREC_FP8 : MPQR_PREC_FP16);
     if (world > 1) o.outer_block = std::max(r, std::min(1024, (n / (2 * world)) / r * r));   // >= 2 blocks per rank (see dist.py)
@@ -216,6 +220,22 @@ static int run_multi_gpu(int world, int m, int n, int r, uint64_t seed, int step
             for (int it = 0; it < steps && good; it++) good = factor();
             if (!good || !bar.wait()) break;
             ms[rank] = std::chrono::duration<double, std::milli>(std::chrono::high_resolution_clock::now() - t0).count() / steps;
+            if (check) {                                                 // shards -> their global columns of the host copies (disjoint per rank)
+                const int ko = mpqr_dist_block(h), nloc = mpqr_dist_local_cols(h), qloc = mpqr_dist_local_q_cols(h);
+                std::vector<float> a((size_t)m * std::max(nloc, 1)), f((size_t)(m + 1) * std::max(nloc, 1)), q((size_t)m * std::max(qloc, 1));
+                if (!ok_q(mpqr_dist_get_local_input_host(h, a.data()), "mpqr_dist_get_local_input_host") ||
+                    !ok_q(mpqr_dist_get_local_factor_host(h, f.data()), "mpqr_dist_get_local_factor_host") ||
+                    !ok_q(mpqr_dist_get_local_q_host(h, q.data()), "mpqr_dist_get_local_q_host")) break;
+                for (int lc = 0; lc < nloc; lc++) {
+                    const int gc = mpqr_part_global_index(lc, ko, world, rank);
+                    for (int i = 0; i < m; i++) Ain[(size_t)i * n + gc] = a[(size_t)i * nloc + lc];
+                    for (int i = 0; i <= m; i++) Fac[(size_t)i * n + gc] = f[(size_t)i * nloc + lc];
+                }
+                for (int lc = 0; lc < qloc; lc++) {
+                    const int gc = mpqr_part_global_index(lc, ko, world, rank);
+                    for (int i = 0; i < m; i++) Qfull[(size_t)i * m + gc] = q[(size_t)i * qloc + lc];
+                }
+            }
         } while (0);
         for (void* b : bufs) if (b) (void)hipFree(b);
         for (hipEvent_t e : {ev_pack, ev_bcast, ev_unp[0], ev_unp[1]}) if (e) (void)hipEventDestroy(e);
@@ -231,11 +251,21 @@ static int run_multi_gpu(int world, int m, int n, int r, uint64_t seed, int step
     const double geqrf = 2.0 * m * (double)n * n - 2.0 / 3.0 * (double)n * n * n;
     printf("multi-GPU block QR: %d GPU(s), %d x %d, r = %d, outer block %d, %s: %.2f ms per factorisation incl. Q, %.1f GFLOP/s (GEQRF-equivalent flops)\n",
            world, m, n, r, o.outer_block ? o.outer_block : 1024, dtype, worst, geqrf / (worst * 1e-3) / 1e9);
+    if (check) {
+        // the reference's three criteria on the gathered result, p = operand precision (qr.cu:1889: 11 for the mixed path; 23 / 4 for fp32 / e4m3)
+        const int bits = !strcmp(dtype, "fp32") ? 23 : (!strcmp(dtype, "fp8") ? 4 : 11);
+        std::vector<float> R((size_t)m * n);
+        h_strip_R_from_A(Fac.data(), R.data(), m, n);
+        printf("Dimensions of A (m, n, r): (%d, %d, %d)\n", m, n, r);
+        h_backward_error(Ain.data(), R.data(), Qfull.data(), m, n, bits);
+        h_q_error(Qfull.data(), m, bits);
+        h_lower_trapezoid_error(R.data(), m, n, bits);
+    }
     return 0;
 }
 
 int main(int argc, char** argv) {
-    const char* jac = nullptr; int m = 0, n = 0, r = 0, gpus = 0, steps = 3; const char* dtype = "fp16"; bool random_list = true;
+    const char* jac = nullptr; int m = 0, n = 0, r = 0, gpus = 0, steps = 3; const char* dtype = "fp16"; bool random_list = true, check = true;
     for (int i = 1; i < argc; i++) {
         if (!strcmp(argv[i], "--jacobians") && i + 1 < argc) jac = argv[++i];
         else if (!strcmp(argv[i], "--m") && i + 1 < argc) m = atoi(argv[++i]);
@@ -245,13 +275,14 @@ int main(int argc, char** argv) {
         else if (!strcmp(argv[i], "--gpus") && i + 1 < argc) gpus = atoi(argv[++i]);
         else if (!strcmp(argv[i], "--steps") && i + 1 < argc) steps = atoi(argv[++i]);
         else if (!strcmp(argv[i], "--dtype") && i + 1 < argc) dtype = argv[++i];
+        else if (!strcmp(argv[i], "--no-check")) check = false;               // --gpus: skip the gather + the three error criteria
         else if (!strcmp(argv[i], "--skip-random")) random_list = false;      // with --jacobians: only the Jacobian run list (qr.cu:1794-1804)
-        else { fprintf(stderr, "usage: %s [--jacobians DIR [--skip-random]] [--m M --n N --r R] [--seed S] [--dtype fp16|fp32|fp8] [--gpus N [--steps K]]\n", argv[0]); return 2; }
+        else { fprintf(stderr, "usage: %s [--jacobians DIR [--skip-random]] [--m M --n N --r R] [--seed S] [--dtype fp16|fp32|fp8] [--gpus N [--steps K] [--no-check]]\n", argv[0]); return 2; }
     }
     try {
         if (gpus > 0) {
             if (!(m > 0 && n > 0 && r > 0)) { fprintf(stderr, "--gpus needs --m --n --r\n"); return 2; }
-            return run_multi_gpu(gpus, m, n, r, g_seed, std::max(1, steps), dtype);
+            return run_multi_gpu(gpus, m, n, r, g_seed, std::max(1, steps), dtype, check);
         }
         if (m > 0 && n > 0 && r > 0) {
             if (!strcmp(dtype, "fp32")) test_dev_block_qr(m, n, r, generate(m, n));

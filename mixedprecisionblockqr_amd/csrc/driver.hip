@@ -114,8 +114,10 @@ struct mpqr_handle_s {
     bool robust = false;          // true: EVERY tall leaf is factored column by column instead of by Gram-Householder
     std::vector<char> leaf_robust;   // per tree node: this tall leaf was flagged by gh_solve and takes the robust path
     int nflag = 0;                // ints in dflag: one flag per tree node (gh_solve raises dflag[node id])
-    int* hflag_host = nullptr;    // one word of mapped host memory: a flagged Gram-Householder leaf raises it as well, the thread that
-    int* hflag_dev = nullptr;     // enqueues the block loop polls it before every leaf and stops enqueuing (run_block_loop)
+    int* hflag_host = nullptr;    // mapped host memory, one word per top-level block: a flagged Gram-Householder leaf raises its block's word,
+    int* hflag_dev = nullptr;     // the thread that enqueues the block loop polls the words and stops enqueuing (run_block_loop)
+    int flag_words = 0;           // number of words
+    int cur_block = 0;            // the block whose leaves are being enqueued (their flags go to word cur_block)
     bool watch_flags = false;     // only mpqr_factor's block loop reacts to the word
     bool copied_in = false;       // mpqr_factor has just copied the input into the working matrix (together with the scale pass)
     bool pass_aborted = false;    // the last pass of the block loop stopped enqueuing at a flagged leaf
@@ -123,6 +125,9 @@ struct mpqr_handle_s {
     int n_gh_leaves = 0;                     // Gram-Householder leaves launched by the last mpqr_factor (all passes)
     int restart_block = 0;                   // top-level block the last pass of mpqr_factor started from
     int n_q_ident_rows = 0;                  // rows of X copied from V in the last Q formation (identity columns of Q)
+    bool dispatch_error = false;             // a GEMM enqueued on behalf of this handle found no kernel (gemm_dispatch)
+    bool q_inited = false;                   // Q = I (and its fp16 shadow) was set up early, on the far stream beside the first panels
+    std::vector<size_t> far_mark, chain_mark;   // event-pool positions at the start of every top-level block (a restart rewinds to them)
     float us_gh_solve = 0.f;                 // mpqr_bench_leaf_solve's last result
     float* rbTf = nullptr; half_t* rbTh = nullptr; half_t* rbTth = nullptr; size_t rb_elems = 0;   // T arena of a robust leaf's sub-tree
     bool force32 = false;         // tree building: only 32-column leaves (sub-tree of a robustly factored tall leaf)
@@ -217,7 +222,7 @@ void free_plan(mpqr_handle_t h) {
                     h->S2, h->tmp1b, h->tmp2b, h->Qt, h->At, h->Xh, h->Wh, h->Xl, h->Xh1, h->Xl1};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (h->hflag_host) (void)hipHostFree(h->hflag_host);
-    h->hflag_host = h->hflag_dev = nullptr;
+    h->hflag_host = h->hflag_dev = nullptr; h->flag_words = 0; h->cur_block = 0;
     h->S2 = h->tmp1b = h->tmp2b = nullptr; h->s2_elems = 0; h->Qt = nullptr; h->shadow = nullptr; h->At = nullptr; h->at_read = false; h->Xh = nullptr; h->Xl = h->Xh1 = h->Xl1 = nullptr; h->Wh = nullptr; h->qroot = -1; h->qmerge_after.clear(); h->qpair.clear(); h->pairs_ready = false;
     h->dA = h->dA0 = h->dQ = nullptr; h->Vh = h->Vt = nullptr; h->vdiag = nullptr; h->Xt = nullptr; h->Yt = nullptr;
     h->S = nullptr; h->P = nullptr; h->tmp1 = h->tmp2 = nullptr; h->Tf = nullptr; h->Th = h->Tth = nullptr;
@@ -235,7 +240,8 @@ void free_plan(mpqr_handle_t h) {
     for (hipEvent_t e : h->far_ev) (void)hipEventDestroy(e);
     h->far_ev.clear();
     h->nodes.clear(); h->tops.clear();
-    h->planned = false; h->have_input = false; h->factored = false; h->q_formed = false;
+    h->planned = false; h->have_input = false; h->factored = false; h->q_formed = false; h->q_inited = false;
+    h->far_mark.clear(); h->chain_mark.clear();
 }
 
 // ---- column-range tree
@@ -255,8 +261,12 @@ int pick_split(mpqr_handle_t h, int c0, int c1, int r) {
             if (best < 0 || abs(x - mid) < abs(best - mid)) best = x;
         return best;
     };
-    int s = nearest_multiple(r);            // keep the caller's r-wide panels intact as long as possible
-    if (s < 0 && leaf_width(h, c0) == 128) s = nearest_multiple(128);
+    // Tall ranges are cut at multiples of 128 whatever the caller's r: a Gram-Householder leaf costs nearly the same for 64 columns as
+    // for 128 (its launches and hand-offs, not its arithmetic), so r = 64 on 2048 rows (BASELINE config 2) took 32 leaves where 16 do.
+    // r is the reference's blocking parameter, not part of the result: the reflectors, R and Q are the same for every blocking
+    // (Cuda/qr.cu:1075-1076 only groups the same Householder steps).  Short ranges keep the caller's r-wide panels.
+    int s = leaf_width(h, c0) == 128 ? nearest_multiple(128) : -1;
+    if (s < 0) s = nearest_multiple(r);
     if (s < 0) s = nearest_multiple(32);
     if (s < 0) s = mid;
     return s;
@@ -290,19 +300,17 @@ static long gemm2_min_tiles() {
     static const long v = []() { const char* e = getenv("MPQR_GEMM2_MIN_TILES"); return e ? atol(e) : 48L; }();
     return v;
 }
-static int far_tn_split() {   // tuning hook, see apply_node
-    static const int v = []() { const char* e = getenv("MPQR_FAR_TN_SPLIT"); return e ? atoi(e) : 0; }();
-    return v;
-}
-// set when a GEMM found no kernel: mpqr_factor / form_q report it instead of returning garbage
-static std::atomic<int> g_dispatch_error{0};
+// a GEMM that finds no kernel marks ITS handle (thread-local "current handle", set by every C-ABI entry that enqueues GEMMs):
+// mpqr_factor / form_q / the mpqr_dist_* steps report it instead of returning garbage, and one rank thread of the multi-GPU host
+// can neither consume nor inherit another handle's error
+static thread_local mpqr_handle_t t_dispatch_handle = nullptr;
 void gemm_dispatch(AMode am, EMode em, const GemmArgs& g, hipStream_t s) {
     const long tiles = (long)(g.M / 256) * (g.N / 256);
     if ((g.nsplit <= 1 || (em == E_STORE_F32 && am == A_F32T)) && (g.nslab_in <= 1) && g.M >= 256 && g.N >= 256 &&
         tiles >= gemm2_min_tiles() && (g.K % 64) == 0 &&
         launch_gemm2_f16(am, em, g, s, gemm2_config()))
         return;
-    if (!launch_gemm_f16(am, em, g, s)) g_dispatch_error.store(1);
+    if (!launch_gemm_f16(am, em, g, s) && t_dispatch_handle) t_dispatch_handle->dispatch_error = true;
 }
 
 int choose_split(int M, int N, int K, size_t cap_elems, long slab) {
@@ -402,14 +410,6 @@ void apply_node(mpqr_handle_t h, const Node& nd, float* C, long ldc, int clo, in
     g1.in_scale = in_scale; g1.alpha = 1.f;
     const long slab = (long)M1 * Kr;
     g1.nsplit = choose_split(M1, Kr, Kw, lane == 2 ? h->xt2_elems : h->xt_elems, slab);
-    // big far updates: X = C2^T V runs K = all rows per workgroup (256 x 256 tiles: ~500 us per workgroup at 16384 rows), and while
-    // those workgroups sit on every CU the chain's own GEMMs wait for them.  MPQR_FAR_TN_SPLIT=n splits K over n slabs (fp32, summed
-    // by slab_reduce): n times shorter workgroups for n x (M1 x Kr x 4 B) of slab traffic
-    if (far && lane == 1 && far_tn_split() > 1 && g1.nsplit == 1 && (long)(M1 / 256) * (Kr / 256) >= gemm2_min_tiles() && Kw >= 4096) {
-        int ns = std::min(far_tn_split(), Kw / 2048);
-        while (ns > 1 && (size_t)ns * (size_t)slab > h->xt1_elems) ns--;
-        g1.nsplit = std::max(ns, 1);
-    }
     g1.slab_out_stride = slab;
     if (record) (void)hipEventRecord(e0, st);
     hipStream_t st1 = (h->op1_stream && lane == 0) ? h->op1_stream : st;     // flat schedule: X on the side stream, T on the chain
@@ -419,8 +419,7 @@ void apply_node(mpqr_handle_t h, const Node& nd, float* C, long ldc, int clo, in
     const bool a_shadow = h->At && lane == 1 && far && !f8 && C == h->dA;   // fp16 shadow of the trailing matrix (far updates)
     // X keeps ~22 bits through Y = X T' (fp16 hi + lo parts, MPQR_XSPLIT=0: one fp16 rounding as in round 1); the fp16-X
     // shortcut of Q formation (MPQR_X16=1) is the opposite trade
-    static const int xsplit = []() { const char* e = getenv("MPQR_XSPLIT"); return e ? atoi(e) : 1; }();
-    static const int x16_env = []() { const char* e = getenv("MPQR_X16"); return e ? atoi(e) : 1; }();
+    constexpr int xsplit = 1, x16_env = 1;                  // (round 1's single-rounding X and the fp32 X through memory lost for two rounds: removed)
     // big unsplit updates: X goes from its GEMM to the next one as fp16 (hi, and lo when xsplit) instead of fp32
     half_t* const Xhi = lane == 1 ? h->Xh1 : lane == 2 ? nullptr : h->Xh;
     // (Q formation: Q has no dominant component, the lo part buys 1.5 % of backward error and 7 % of ||Q^T Q - I|| for
@@ -431,8 +430,7 @@ void apply_node(mpqr_handle_t h, const Node& nd, float* C, long ldc, int clo, in
     const bool x16 = x16_env && Xhi && (!xsplit || Xlo || q_apply) && !f8 && g1.nsplit == 1 && M1 >= 256 && Kr >= 256 && (Kr % 64) == 0 &&
                      (long)(M1 / 256) * (Kr / 256) >= gemm2_min_tiles() && h->opts.precision != MPQR_PREC_FP32;
     // one leaf (128 reflectors) onto a few columns: slab sum and Y = X T' in one small kernel (leaf_xt_kernel)
-    static const int fuse_env = []() { const char* e = getenv("MPQR_FUSE_XT"); return e ? atoi(e) : 1; }();
-    const bool fuse_xt = fuse_env && !f8 && !far && lane != 1 && Kr == 128 && M1 <= 4096 && !(h->shadow && lane == 0);
+    const bool fuse_xt = !f8 && !far && lane != 1 && Kr == 128 && M1 <= 4096 && !(h->shadow && lane == 0);
     if (f8) {
         if (h->v8_node != nd.id) {                          // the block's reflectors, once per block: 2^8 V in both layouts
             launch_quant_h16_fp8(h->Vh + (long)rlo * h->ldvh + nd.a0, h->ldvh, h->V8n, h->ld8k, Kw, Kr, 256.f, st);
@@ -498,7 +496,7 @@ void apply_node(mpqr_handle_t h, const Node& nd, float* C, long ldc, int clo, in
     if (fuse_xt) launch_leaf_xt(Xt, g1.nsplit, slab, M1, g2.Bt, g2.ldb, g2.tri, Yt, Kr, g2.cscale, g2.cscale_ld, st);
     else if (x16) { g2.A = Xhi; g2.A2 = Xlo; gemm_dispatch(A_H16, E_STORE_H16, g2, st); }
     else
-    gemm_dispatch(xsplit ? A_F32S : A_F32, E_STORE_H16, g2, st);
+    gemm_dispatch(A_F32S, E_STORE_H16, g2, st);
     // op3: C2 -= (1/in_scale) V Yt^T
     GemmArgs g3{};
     g3.A = h->Vh + (long)rlo * h->ldvh + nd.a0; g3.lda = h->ldvh;
@@ -532,8 +530,18 @@ int robust_tall_leaf(mpqr_handle_t h, const Node nd, bool do_panel);
 // thread that enqueues mpqr_factor's block loop reads that word before every leaf (a plain load, nothing on the device) and stops
 // enqueuing: everything downstream of the flagged leaf is redone anyway, so the sooner the queue ends the less is wasted.
 constexpr int MPQR_ABORT_PASS = -1000;                   // internal: factor_node's "stop enqueuing", never returned to callers
+// any flag word of blocks [0, upto) raised?
+static inline bool flag_words_set(mpqr_handle_t h, int upto) {
+    if (!h->hflag_host) return false;
+    for (int b = 0; b < upto && b < h->flag_words; b++)
+        if (__atomic_load_n(h->hflag_host + b, __ATOMIC_RELAXED) != 0) return true;
+    return false;
+}
+// Checked before every leaf: a flag in an EARLIER block ends the pass at once.  A flag in the block being enqueued does not: its
+// remaining leaves are still enqueued, so that every ill-conditioned leaf of the block has flagged itself when the pass is read back
+// and ONE restart repairs the whole block (run_block_loop stops at the block's end).
 static inline bool pass_is_flagged(mpqr_handle_t h) {
-    return h->watch_flags && h->hflag_host && __atomic_load_n(h->hflag_host, __ATOMIC_RELAXED) != 0;
+    return h->watch_flags && flag_words_set(h, h->cur_block);
 }
 
 // Robust path for a tall (<=128-column) leaf: factor it through a temporary sub-tree of 32-column leaves
@@ -595,7 +603,7 @@ int factor_rec(mpqr_handle_t h, int id, bool do_panel) {
             Range rg("mpqr:panel");
             a.A = h->Aeff; a.lda = h->lda; a.mrows = h->m; a.cb = rdown(nd.c0, tall ? 128 : 32); a.c0 = nd.c0; a.c1 = nd.c1;
             a.Vh = h->Vh; a.ldvh = h->ldvh; a.Vt = h->Vt; a.ldvt = h->ldvt; a.vdiag = h->vdiag;
-            a.P = h->P; a.maxwg = h->maxwg; a.hostflag = h->hflag_dev;
+            a.P = h->P; a.maxwg = h->maxwg; a.hostflag = h->hflag_dev + h->cur_block;
             const bool fused = tall && !h->Vf;    // fp16 mode: the Gram of the rounded reflectors comes out of gh_apply
             int* flag = h->dflag + (id < h->nflag ? id : 0);
             if (tall) { launch_leaf_gram_householder(a, h->Gp, h->Gs, h->Cv, flag, fused ? h->Sp : nullptr, nullptr, h->s0); h->n_gh_leaves++; }
@@ -674,8 +682,7 @@ static void collect_leaves(mpqr_handle_t h, int id, std::vector<int>& out) {
     collect_leaves(h, nd.left, out); collect_leaves(h, nd.right, out);
 }
 static bool flat_block_ok(mpqr_handle_t h, int top, std::vector<int>& leaves) {
-    static const int on = []() { const char* e = getenv("MPQR_FLAT"); return e ? atoi(e) : 1; }();
-    if (!on || h->Vf || h->force32) return false;
+    if (h->Vf || h->force32) return false;
     leaves.clear();
     collect_leaves(h, top, leaves);
     if (leaves.size() < 2) return false;
@@ -712,8 +719,7 @@ int factor_block_flat(mpqr_handle_t h, int top, const std::vector<int>& leaves) 
         // K = o (up to 896) in one workgroup per 64 x 64 tile is a 70 us latency chain of 56 load / barrier / MFMA steps, and the
         // last leaf's column block sits on the path to the block's far update: K is cut into ranges of 128, the partial products
         // (S is free again: tmp1 = S T_j has been formed) are summed by t_colblock_h16 on its way to the fp16 copies
-        static const int ks_env = []() { const char* e = getenv("MPQR_TCOL_KSPLIT"); return e ? atoi(e) : 1; }();
-        const int nz = ks_env ? std::min(8, o / 128) : 1;
+        const int nz = std::min(8, o / 128);
         if (nz > 1 && (size_t)nz * o * lf.ldt <= h->s_elems) {
             s2.C = h->S; s2.ldc = lf.ldt; s2.ksplit = nz; s2.slab_c = (long)o * lf.ldt;
             launch_sgemm(s2, st);
@@ -746,7 +752,7 @@ int factor_block_flat(mpqr_handle_t h, int top, const std::vector<int>& leaves) 
             LeafArgs a{};
             a.A = h->Aeff; a.lda = h->lda; a.mrows = h->m; a.cb = rdown(lf.c0, 128); a.c0 = lf.c0; a.c1 = lf.c1;
             a.Vh = h->Vh; a.ldvh = h->ldvh; a.Vt = h->Vt; a.ldvt = h->ldvt; a.vdiag = h->vdiag;
-            a.P = h->P; a.maxwg = h->maxwg; a.hostflag = h->hflag_dev;
+            a.P = h->P; a.maxwg = h->maxwg; a.hostflag = h->hflag_dev + h->cur_block;
             launch_gh_gram(a, h->Gp, h->Gs, h->s0);
             // the previous block's far update is enqueued HERE (run_block_loop): its stream starts when this leaf's gh_solve does,
             // so its first GEMMs fill the other 255 CUs during the solve instead of holding them while gh_gram wants them
@@ -788,8 +794,9 @@ int factor_block_flat(mpqr_handle_t h, int top, const std::vector<int>& leaves) 
         // so rest(j) has written the columns X_urgent(j+1) reads, and the chain's own update of them waits for that X (ev_x).
         static const int leaf_la = []() { const char* e = getenv("MPQR_LEAF_LA"); return e ? atoi(e) : 0; }();
         const int next_c1 = j + 1 < leaves.size() ? h->nodes[leaves[j + 1]].c1 : lf.c1 + 128;
-        const bool la_split = tq && leaf_la && lf.c1 < upd_end && std::min(next_c1, upd_end) < upd_end;
-        const bool pre_split = tq && P >= 2 && (int)j < P - 1 && cpre < upd_end;      // a pre-updated leaf before the last one
+        const bool lane2_ok = h->Xt2 != nullptr && h->Yt2 != nullptr;      // (allocated with opts.lookahead only: ADVICE round 3)
+        const bool la_split = tq && lane2_ok && leaf_la && lf.c1 < upd_end && std::min(next_c1, upd_end) < upd_end;
+        const bool pre_split = tq && lane2_ok && P >= 2 && (int)j < P - 1 && cpre < upd_end;      // a pre-updated leaf before the last one
         if ((int)j == P - 1 || P == 0 || (int)j >= P || !tq) {
             if (h->wait_after_first_leaf) {
                 // Only X = C2^T V_j reads those columns first, and it runs on the side stream: that stream waits, the chain stream goes
@@ -910,10 +917,9 @@ static void merge_pair(mpqr_handle_t h, int pid, hipStream_t st) {
     s1.B = h->Tf + R.toff; s1.ldb = R.ldt; s1.transB = 0;
     s1.C = h->tmp1b; s1.ldc = R.ldt; s1.M = L.ldt; s1.N = R.ldt; s1.K = R.ldt; s1.alpha = 1.f; s1.beta = 0.f; s1.upperB = 1;
     // both products are 1024^3 on 256 workgroups whose K loops (64 load / barrier / MFMA steps) take ~85 us each: K is cut into
-    // ranges of 256, the partial slabs are summed by the next consumer's operand staging / by t_assemble (MPQR_TCOL_KSPLIT=0: whole K)
-    static const int ks_env = []() { const char* e = getenv("MPQR_TCOL_KSPLIT"); return e ? atoi(e) : 1; }();
+    // ranges of 256, the partial slabs are summed by the next consumer's operand staging / by t_assemble
     const long zs = (long)L.ldt * R.ldt;
-    int nz = ks_env ? std::min(4, std::min(L.ldt, R.ldt) / 256) : 1;
+    int nz = std::max(1, std::min(4, std::min(L.ldt, R.ldt) / 256));
     if ((size_t)nz * (size_t)zs > h->tmpb_elems) nz = 1;
     if (nz > 1) { s1.ksplit = nz; s1.slab_c = zs; }
     launch_sgemm(s1, st);
@@ -994,16 +1000,24 @@ static int form_q_one_shot(mpqr_handle_t h) {
     return MPQR_OK;
 }
 
+// Q = I and its transposed fp16 shadow = I (1.6 GB of stores at 16384^2).  run_block_loop issues this on the far stream at the START of
+// the factorisation, where that stream has nothing to do until the first block is factored, instead of in front of Q formation.
+static int init_q(mpqr_handle_t h, hipStream_t st) {
+    HIPCHK(h, hipMemsetAsync(h->dQ, 0, (size_t)h->m_pad * h->ldq * sizeof(float), st));
+    launch_set_identity(h->dQ, h->ldq, h->m, h->m, st);
+    if (h->Qt && h->world == 1) {
+        HIPCHK(h, hipMemsetAsync(h->Qt, 0, (size_t)(h->ldq + 256) * h->ldqt * sizeof(half_t), st));
+        launch_set_identity_h16(h->Qt, h->ldqt, h->m, st);
+    }
+    return MPQR_OK;
+}
+
 int form_q(mpqr_handle_t h) {
     Range rg("mpqr:form_q");
     if (h->qroot >= 0 && h->pairs_ready && h->world == 1) return form_q_one_shot(h);
-    HIPCHK(h, hipMemsetAsync(h->dQ, 0, (size_t)h->m_pad * h->ldq * sizeof(float), h->s0));
-    launch_set_identity(h->dQ, h->ldq, h->m, h->m, h->s0);
-    if (h->Qt && h->world == 1) {
-        HIPCHK(h, hipMemsetAsync(h->Qt, 0, (size_t)(h->ldq + 256) * h->ldqt * sizeof(half_t), h->s0));
-        launch_set_identity_h16(h->Qt, h->ldqt, h->m, h->s0);
-        h->shadow = h->Qt; h->ldshadow = h->ldqt;
-    }
+    if (!h->q_inited) { int rc = init_q(h, h->s0); if (rc) return rc; }
+    h->q_inited = false;                                  // (consumed: the applies below overwrite the identity)
+    if (h->Qt && h->world == 1) { h->shadow = h->Qt; h->ldshadow = h->ldqt; }
     const bool rec = h->world == 1 && h->factored;        // timed like the far updates (mpqr_get_timings: ms_q_*)
     h->n_q_ident_rows = 0;
     h->q_first = rec ? h->far_used : (size_t)-1;
@@ -1046,6 +1060,7 @@ hipError_t create_update_stream(hipStream_t* st, int prio) {
 
 int check_shape(mpqr_handle_t h, int m, int n, int r) {
     if (!h) return MPQR_ERR_INVALID;
+    t_dispatch_handle = h;
     if (m < 1 || n < 1 || r < 1) return fail(h, MPQR_ERR_INVALID, "m, n, r must be >= 1");
     if (n > m) return fail(h, MPQR_ERR_INVALID, "m >= n required (Householder QR of a tall or square matrix)");
     return MPQR_OK;
@@ -1169,7 +1184,7 @@ static int plan_common(mpqr_handle_t h, int m, int n, int r, const mpqr_opts* op
     h->m_pad = rup(m, 256); h->n_pad = rup(n, 256);
     int Ko = o.outer_block > 0 ? o.outer_block : 1024;
     Ko = std::max(Ko, 32);
-    if (r >= Ko) Ko = r; else Ko = (Ko / r) * r;
+    if (r >= Ko) Ko = r; else if (Ko % 128 != 0) Ko = (Ko / r) * r;   // (128-aligned top-level blocks stay: tall leaves are 128-column windows)
     h->Ko = Ko;
     h->nloc = (world == 1) ? n : mpqr_part_local_cols(n, Ko, world, rank);
     h->qloc = (world == 1) ? m : mpqr_part_local_cols(m, Ko, world, rank);
@@ -1283,7 +1298,7 @@ static int plan_common(mpqr_handle_t h, int m, int n, int r, const mpqr_opts* op
     HIPCHK(h, hipMemsetAsync(h->Xt, 0, (h->xt_elems + (size_t)256 * x_ldt) * sizeof(float), h->s0));
     HIPCHK(h, hipMemsetAsync(h->Yt, 0, (h->yt_elems + (size_t)256 * x_ldt) * sizeof(half_t), h->s0));
     if (o.lookahead && o.precision != MPQR_PREC_FP32) {
-        h->xt1_elems = h->xt_elems * (size_t)std::max(1, far_tn_split());
+        h->xt1_elems = h->xt_elems;
         if ((rc = dalloc(h, &h->Xt1, h->xt1_elems + (size_t)256 * x_ldt))) return rc;
         if ((rc = dalloc(h, &h->Yt1, h->yt_elems + (size_t)256 * x_ldt))) return rc;
         HIPCHK(h, hipMemsetAsync(h->Xt1, 0, (h->xt1_elems + (size_t)256 * x_ldt) * sizeof(float), h->s0));
@@ -1318,8 +1333,9 @@ static int plan_common(mpqr_handle_t h, int m, int n, int r, const mpqr_opts* op
     if ((rc = dalloc(h, &h->dflag, (size_t)h->nflag))) return rc;
     {   // the flag word the enqueuing thread polls: mapped, coherent host memory (a flagged leaf stores 1 into it, system scope)
         void* hp = nullptr; void* dp = nullptr;
-        if (hipHostMalloc(&hp, 64, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess) { h->err = "hipHostMalloc failed"; return MPQR_ERR_ALLOC; }
-        h->hflag_host = (int*)hp; *h->hflag_host = 0;
+        h->flag_words = (int)h->tops.size() + 16;
+        if (hipHostMalloc(&hp, (size_t)h->flag_words * sizeof(int), hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess) { h->err = "hipHostMalloc failed"; return MPQR_ERR_ALLOC; }
+        h->hflag_host = (int*)hp; memset(h->hflag_host, 0, (size_t)h->flag_words * sizeof(int));
         HIPCHK(h, hipHostGetDevicePointer(&dp, hp, 0));
         h->hflag_dev = (int*)dp;
     }
@@ -1387,8 +1403,10 @@ int mpqr_plan(mpqr_handle_t h, int m, int n, int r, const mpqr_opts* opts) {
     return plan_common(h, m, n, r, opts, 1, 0);
 }
 
+static bool dispatch_failed(mpqr_handle_t h) { const bool f = h->dispatch_error; h->dispatch_error = false; return f; }
 static int need_plan(mpqr_handle_t h, bool dist = false) {
     if (!h) return MPQR_ERR_INVALID;
+    t_dispatch_handle = h;                                  // GEMMs enqueued by this call report to this handle
     if (!h->planned) return fail(h, MPQR_ERR_STATE, "mpqr_plan has not been called");
     if (!dist && h->world != 1) return fail(h, MPQR_ERR_STATE, "handle holds a distributed plan: use the mpqr_dist_* calls");
     hipError_t e = hipSetDevice(h->device);
@@ -1429,11 +1447,17 @@ int mpqr_generate_matrix(mpqr_handle_t h, uint64_t seed) {
 // start > 0 (restart after a flagged leaf): blocks [0, start) of the previous pass are kept -- their reflectors, T's and columns of
 // R -- and the columns right of them are brought back to the state in which block `start` found them: the input with the far
 // updates of the kept blocks applied again (GEMM work only, no panel chain).  The pass then runs blocks start .. end.
-static int run_block_loop(mpqr_handle_t h, std::vector<int>& flags, int start = 0) {
+static int run_block_loop(mpqr_handle_t h, int start = 0) {
     int rc;
     h->v8_node = -1;
     h->pairs_ready = false; h->q_first = (size_t)-1;
     const auto host_t0 = std::chrono::steady_clock::now();  // host time to enqueue the block loop (ms_host_enqueue)
+    if (start > 0 && (size_t)start < h->far_mark.size()) {
+        // restart: the aborted pass's recordings for blocks >= start describe work that is thrown away -- rewind the event pools to
+        // where block `start` began, so that ms_panel / ms_far_* / the roofline figures cover only work that is kept
+        h->far_used = h->far_mark[start]; h->chain_used = h->chain_mark[start];
+        h->far_flops.resize(h->far_used / 4); h->far_bytes.resize(h->far_used / 4);
+    }
     if (start <= 0) {
         start = 0;
         h->far_used = 0; h->far_flops.clear(); h->far_bytes.clear(); h->chain_used = 0;
@@ -1452,7 +1476,7 @@ static int run_block_loop(mpqr_handle_t h, std::vector<int>& flags, int start = 
     }
     HIPCHK(h, hipMemsetAsync(h->dflag, 0, (size_t)h->nflag * sizeof(int), h->s0));
     static const int watch_env = []() { const char* e = getenv("MPQR_WATCH_FLAGS"); return e ? atoi(e) : 1; }();   // 0: never stop a pass early (round 2)
-    __atomic_store_n(h->hflag_host, 0, __ATOMIC_RELAXED);   // (no kernel of an earlier pass is still running: every pass ends synchronised)
+    for (int b = 0; b < h->flag_words; b++) __atomic_store_n(h->hflag_host + b, 0, __ATOMIC_RELAXED);   // (no leaf of an earlier pass is still running: mpqr_factor waits for every pass's last leaf)
     h->watch_flags = watch_env != 0;
     bool aborted = false;
     const bool la = h->Xt1 != nullptr;                    // look-ahead: far updates on s1, panel chain on s0
@@ -1460,6 +1484,8 @@ static int run_block_loop(mpqr_handle_t h, std::vector<int>& flags, int start = 
         // s1 must see the copy-in / clears issued on s0
         HIPCHK(h, hipEventRecord(h->ev[3], h->s0));
         HIPCHK(h, hipStreamWaitEvent(h->s1, h->ev[3], 0));
+        // Q = I now, on the idle far stream (form_q then starts with its first GEMM); tall matrices store Q in one product, no init
+        if (start == 0 && h->opts.form_q && h->qroot < 0 && h->world == 1 && !h->q_inited) { if ((rc = init_q(h, h->s1))) return rc; h->q_inited = true; }
     }
     // Look-ahead.  Far update t (stream s1) is released in two parts: (a) the columns the chain needs next, (b) the rest,
     // which overlaps the next block's panels.  With the flat block schedule (ext[t]) block t's own in-block updates also
@@ -1467,6 +1493,7 @@ static int run_block_loop(mpqr_handle_t h, std::vector<int>& flags, int start = 
     // plus the first leaf of block t+2 (when that block is flat too), waited for after block t+1's first leaf is enqueued.
     // Tree-scheduled blocks keep the older split: first leaf of block t+1 first (ev_cols, waited for before the block).
     const size_t nt = h->tops.size();
+    h->far_mark.resize(nt + 1); h->chain_mark.resize(nt + 1);
     // MPQR_EXT_LEAVES (default 2): how many leading leaves of block t+1 the in-block updates of a flat block t reach.  With 2 the
     // chain meets the columns of part (a) one leaf after the boundary: the first leaf's update of the rest of its block is deferred
     // to the T stream (factor_block_flat), and part (a) -- which needs the block's complete T -- has a whole leaf to arrive in.
@@ -1535,6 +1562,8 @@ static int run_block_loop(mpqr_handle_t h, std::vector<int>& flags, int start = 
     };
     for (size_t t = (size_t)start; t < nt; t++) {
         const Node nd = h->nodes[h->tops[t]];
+        h->far_mark[t] = h->far_used; h->chain_mark[t] = h->chain_used;
+        h->cur_block = (int)t;
         if (la && t > 0) {
             if (!ext[t - 1]) HIPCHK(h, hipStreamWaitEvent(h->s0, h->ev_cols[t], 0));
             h->wait_after_first_leaf = h->ev_cols2[t];
@@ -1546,6 +1575,7 @@ static int run_block_loop(mpqr_handle_t h, std::vector<int>& flags, int start = 
         if (pending_far >= 0) { const size_t tp = (size_t)pending_far; pending_far = -1; h->far_hook = [&far_update, tp]() { return far_update(tp); }; }
         rc = factor_node(h, h->tops[t], true);
         h->ext_c1 = 0;
+        if (!rc && h->watch_flags && flag_words_set(h, (int)t + 1)) rc = MPQR_ABORT_PASS;   // this block (or an earlier one) holds a flagged leaf: all of its leaves are enqueued, stop here
         if (rc == MPQR_ABORT_PASS) {          // a leaf of this pass is flagged: nothing enqueued from here on would be kept
             aborted = true;
             h->wait_after_first_leaf = nullptr; h->op1_stream = nullptr; h->far_hook = nullptr;
@@ -1573,7 +1603,7 @@ static int run_block_loop(mpqr_handle_t h, std::vector<int>& flags, int start = 
         if (defer_env && ext[t] && t + 1 < nt && flat[t + 1]) { pending_far = (int)t; continue; }   // (a flat block takes the hook in its first leaf)
         if ((rc = far_update(t))) { h->defer_join = false; h->watch_flags = false; return rc; }
     }
-    h->watch_flags = false; h->pass_aborted = aborted; h->pre_leaves = 0;
+    h->watch_flags = false; h->pass_aborted = aborted; h->pre_leaves = 0; h->cur_block = 0;
     h->pairs_ready = !aborted && h->opts.form_q && h->S2 != nullptr;     // (pairs or the whole tree)
     if (h->defer_join) {                                    // the T stream's work of every block, once
         h->defer_join = false;
@@ -1585,12 +1615,9 @@ static int run_block_loop(mpqr_handle_t h, std::vector<int>& flags, int start = 
         HIPCHK(h, hipStreamWaitEvent(h->s0, h->ev[3], 0));
     }
     HIPCHK(h, hipEventRecord(h->ev[1], h->s0));
-    flags.assign(h->nodes.size(), 0);
     h->host_enqueue_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - host_t0).count();
-    HIPCHK(h, hipMemcpyAsync(flags.data(), h->dflag, flags.size() * sizeof(int), hipMemcpyDeviceToHost, h->s0));
-    HIPCHK(h, hipStreamSynchronize(h->s0));
     HIPCHK(h, hipGetLastError());
-    return MPQR_OK;
+    return MPQR_OK;                                         // nothing is synchronised here: mpqr_factor waits for ev[1] AFTER it has enqueued Q formation
 }
 
 int mpqr_factor(mpqr_handle_t h) {
@@ -1607,38 +1634,56 @@ int mpqr_factor(mpqr_handle_t h) {
     // Only the FIRST flagged leaf (in column order) is believed: the leaves behind it worked on columns it had spoiled, so their
     // flags say nothing.  Six restarts at most; after that every tall leaf goes robust and the pass runs from block 0.
     // n_passes counts passes (stopped ones included), restart_block is the block the last pass started from.
+    // No host synchronisation between the block loop and Q formation (round 4): Q formation is enqueued right behind the pass, THEN the
+    // host waits for the event behind the block loop and reads the mapped flag word (zero unless a leaf was flagged: the normal case
+    // returns with Q formation still running, as before).  A flagged pass has a speculative Q formation in the queue; it is simply
+    // formed again after the repair passes.
     std::vector<int> flags;
     h->n_passes = 0;
     int start = 0, gh_total = 0;
-    for (int pass = 0; pass < 8; pass++) {
+    const int nblocks = (int)h->tops.size();
+    for (int pass = 0; pass < 2 * nblocks + 8; pass++) {
         h->n_passes++;
         h->n_gh_leaves = 0;
         h->restart_block = start;
-        if ((rc = run_block_loop(h, flags, start))) return rc;
+        if ((rc = run_block_loop(h, start))) return rc;
         gh_total += h->n_gh_leaves;
+        h->factored = true;
+        if (h->opts.form_q && !h->pass_aborted) { if ((rc = form_q(h))) return rc; }
+        HIPCHK(h, hipEventRecord(h->ev[2], h->s0));
+        HIPCHK(h, hipEventSynchronize(h->ev[1]));           // the block loop (not Q formation) is done: the flag word is final
+        HIPCHK(h, hipGetLastError());
+        if (!flag_words_set(h, h->flag_words) && !h->pass_aborted) break;
+        h->factored = false; h->q_formed = false;
+        flags.assign(h->nodes.size(), 0);
+        HIPCHK(h, hipMemcpyAsync(flags.data(), h->dflag, flags.size() * sizeof(int), hipMemcpyDeviceToHost, h->s0));
+        HIPCHK(h, hipStreamSynchronize(h->s0));
+        // The first flagged leaf in column order is certainly ill conditioned; leaves right of it inside the SAME top-level block saw
+        // columns that only its (still valid, if inaccurate) reflectors had touched, so their flags are believed too -- a Jacobian whose
+        // dependent columns are spread over a block is repaired in one restart instead of one per leaf.  Blocks further right
+        // worked on columns a wrong far update may have spoiled: their flags say nothing and are left for the next pass to raise again.
         int bad = -1;                                     // the flagged leaf with the smallest first column
         for (size_t id = 0; id < flags.size(); id++)
             if (flags[id] && !h->leaf_robust[id] && (bad < 0 || h->nodes[id].c0 < h->nodes[bad].c0)) bad = (int)id;
         if (bad < 0 && h->pass_aborted) return fail(h, MPQR_ERR_STATE, "the block loop stopped at a flagged leaf, but no leaf flag is set");
-        if (bad < 0 || h->robust) break;
-        h->leaf_robust[bad] = 1;
+        if (bad < 0) return fail(h, MPQR_ERR_STATE, "the flag word is raised, but no leaf flag is set");
+        if (h->robust) { h->factored = true; break; }       // (every tall leaf already on the robust path: nothing left to repair)
         int first = 0;
-        for (int t = 0; t < (int)h->tops.size(); t++) {
+        for (int t = 0; t < nblocks; t++) {
             const Node& tp = h->nodes[h->tops[t]];
             if (h->nodes[bad].c0 >= tp.c0 && h->nodes[bad].c0 < tp.c1) { first = t; break; }
         }
+        const Node& fb = h->nodes[h->tops[first]];
+        for (size_t id = 0; id < flags.size(); id++)
+            if (flags[id] && h->nodes[id].left < 0 && h->nodes[id].c0 >= fb.c0 && h->nodes[id].c0 < fb.c1) h->leaf_robust[id] = 1;
         static const int restart_env = []() { const char* e = getenv("MPQR_RESTART"); return e ? atoi(e) : 1; }();   // 0: every pass from block 0 (round 2)
         start = restart_env ? first : 0;
-        if (pass >= 5) { h->robust = true; start = 0; }
+        if (pass >= nblocks + 5) { h->robust = true; start = 0; }   // (one pass per block holding flagged leaves is the expected worst case)
     }
     h->n_gh_leaves = gh_total;
     h->n_robust_leaves = 0;
     for (char c : h->leaf_robust) h->n_robust_leaves += c ? 1 : 0;
-    h->factored = true;
-    if (h->opts.form_q) { if ((rc = form_q(h))) return rc; }
-    HIPCHK(h, hipEventRecord(h->ev[2], h->s0));
-    HIPCHK(h, hipGetLastError());
-    if (g_dispatch_error.exchange(0)) return fail(h, MPQR_ERR_STATE, "a GEMM of the factorisation found no kernel for its operand staging / epilogue");
+    if (dispatch_failed(h)) return fail(h, MPQR_ERR_STATE, "a GEMM of the factorisation found no kernel for its operand staging / epilogue");
     return MPQR_OK;
 }
 
@@ -1648,6 +1693,7 @@ int mpqr_sync(mpqr_handle_t h) {
     HIPCHK(h, hipStreamSynchronize(h->s0));
     if (h->s1) HIPCHK(h, hipStreamSynchronize(h->s1));
     if (h->sT) HIPCHK(h, hipStreamSynchronize(h->sT));
+    if (dispatch_failed(h)) return fail(h, MPQR_ERR_STATE, "a GEMM enqueued for this handle found no kernel for its operand staging / epilogue");
     return MPQR_OK;
 }
 
@@ -1995,7 +2041,7 @@ static int stage_load(mpqr_handle_t h, const float* A, int m, int n, int r, int 
     launch_unpack_factor(h->dstage, m, n, c0, c1, h->dA, h->lda, h->vdiag, h->Vh, h->ldvh, h->Vt, h->ldvt, h->s0);
     if (h->Vf && c1 > c0) launch_extract_vf(h->dA, h->lda, h->vdiag, h->Vf, h->n_pad, h->m, c0, c1, h->s0);
     HIPCHK(h, hipStreamSynchronize(h->s0));
-    h->Aeff = h->dA; h->v8_node = -1;
+    h->Aeff = h->dA; h->v8_node = -1; h->q_inited = false;
     h->factored = false; h->q_formed = false; h->have_input = false;
     return MPQR_OK;
 }
@@ -2477,6 +2523,7 @@ int mpqr_dist_update_part(mpqr_handle_t h, int s, int part) {
         HIPCHK(h, hipEventRecord(h->ev[1], h->s0)); h->factored = true;
     }
     HIPCHK(h, hipGetLastError());
+    if (dispatch_failed(h)) return fail(h, MPQR_ERR_STATE, "a GEMM of the trailing update found no kernel for its operand staging / epilogue");
     return MPQR_OK;
 }
 int mpqr_dist_update(mpqr_handle_t h, int s) { return mpqr_dist_update_part(h, s, 2); }
@@ -2520,7 +2567,7 @@ int mpqr_dist_form_q(mpqr_handle_t h) {
         h->q_formed = true;
         HIPCHK(h, hipEventRecord(h->ev[2], h->s0));
         HIPCHK(h, hipGetLastError());
-        if (g_dispatch_error.exchange(0)) return fail(h, MPQR_ERR_STATE, "a GEMM of the Q formation found no kernel for its operand staging / epilogue");
+        if (dispatch_failed(h)) return fail(h, MPQR_ERR_STATE, "a GEMM of the Q formation found no kernel for its operand staging / epilogue");
         return MPQR_OK;
     }
     const bool pairs = h->pairs_ready && h->qpair.size() == h->tops.size();
@@ -2536,6 +2583,7 @@ int mpqr_dist_form_q(mpqr_handle_t h) {
     h->q_formed = true;
     HIPCHK(h, hipEventRecord(h->ev[2], h->s0));
     HIPCHK(h, hipGetLastError());
+    if (dispatch_failed(h)) return fail(h, MPQR_ERR_STATE, "a GEMM of the Q formation found no kernel for its operand staging / epilogue");
     return MPQR_OK;
 }
 

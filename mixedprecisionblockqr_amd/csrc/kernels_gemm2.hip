@@ -309,11 +309,7 @@ template <int AM, int EM, int WM, int WN, int BK>
 static void launch2(const GemmArgs& g, hipStream_t s) {
     constexpr int BM = 128 * WM, BN = 64 * WN, NT = 64 * WM * WN;
     constexpr int LDS = 2 * ((AM == A_F32S ? 2 : 1) * BM + BN) * BK * 2;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)gemm2_f16_kernel<AM, EM, WM, WN, BK>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-        attr_set = true;
-    }
+    MPQR_ONCE_PER_DEVICE((void)hipFuncSetAttribute((const void*)gemm2_f16_kernel<AM, EM, WM, WN, BK>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
     const int tilesM = (g.M + BM - 1) / BM, tilesN = (g.N + BN - 1) / BN;
     const int groups = ((tilesM + 3) / 4) * ((tilesN + 7) / 8);
     GemmArgs a = g;
@@ -635,11 +631,7 @@ __global__ __launch_bounds__(512) void gemm6_f16_kernel(GemmArgs g, int tilesM, 
 template <int EM, int DMA_EPI>
 static void launch6(const GemmArgs& g, hipStream_t s) {
     constexpr int LDS = 2 * 2 * 256 * 128;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)gemm6_f16_kernel<EM, DMA_EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-        attr_set = true;
-    }
+    MPQR_ONCE_PER_DEVICE((void)hipFuncSetAttribute((const void*)gemm6_f16_kernel<EM, DMA_EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
     const int tilesM = (g.M + 255) / 256, tilesN = (g.N + 255) / 256;
     const int groups = ((tilesM + 3) / 4) * ((tilesN + 7) / 8);
     hipLaunchKernelGGL((gemm6_f16_kernel<EM, DMA_EPI>), dim3(groups * 32), dim3(512), LDS, s, g, tilesM, tilesN);

@@ -389,271 +389,6 @@ __global__ __launch_bounds__(256) void gh_reduce_kernel(const double* __restrict
 }
 
 
-// 768 threads.  Waves 0-7 ("update", a 16 x 32 grid): thread (ti,tj) keeps the CYCLIC entries {ti + 16x} x {tj + 32y},
-// x < 8, y < 4, of B_top (fp32) and of N (fp64) in registers.  N is symmetric and only rows <= columns are ever
-// read, so the 16 x 32 blocks entirely below the diagonal (x > 2y+1) are not kept: 20 of 32.
-//
-// The recursion splits into two chains that only meet in one direction.  With u = column k over the remaining rows,
-// s_j = N[k][j]:  the now-final row k of R leaves the set of remaining rows, N' = N - R[k] (x) R[k], and
-// R[k][j] = -sgn(u0) N[k][j] / sqrt(N[k][k]).  The sign drops out of the outer product, so N follows a plain
-// CHOLESKY recursion  c_k = N[k][:] / sqrt(N[k][k]),  N' = N - c_k (x) c_k  that never looks at B (fp64: this is
-// where cond(A)^2 lives).  The HOUSEHOLDER part -- u0 = B[k][k], nu = c_kk, alpha = sgn(u0) nu,
-// inv = 1/||u|| = rsqrt(2 nu (nu + |u0|)),  w_j = 2 nu (c_kj + sgn(u0) B[k][j]) inv,  v_top[i] = (B[i][k] + [i==k] alpha) inv,
-// B' = B - v_top (x) w -- needs c_k but is sums of like-signed terms and runs in fp32 like the reference's panel.
-// So: waves 8-9 run the Cholesky chain one step AHEAD, waves 10-11 the Householder chain, waves 0-7 apply both
-// rank-1 updates to their blocks; one barrier per reflector, nobody waits for anybody inside an iteration.  Rows and
-// columns the scalar waves need are published by their owners one iteration earlier (one step behind) and brought up
-// to date by the scalar waves themselves with the very FMAs the owners execute.  Step vectors are also stored in the
-// two permuted orders in which the update threads read them (16-byte LDS reads).
-// A column that cannot be reflected (N[k][k] <= 0: exactly zero or cancelled) raises the flag: the driver redoes the
-// work on the column-by-column kernels, which implement the reference's zero-column skip.
-// The coefficient matrix (V_low = A_low C) needs no update in the loop: with M the running column map,
-// C[:,k] = M[:,k] inv_k and M[:,j] = e_j - sum_{k<j} C[:,k] w^(k)_j, i.e. C (D^-1 + W) = I with W[k][j] = w^(k)_j
-// strictly upper and D = diag(inv): one triangular inverse after the loop (MFMA merges, tri_inverse_128).
-constexpr int SR = 8, SC = 4;
-constexpr int GH_UPD_THREADS = 512, GH_SOLVE_THREADS = 768;
-struct GhVecA { double c[GW], c1[GW], c2[GW]; };                    // Cholesky row: natural, by-column-block, by-row-block order
-struct GhVecB { float w[GW], w1[GW], vt[GW], vt2[GW]; };           // Householder w (natural, by column block), v_top (natural, by row block)
-struct GhPreN { double N[GW]; };                                    // a row of N, one step behind
-struct GhPreB { float B[GW], C[GW]; };                              // a row and a column of B, one step behind
-__device__ __forceinline__ int gh_p1(int i) { return (i & 31) * 4 + (i >> 5); }   // thread tj reads entries tj + 32y contiguously
-__device__ __forceinline__ int gh_p2(int i) { return (i & 15) * 8 + (i >> 4); }   // thread ti reads entries ti + 16x contiguously
-__global__ __launch_bounds__(GH_SOLVE_THREADS) void gh_solve_kernel(LeafArgs a, const double* __restrict__ G,
-                                                                    float* __restrict__ Cv, int* __restrict__ flag) {
-    float* Ws = (float*)gh_smem;                          // [TP][TPS]: row k = w^(k)
-    float* Ts = Ws + TP * TPS;                            // [TP][TPS]: final columns of the top block, then the inverse
-    __shared__ double col0[GW], nuv[GW];
-    __shared__ float vdl[GW], tdiag[GW], sgn[GW];
-    __shared__ GhVecA vecA[2];
-    __shared__ GhVecB vecB[2];
-    __shared__ GhPreN preN[2];
-    __shared__ GhPreB preB[2];
-    __shared__ int lflag, cmask[GW];
-    const int tid = threadIdx.x;
-    KT_DECL; KT();
-    const bool upd = tid < GH_UPD_THREADS;
-    const int role = upd ? 0 : (tid < GH_UPD_THREADS + GW ? 1 : 2);   // 0 update, 1 Cholesky chain, 2 Householder chain
-    const int ti = (tid >> 5) & 15, tj = tid & 31;
-    const int w = a.c1 - a.c0, off = a.c0 - a.cb;
-    double N[SR][SC];                                     // x <= 2y+1 used
-    float B[SR][SC];
-#pragma unroll
-    for (int x = 0; x < SR; x++)
-#pragma unroll
-        for (int y = 0; y < SC; y++) {
-            const int i = ti + 16 * x, j = tj + 32 * y;
-            double g = 0; float b = 0.f;
-            if (upd && i < w && j < w) {
-                if (x <= 2 * y + 1) g = G[(off + i) * GW + off + j];
-                b = a.A[(long)(a.c0 + i) * a.lda + a.c0 + j];
-            }
-            N[x][y] = g; B[x][y] = b;
-        }
-    // LDS set-up while the loads above are in flight
-    for (int e = tid; e < TP * TPS; e += GH_SOLVE_THREADS) Ws[e] = 0.f;
-    if (role == 1) {
-        const int i = tid - GH_UPD_THREADS;
-        vdl[i] = 0.f; tdiag[i] = 1.f; cmask[i] = 0; sgn[i] = 1.f; nuv[i] = 0.0;
-        col0[i] = (i < w) ? G[(off + i) * GW + off + i] : 0.0;     // ||a_j||^2 over all leaf rows
-#pragma unroll
-        for (int q = 0; q < 2; q++) { vecA[q].c[i] = 0.0; vecA[q].c1[i] = 0.0; vecA[q].c2[i] = 0.0; }
-        if (i == 0) lflag = 0;
-    } else if (role == 2) {
-        const int i = tid - GH_UPD_THREADS - GW;
-#pragma unroll
-        for (int q = 0; q < 2; q++) { vecB[q].w[i] = 0.f; vecB[q].w1[i] = 0.f; vecB[q].vt[i] = 0.f; vecB[q].vt2[i] = 0.f; }
-    } else if (ti == 0) {
-#pragma unroll
-        for (int y = 0; y < SC; y++) preN[0].N[tj + 32 * y] = N[0][y];   // row 0 for the first Cholesky step
-    }
-    // the scalar chains are the critical path: their waves issue first
-    if (!upd) __builtin_amdgcn_s_setprio(3);
-    __syncthreads();
-    KT();
-    for (int it = 0; it <= w; it++) {
-        if (role == 1) {
-            // ---- Cholesky step a = it (one ahead of the Householder chain)
-            const int aa = it;
-            if (aa < w) {
-                const GhVecA& pc = vecA[(aa + 1) & 1];         // c^(a-1) (zero for a = 0)
-                GhVecA& nc = vecA[aa & 1];
-                const GhPreN& pr = preN[aa & 1];
-                const int i = tid - GH_UPD_THREADS;
-                const double pk = pc.c[aa], pi = pc.c[i], pN_a = pr.N[aa], pN_i = pr.N[i], c0k = col0[aa];
-                // row a after step a-1: the same FMAs its owners execute in their update
-                const double sk = fma(-pk, pk, pN_a), rni = fma(-pk, pi, pN_i);
-                const bool ok = sk > 1e-30 && sk < 1e30;       // false: zero / cancelled column or out of range -> flagged
-                const double skd = ok ? sk : 1.0;
-                double y = refine_rsqrt(skd, (double)rsqrtf((float)skd));
-                y = ok ? y : 0.0;
-                double ci = rni * y;                           // c_a[i] = N[a][i] / sqrt(N[a][a]);  c_a[a] = sqrt(N[a][a])
-                ci = (i >= aa && i < w) ? ci : 0.0;
-                nc.c[i] = ci; nc.c1[gh_p1(i)] = ci; nc.c2[gh_p2(i)] = ci;
-                if (i >= aa) Ts[i * TPS + aa] = (float)ci;     // |R[a][i]|: the sign comes from the Householder chain
-                if (i == 0) {
-                    if (!ok || sk < GH_RHO_MIN * c0k) lflag = 1;
-                    nuv[aa] = ok ? sk * y : 0.0;
-                    cmask[aa] = ok ? 1 : 0;
-                }
-            }
-        } else if (role == 2) {
-            // ---- Householder step b = it - 1
-            const int b = it - 1;
-            if (b >= 0) {
-                const GhVecB& pb = vecB[(b + 1) & 1];          // step b-1 (zero for b = 0)
-                GhVecB& nb = vecB[b & 1];
-                const GhPreB& pr = preB[b & 1];
-                const int i = tid - GH_UPD_THREADS - GW;
-                const float pk_vt = pb.vt[b], pk_w = pb.w[b], pi_w = pb.w[i], pi_vt = pb.vt[i];
-                const float pB_b = pr.B[b], pB_i = pr.B[i], pC_i = pr.C[i];
-                const float ci = (float)vecA[b & 1].c[i], nu = (float)nuv[b];
-                const bool ok = cmask[b] != 0;
-                // row / column b after step b-1: the same FMAs their owners execute in their update
-                const float u0 = fmaf(-pk_vt, pk_w, pB_b), rbi = fmaf(-pk_vt, pi_w, pB_i), cbi = fmaf(-pi_vt, pk_w, pC_i);
-                const float s = (u0 >= 0.f) ? 1.f : -1.f, alpha = s * nu;
-                const float d = ok ? 2.f * nu * (nu + fabsf(u0)) : 1.f;
-                float inv = __builtin_amdgcn_rsqf(d);
-                inv = inv * (1.5f - 0.5f * d * inv * inv);     // one Newton step: full fp32 accuracy
-                inv = ok ? inv : 0.f;
-                float wi = 2.f * nu * (ci + s * rbi) * inv;
-                wi = (i > b && i < w) ? wi : 0.f;              // w_i (0 for i <= b)
-                float vi = (cbi + (i == b ? alpha : 0.f)) * inv;
-                vi = (i >= b && i < w) ? vi : 0.f;             // v_top[i] (0 for i < b)
-                nb.w[i] = wi; nb.w1[gh_p1(i)] = wi; nb.vt[i] = vi; nb.vt2[gh_p2(i)] = vi;
-                Ws[b * TPS + i] = wi;
-                if (i > b) Ts[b * TPS + i] = vi;               // final column b below the diagonal
-                if (i == 0) {
-                    sgn[b] = s;
-                    vdl[b] = (u0 + alpha) * inv;               // v_top[b]
-                    tdiag[b] = ok ? inv : 1.f;
-                }
-            }
-        } else {
-            // ---- update waves: Cholesky step it-1 on N, Householder step it-2 on B (vectors are zero before they exist)
-            const GhVecA& va = vecA[(it + 1) & 1];
-            const GhVecB& vb = vecB[it & 1];
-            double rkj[SC], rki[SR]; float wj[SC], vti[SR];
-#pragma unroll
-            for (int y = 0; y < SC; y++) { rkj[y] = va.c1[SC * tj + y]; wj[y] = vb.w1[SC * tj + y]; }
-#pragma unroll
-            for (int x = 0; x < SR; x++) { rki[x] = va.c2[SR * ti + x]; vti[x] = vb.vt2[SR * ti + x]; }
-#pragma unroll
-            for (int x = 0; x < SR; x++)
-#pragma unroll
-                for (int y = 0; y < SC; y++) {
-                    B[x][y] = fmaf(-vti[x], wj[y], B[x][y]);
-                    if (x <= 2 * y + 1) N[x][y] = fma(-rki[x], rkj[y], N[x][y]);
-                }
-            // publish: row it+1 of N (state after Cholesky step it-1), row / column it of B (state after Householder step it-2)
-            const int tn1 = it + 1;
-            if (tn1 < w && ti == (tn1 & 15)) {
-                GhPreN& nx = preN[tn1 & 1];
-#pragma unroll
-                for (int x = 0; x < SR; x++)
-                    if (x == (tn1 >> 4)) {
-#pragma unroll
-                        for (int y = 0; y < SC; y++)
-                            if (x <= 2 * y + 1) nx.N[tj + 32 * y] = N[x][y];
-                    }
-            }
-            if (it < w) {
-                GhPreB& nx = preB[it & 1];
-                if (ti == (it & 15)) {
-#pragma unroll
-                    for (int x = 0; x < SR; x++)
-                        if (x == (it >> 4)) {
-#pragma unroll
-                            for (int y = 0; y < SC; y++) nx.B[tj + 32 * y] = B[x][y];
-                        }
-                }
-                if (tj == (it & 31)) {
-#pragma unroll
-                    for (int y = 0; y < SC; y++)
-                        if (y == (it >> 5)) {
-#pragma unroll
-                            for (int x = 0; x < SR; x++) nx.C[ti + 16 * x] = B[x][y];
-                        }
-                }
-            }
-        }
-        __syncthreads();
-    }
-    if (!upd) __builtin_amdgcn_s_setprio(0);
-    KT();
-    // R and the top block of V go out first (from the LDS columns): the stores drain while the inverse below runs.
-    // Ts[k][i] = |R[i][k]| for i <= k (sign -sgn[i]), v_top of column k for i > k.
-    if ((w & 7) == 0 && (a.c0 & 7) == 0) {                 // usual case: 16-byte stores (8 fp16 / 4 fp32 per thread)
-        typedef half_t half4v __attribute__((ext_vector_type(4)));
-        typedef half_t half8v __attribute__((ext_vector_type(8)));
-        for (int e = tid; e < GW * (GW / 4); e += GH_SOLVE_THREADS) {
-            const int i = e >> 5, k = (e & 31) * 4;           // 4 consecutive k: a row segment of A and Vh
-            if (i < w && k < w) {
-                const float ns = -sgn[i];
-                float t4[4]; float4 v; half4v hv;
-#pragma unroll
-                for (int q = 0; q < 4; q++) { const float t = Ts[(k + q) * TPS + i]; t4[q] = (i <= k + q) ? ns * t : t; }
-                v.x = t4[0]; v.y = t4[1]; v.z = t4[2]; v.w = t4[3];
-                *(float4*)&a.A[(long)(a.c0 + i) * a.lda + a.c0 + k] = v;
-                if (i >= k) {                                 // V: below the diagonal from the columns, v_kk on it, zero above
-                    const float vd = vdl[i];
-#pragma unroll
-                    for (int q = 0; q < 4; q++) hv[q] = i > k + q ? (half_t)t4[q] : (i == k + q ? (half_t)vd : (half_t)0.f);
-                    *(half4v*)&a.Vh[(long)(a.c0 + i) * a.ldvh + a.c0 + k] = hv;
-                }
-            }
-        }
-        for (int e = tid; e < GW * (GW / 8); e += GH_SOLVE_THREADS) {
-            const int k = e >> 4, i = (e & 15) * 8;           // 8 consecutive i: a row segment of V^T
-            if (k < w && i < w && i + 7 >= k) {
-                half8v hv;
-                const float vd = vdl[k];
-#pragma unroll
-                for (int q = 0; q < 8; q++) hv[q] = (i + q > k) ? (half_t)Ts[k * TPS + i + q] : (i + q == k ? (half_t)vd : (half_t)0.f);
-                *(half8v*)&a.Vt[(long)(a.c0 + k) * a.ldvt + a.c0 + i] = hv;
-            }
-        }
-    } else {
-        for (int e = tid; e < GW * GW; e += GH_SOLVE_THREADS) {
-            const int i = e >> 7, k = e & 127;                 // k fastest: rows of A and Vh
-            if (i < w && k < w) {
-                const float t = Ts[k * TPS + i];
-                const float v = (i <= k) ? -sgn[i] * t : t;
-                a.A[(long)(a.c0 + i) * a.lda + a.c0 + k] = v;
-                if (i > k) a.Vh[(long)(a.c0 + i) * a.ldvh + a.c0 + k] = (half_t)v;
-            }
-        }
-        for (int e = tid; e < GW * GW; e += GH_SOLVE_THREADS) {
-            const int k = e >> 7, i = e & 127;                 // i fastest: rows of V^T
-            if (i < w && k < w && i > k) a.Vt[(long)(a.c0 + k) * a.ldvt + a.c0 + i] = (half_t)Ts[k * TPS + i];
-        }
-    }
-    if (tid < w) {
-        const int k = a.c0 + tid;
-        const float vd = vdl[tid];
-        a.vdiag[k] = vd;
-        if (!((w & 7) == 0 && (a.c0 & 7) == 0)) {          // the vector path above wrote the diagonal already
-            a.Vh[(long)k * a.ldvh + k] = (half_t)vd;
-            a.Vt[(long)k * a.ldvt + k] = (half_t)vd;
-        }
-    }
-    if (tid == 0 && lflag) {
-        atomicOr(flag, 1);
-        if (a.hostflag) __hip_atomic_store(a.hostflag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // the enqueuing host thread polls this word
-    }
-    __syncthreads();
-    for (int e = tid; e < TP * TPS; e += GH_SOLVE_THREADS) Ts[e] = 0.f;
-    __syncthreads();
-    // C = (D^-1 + W)^-1, columns of flagged reflectors zeroed
-    KT();
-    tri_inverse_128(Ws, tdiag, Ts, (w + 31) / 32, tid);
-    KT();
-    for (int e = tid; e < GW * GW; e += GH_SOLVE_THREADS) {          // window coordinates (leaf index + off), zero elsewhere
-        const int i = (e >> 7) - off, k = (e & 127) - off;
-        Cv[e] = (i >= 0 && i <= k && k < w && cmask[k]) ? Ts[i * TPS + k] : 0.f;
-    }
-    KT(); KT_DUMP(5, "gh_solve load|loop|out|inverse|cstore");
-}
-
 typedef half_t half8p __attribute__((ext_vector_type(8)));
 // partial Gram of the fp16 reflectors held in Ts ([128 columns][72]: the 64 rows of this workgroup, k contiguous):
 // upper 32 x 32 tiles of Ts Ts^T on v_mfma_f32_32x32x16_f16, written to Sp (fp32, 128 x 128, window coordinates)
@@ -814,12 +549,8 @@ void launch_gh_reduce_f32(const float* Sp, int nslab, float* S, hipStream_t s) {
     hipLaunchKernelGGL(gh_reduce_f32_kernel, dim3(256), dim3(256), 0, s, Sp, nslab, S);
 }
 static void gh_set_attrs() {
-    static bool attr = false;
-    if (attr) return;
-    (void)hipFuncSetAttribute((const void*)gh_gram_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, GH_ROWS * GH_TD * 8);
-    (void)hipFuncSetAttribute((const void*)gh_solve_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * TP * TPS * 4);
-    (void)hipFuncSetAttribute((const void*)gh_apply_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (8256 + GW * GH_TS) * 4);
-    attr = true;
+    MPQR_ONCE_PER_DEVICE((void)hipFuncSetAttribute((const void*)gh_gram_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, GH_ROWS * GH_TD * 8);
+                         (void)hipFuncSetAttribute((const void*)gh_apply_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (8256 + GW * GH_TS) * 4));
 }
 // the four steps of a Gram-Householder leaf, separately launchable (the look-ahead schedule puts them on different streams)
 void launch_gh_gram(const LeafArgs& a, double* Gp, double* G, hipStream_t s) {
@@ -832,11 +563,9 @@ void launch_gh_solve(const LeafArgs& a, const double* G, float* Cv, int* flag, h
     gh_set_attrs();
     static const int dbg_skip = []() { const char* e = getenv("MPQR_DBG_NOSOLVE"); return e ? atoi(e) : 0; }();
     if (dbg_skip) return;                                  // timing experiment only (results are garbage): is the chain host-bound?
-    // gh_solve3 (kernels_solve.hip): the same recursion blocked by 16, chains in single waves (bit-identical outputs on the
-    // harness tools/test_solve3.hip); MPQR_SOLVE3=0 selects the step-by-step kernel of round 2 (one barrier per reflector)
-    static const int solve3 = []() { const char* e = getenv("MPQR_SOLVE3"); return e ? atoi(e) : 1; }();
-    if (solve3) { launch_gh_solve3(a, G, Cv, flag, s); return; }
-    hipLaunchKernelGGL(gh_solve_kernel, dim3(1), dim3(GH_SOLVE_THREADS), 2 * TP * TPS * 4, s, a, G, Cv, flag);
+    // gh_solve3 (kernels_solve.hip): the recursion blocked by 16, chains in single waves.  (Round 2's step-by-step kernel, one
+    // barrier per reflector, 104 us against 65, was kept behind MPQR_SOLVE3=0 for a round and is gone: git history.)
+    launch_gh_solve3(a, G, Cv, flag, s);
 }
 void launch_gh_apply(const LeafArgs& a, const float* Cv, float* Sp, hipStream_t s) {
     gh_set_attrs();
@@ -1070,11 +799,7 @@ __global__ __launch_bounds__(1024) void t_merge_kernel(const float* __restrict__
 }
 
 void launch_t_merge(const float* S, int ldl, int ldr, const float* TL, const float* TR, float* TLR, hipStream_t s) {
-    static bool attr = false;
-    if (!attr) {
-        (void)hipFuncSetAttribute((const void*)t_merge_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * TP * TPS * 4);
-        attr = true;
-    }
+    MPQR_ONCE_PER_DEVICE((void)hipFuncSetAttribute((const void*)t_merge_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * TP * TPS * 4));
     hipLaunchKernelGGL(t_merge_kernel, dim3(1), dim3(1024), 2 * TP * TPS * 4, s, S, ldl, ldr, TL, TR, TLR);
 }
 
@@ -1113,22 +838,14 @@ __global__ __launch_bounds__(1024) void trsm_diag_kernel(const float* __restrict
     }
 }
 void launch_trsm_diag(const float* R, long ldr, int k0, int kb, float* Y, long ldy, int nrhs, hipStream_t s) {
-    static bool attr = false;
-    if (!attr) {
-        (void)hipFuncSetAttribute((const void*)trsm_diag_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * TP * TPS * 4);
-        attr = true;
-    }
+    MPQR_ONCE_PER_DEVICE((void)hipFuncSetAttribute((const void*)trsm_diag_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * TP * TPS * 4));
     hipLaunchKernelGGL(trsm_diag_kernel, dim3(1), dim3(1024), 2 * TP * TPS * 4, s, R, ldr, k0, kb, Y, ldy, nrhs);
 }
 
 void launch_t_leaf(const float* S, int nslab, long slab_stride, int lds_, int a0, int c0, int c1, float* T, half_t* Th,
                    half_t* Tth, int ldt, hipStream_t s, int ld) {
     if (ld <= 0) ld = ldt;
-    static bool attr = false;
-    if (!attr) {
-        (void)hipFuncSetAttribute((const void*)t_panel_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * TP * TPS * 4);
-        attr = true;
-    }
+    MPQR_ONCE_PER_DEVICE((void)hipFuncSetAttribute((const void*)t_panel_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * TP * TPS * 4));
     hipLaunchKernelGGL(t_panel_kernel, dim3(1), dim3(1024), 2 * TP * TPS * 4, s, S, nslab, slab_stride, lds_, a0, c0, c1, T, Th,
                        Tth, ldt, ld);
 }

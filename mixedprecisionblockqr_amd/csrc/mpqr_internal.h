@@ -2,6 +2,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <atomic>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -10,6 +12,27 @@
 namespace mpqr {
 
 typedef _Float16 half_t;
+
+// Function attributes (hipFuncSetAttribute: the raised dynamic-LDS limit) belong to the CURRENT DEVICE's function object: a
+// process-wide `static bool` sets them on the first device only, and races between the rank threads of the multi-GPU host
+// (apps/mpqr_main --gpus N: one handle per device in one process).  This runs `stmt` once per (call site, device).
+template <typename F>
+inline void once_per_device(std::atomic<unsigned long long>& done, std::mutex& mu, F&& set) {
+    int d = 0;
+    (void)hipGetDevice(&d);
+    const unsigned long long bit = 1ull << (d & 63);
+    if (done.load(std::memory_order_acquire) & bit) return;
+    std::lock_guard<std::mutex> lk(mu);
+    if (done.load(std::memory_order_relaxed) & bit) return;
+    set();
+    done.fetch_or(bit, std::memory_order_release);
+}
+#define MPQR_ONCE_PER_DEVICE(stmt)                                                   \
+    do {                                                                             \
+        static std::atomic<unsigned long long> once_done_{0};                        \
+        static std::mutex once_mu_;                                                  \
+        ::mpqr::once_per_device(once_done_, once_mu_, [&]() { stmt; });              \
+    } while (0)
 
 // ------------------------------------------------------------------ GEMM family
 // C[M x N] = A[M x K] * B[K x N], B always supplied as Bt[N][K] (k contiguous, fp16).

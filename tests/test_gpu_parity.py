@@ -330,7 +330,7 @@ def test_rank_deficient_jacobian_takes_the_per_leaf_fallback(mp, h, po):
     # the cost of the fallback is stated structurally (the wall-clock ratio above is printed, never asserted: it is host-paced at this
     # size and varies with the box): ONE robust leaf, ONE restart, and the restarted pass re-runs at most the leaves of its own block
     # onwards -- the leaves the first pass launched before the flag was seen are the only other extra work
-    assert t7["n_robust_leaves"] == 1, t7                    # only the first flagged leaf is believed
+    assert 1 <= t7["n_robust_leaves"] <= 2, t7               # the flagged leaf (+ at most a flagged neighbour in the same block: believed together)
     assert t7["n_gh_leaves"] <= 2 * t0["n_gh_leaves"], (t0, t7)
 
 
@@ -351,7 +351,7 @@ def test_flagged_leaf_restarts_from_its_block(mp, po, at, block):
     ms7, t7, mt7, R = _best_factor_ms(mp, M, 128, outer_block=512)
     for mt in (mt0, mt7):
         assert mt["backward_error"] <= 1e-3 and mt["q_error_fro"] <= 2e-3 * np.sqrt(m), mt
-    assert t0["n_passes"] == 1 and t7["n_passes"] == 2 and t7["n_robust_leaves"] == 1, (t0, t7)
+    assert t0["n_passes"] == 1 and t7["n_passes"] == 2 and 1 <= t7["n_robust_leaves"] <= 2, (t0, t7)
     assert t7["restart_block"] == block, t7                   # outer block 512: the block of column `at`, not always block 0
     d = np.abs(np.diag(R))
     assert d[[at + 12 * q + 7 for q in range(7)]].max() <= 1e-3 * np.median(d)       # the dependent columns show in R
@@ -361,6 +361,36 @@ def test_flagged_leaf_restarts_from_its_block(mp, po, at, block):
     # for a late block, and the restarted pass starts at `block`
     per_block, nblocks = 512 // 128, n // 512
     assert t7["n_gh_leaves"] <= t0["n_gh_leaves"] + (nblocks - block) * per_block, (t0, t7)     # pass 1 (at most everything) + blocks `block`..end
+
+
+@pytest.mark.parametrize("spread", ["leaves", "blocks"])
+def test_dependent_columns_spread_over_leaves_and_blocks(mp, spread):
+    """A gauge-deficient Jacobian spreads its dependent columns (the reference skips such columns in line, Cuda/qr.cu:242-244, at no
+    extra cost).  6144 x 4096, outer block 512 (8 blocks of 4 leaves), exactly dependent pairs (column c + 7 = half of column c + 2:
+    a power of two commutes with every rounding, so the pair is still exactly dependent when its leaf is reached) in three leaves
+    of ONE block / in one leaf of each of THREE blocks.  Every flagged leaf of the first flagged block is believed in one pass and
+    the pass restarts at that block: n_passes <= 1 + (blocks holding flagged leaves), each flagged leaf takes the robust path once."""
+    m, n, ob = 6144, 4096, 512
+    M = np.random.default_rng(6).random((m, n), dtype=np.float32)
+    leaf_starts = [0, 128, 256] if spread == "leaves" else [0, 3 * ob + 128, 7 * ob]
+    for c in leaf_starts:
+        for q in range(3):
+            M[:, c + 12 * q + 7] = 0.5 * M[:, c + 12 * q + 2]
+    hh = mp.Handle(0)
+    try:
+        hh.plan(m, n, 128, outer_block=ob)
+        hh.set_matrix(M); hh.factor(); hh.sync()
+        t, mt, R = hh.timings(), hh.metrics(), hh.r_matrix()
+    finally:
+        hh.close()
+    assert mt["backward_error"] <= 1e-3 and mt["q_error_fro"] <= 2e-3 * np.sqrt(m), mt
+    blocks = sorted({c // ob for c in leaf_starts})
+    assert 2 <= t["n_passes"] <= 1 + len(blocks), t
+    assert len(leaf_starts) <= t["n_robust_leaves"] <= len(leaf_starts) + len(blocks), t     # (a neighbour of a flagged leaf may be taken along)
+    assert t["restart_block"] == blocks[-1], t
+    d = np.abs(np.diag(R))
+    dep = [c + 12 * q + 7 for c in leaf_starts for q in range(3)]
+    assert d[dep].max() <= 1e-3 * np.median(d)                 # every dependent column shows in R
 
 
 @pytest.mark.baseline(2)
@@ -762,28 +792,20 @@ def test_distributed_schedule_on_one_gpu(mp, po, m, n, r, ko, world, la):
 # produce the same factorisation.  The switches are read once per process, hence one child interpreter per setting.
 OPT_IN = [
     {},                                            # the default path, the others are compared with it
-    {"MPQR_SOLVE3": "0"},                          # step-by-step leaf solve of round 2 (one barrier per reflector)
     {"MPQR_GEMM6": "0"},                           # register-staged 256-tile kernel instead of the LDS-DMA ping-pong one
-    {"MPQR_FLAT": "0"},                            # tree schedule inside a block
     {"MPQR_TSTREAM": "0"},                         # compact-WY T on the chain stream
     {"MPQR_EXT_LOOKAHEAD": "0"},                   # block boundary: first leaf of the next block through the far update
-    {"MPQR_ASHADOW": "1"},                         # fp16 shadow of the trailing matrix for the far updates' X = A2^T V
     {"MPQR_QSHADOW": "0", "MPQR_QPAIR": "0"},      # Q formation block by block from the fp32 Q (round-1 form)
-    {"MPQR_FUSE_XT": "0", "MPQR_SPLIT_CAP": "64"}, # in-block update with a separate slab sum and small GEMM
-    {"MPQR_XSPLIT": "0"},                          # X rounded once to fp16 between the two GEMMs of an update (round 1)
     {"MPQR_QSPLIT": "1"},                          # hi + lo parts of X in Q formation as well
-    {"MPQR_X16": "0"},                             # fp32 X through memory, split while staged (gemm2 A_F32S)
     {"MPQR_FAR_PAIR": "0"},                        # far updates block by block (K = outer block) instead of pairwise
     {"MPQR_ASHADOW": "1", "MPQR_FAR_PAIR": "1"},   # pairwise far updates reading the fp16 shadow of the trailing matrix
-    # round 3
     {"MPQR_EXT_LEAVES": "1"},                      # block boundary: the in-block updates reach ONE leaf of the next block (round 2)
-    {"MPQR_EXT_LEAVES": "3"},                      # ... three leaves (two deferred updates on the T stream per boundary)
     {"MPQR_DEFER_FAR": "0"},                       # far update enqueued at the block's end instead of behind the next block's first gh_gram
     {"MPQR_LEAF_LA": "1"},                         # leaf-level look-ahead: every leaf's update of the rest of its block on the T stream
-    {"MPQR_TCOL_KSPLIT": "0"},                     # exact-f32 products of the block T and of the pair merges in one K range
-    {"MPQR_FAR_TN_SPLIT": "4"},                    # big far X = C2^T V GEMMs split over four K slabs
     {"MPQR_RESTART": "0", "MPQR_WATCH_FLAGS": "0"},   # robust fallback as in round 2 (no early stop, every pass from block 0)
 ]
+# (round 4: the variants that lost for two rounds are gone with their code -- MPQR_SOLVE3=0, MPQR_FLAT=0, MPQR_FUSE_XT=0, MPQR_X16=0,
+#  MPQR_XSPLIT=0, plain MPQR_ASHADOW=1, MPQR_EXT_LEAVES=3, MPQR_TCOL_KSPLIT=0, MPQR_FAR_TN_SPLIT)
 
 
 @pytest.mark.gpu
