@@ -72,19 +72,40 @@ def cpu_baseline_port():
             "sample": f"{m}x{n} r={r} fp32 compact-WY block loop incl. Q formation, {dt:.1f} s, GEQRF-equivalent flops"}
 
 
+def gemm_source_sha():
+    """sha256 (16 hex digits) of the sources the dominant GEMM kernel is built from: ties a committed PMC profile to a build."""
+    import hashlib
+    hsh = hashlib.sha256()
+    for f in ("kernels_gemm2.hip", "gemm_epilogue.h", "mpqr_internal.h"):
+        with open(os.path.join(ROOT, "mixedprecisionblockqr_amd", "csrc", f), "rb") as fh:
+            hsh.update(fh.read())
+    return hsh.hexdigest()[:16]
+
+
 def _pmc_traffic():
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes of this same command
-    (profiles/, tools/pmc_traffic.py); PMC counters cannot be read from inside the timed run."""
+    (profiles/, tools/pmc_traffic.py); PMC counters cannot be read from inside the timed run.  Returns (bytes or None, source):
+    the figure is only quoted when the profile was taken on THIS build's GEMM sources (`kernel_source_sha` in the profile,
+    written by tools/collect_profiles.sh) -- a stale profile yields traffic = null and says why in `traffic_source`."""
     best = None
     pdir = os.path.join(ROOT, "profiles")
     if os.path.isdir(pdir):
         for f in sorted(os.listdir(pdir)):
             if f.endswith("traffic_far_nn.json"):
                 try:
-                    best = json.load(open(os.path.join(pdir, f)))["hbm_bytes_per_launch"]
+                    best = (f, json.load(open(os.path.join(pdir, f))))
                 except Exception:
                     pass
-    return best
+    if best is None:
+        return None, {"file": None, "note": "no PMC profile committed"}
+    f, d = best
+    sha = gemm_source_sha()
+    src = {"file": "profiles/" + f, "profile_kernel_source_sha": d.get("kernel_source_sha"), "build_kernel_source_sha": sha,
+           "how": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) of `python bench.py --steps 1 --warmup 0`, FETCH_SIZE x 2 (gfx950), per launch"}
+    if d.get("kernel_source_sha") != sha:
+        src["note"] = "profile taken on other GEMM sources than this build: not quoted"
+        return None, src
+    return d["hbm_bytes_per_launch"], src
 
 
 def main():
@@ -168,11 +189,13 @@ def main():
                  "gemm6_f16_kernel<E_SUB_F32> (C -= V*Y^T, fp16 x fp16 -> fp32: far trailing updates, K = 2 outer blocks beyond the next two blocks, and Q formation, K = 2 outer blocks)")
         roof = {"bound": "mfma", "kernel": kname,
                 "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
-                "traffic": _pmc_traffic() if (args.config == "c4" and not args.outer_block and prec_name == "fp16") else None, "launches": tm["n_far_launches"] + (tm.get("n_q_launches", 0) if q_nn else 0),
+                "traffic": None, "launches": tm["n_far_launches"] + (tm.get("n_q_launches", 0) if q_nn else 0),
                 "avg_launch_ms": (tm["ms_far_nn"] + (tm["ms_q_nn"] if q_nn else 0.0)) / (tm["n_far_launches"] + (tm.get("n_q_launches", 0) if q_nn else 0)),
                 "far_update_achieved": ach_far, "q_formation_achieved": q_nn,
                 "q_formation_tn_achieved": (tm["tflop_q"] / (tm["ms_q_tn"] * 1e-3)) if q_nn and tm["ms_q_tn"] > 0 else None,
                 "tn_achieved": (tm["flops_far_tn"] / (tm["ms_far_tn"] * 1e-3) / 1e12) if tm["ms_far_tn"] > 0 else None}
+        if args.config == "c4" and not args.outer_block and prec_name == "fp16":
+            roof["traffic"], roof["traffic_source"] = _pmc_traffic()
         # The far launches against the HBM roof: algorithmic bytes = fp32 C read + write (8 M N) + both fp16 operands once
         # (2 K (M + N)), summed by the library over the far updates it launched (pairs of blocks beyond the next two).
         alg = tm["gbytes_far_nn"] * 1e9

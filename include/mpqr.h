@@ -150,6 +150,14 @@ int mpqr_bench_leaf_solve(mpqr_handle_t h, int w, int iters, float* us_per_launc
  * mode:   0: C = A B,  2: C -= A B (read-modify-write epilogue; kernels 1, 6, 8; M % 32 == 0 -- the library's own callers pad the
  *         row count of the matrix being updated, the epilogue treats a 32-row sub-tile as valid or invalid as a whole). */
 int mpqr_gemm_test_f32(mpqr_handle_t h, const float* A, const float* B, float* C, int M, int N, int K, int kernel, int mode);
+/* measurement aid (bench.py --gemm, tools/bench_gemm.py): ONE of the large-shape GEMM kernels alone on the GPU, on device-resident random
+ * operands, `iters` launches between two HIP events on the handle's chain stream -> mean milliseconds per launch.  The kernel-alone
+ * rate next to the rate the same kernel reaches beside the panel chain (mpqr_get_timings) separates kernel quality from contention.
+ * kernel: 6 = ping-pong kernel, fp16 A[M][K] and Bt[N][K] by LDS-DMA; 2 = fp32 A stored [K][M], converted + transposed while staged
+ *         (the far X = A2^T V);  16 = kernel 6's loop on v_mfma_f32_16x16x32_f16 (experiment).
+ * mode:   0: C = A B (fp32 store), 1: fp16 store, 2: C -= A B (fp32 read-modify-write), 3: mode 2 + the transposed fp16 shadow store.
+ * M, N multiples of 256, K of 64.  Replaces nothing in the reference (its GEMM tests check values only, Cuda/mmult.cuh:387-435). */
+int mpqr_bench_gemm(mpqr_handle_t h, int kernel, int mode, int M, int N, int K, int iters, float* ms_per_launch);
 /* results: A_out is (m+1) x n in the reference's shifted-reflector layout, Q is m x m */
 int mpqr_get_factor_host(mpqr_handle_t h, float* A_out);
 int mpqr_get_q_host(mpqr_handle_t h, float* Q);

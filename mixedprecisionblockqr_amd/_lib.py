@@ -68,6 +68,7 @@ SIGNATURES = {
     "mpqr_get_timings": (_i, [_H, C.POINTER(MpqrTimings)]),
     "mpqr_bench_leaf_solve": (_i, [_H, _i, _i, C.POINTER(C.c_float)]),
     "mpqr_gemm_test_f32": (_i, [_H, _f32, _f32, _f32, _i, _i, _i, _i, _i]),
+    "mpqr_bench_gemm": (_i, [_H, _i, _i, _i, _i, _i, _i, C.POINTER(C.c_float)]),
     "mpqr_get_factor_host": (_i, [_H, _f32]),
     "mpqr_get_q_host": (_i, [_H, _f32]),
     "mpqr_get_r_host": (_i, [_H, _f32]),

@@ -76,6 +76,12 @@ class Handle:
         self._chk(L.lib().mpqr_get_timings(self._h, C.byref(t)))
         return {k: getattr(t, k) for k, _ in L.MpqrTimings._fields_ if k != "reserved"}
 
+    def bench_gemm(self, kernel, mode, M, N, K, iters=10):
+        """Mean ms per launch of one large-shape GEMM kernel alone on the GPU (include/mpqr.h: mpqr_bench_gemm)."""
+        ms = C.c_float()
+        self._chk(L.lib().mpqr_bench_gemm(self._h, kernel, mode, M, N, K, iters, C.byref(ms)))
+        return ms.value
+
     def bench_leaf_solve(self, w=128, iters=50):
         """Mean launch time (us) of the serial core of one Gram-Householder leaf of width w, timed alone."""
         us = C.c_float()

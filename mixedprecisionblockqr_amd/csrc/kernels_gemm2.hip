@@ -433,9 +433,14 @@ __device__ __forceinline__ void epilogue_sub_f32_dma(ACC (&acc)[4][2], char* sme
 //     tiles (48-64 KiB) are always in flight behind counted s_waitcnt vmcnt(8 / 6); the region a DMA overwrites was
 //     last read at least one full phase earlier by either group, and the data a phase reads was waited for by every
 //     wave before the barrier that precedes it.
-template <int EM, int DMA_EPI>
+// MF = 1 (experiment, mpqr_bench_gemm kernel 16): the same pipeline on v_mfma_f32_16x16x32_f16 -- a quadrant is 4 x 2 tiles of 16 x 16
+// over two K steps of 32 (16 MFMAs of 16 cycles instead of 8 of 32); fragment registers and LDS reads are the same in number, lane
+// l reads row l & 15, 16-byte chunk 4 ks + (l >> 4).  On random data the chip holds a higher clock on this shape
+// (MI355X_MICROARCH.md, DVFS give-back (7); tools/ubench_mfma.hip).  Store epilogues only.
+template <int EM, int DMA_EPI, int MF = 0>
 __global__ __launch_bounds__(512) void gemm6_f16_kernel(GemmArgs g, int tilesM, int tilesN) {
     using namespace g2;
+    typedef float floatx4 __attribute__((ext_vector_type(4)));
     constexpr int BM = 256, BN = 256, BK = 64;
     constexpr int ROWB = 128, A_BYTES = BM * ROWB, BUF = 2 * A_BYTES;
     auto swz = [](int r, int c) -> int { return r * ROWB + ((c ^ ((r >> 1) & 7)) << 4); };
@@ -497,20 +502,63 @@ __global__ __launch_bounds__(512) void gemm6_f16_kernel(GemmArgs g, int tilesM, 
 #pragma unroll
             for (int e = 0; e < 16; e++) acc[i][j][e] = 0.f;
 
+    floatx4 acc16[MF ? 8 : 1][MF ? 4 : 1];                    // MF = 1: [16-row tile][16-column tile] of the wave's 128 x 64
+    if (MF) {
+#pragma unroll
+        for (int i = 0; i < 8; i++)
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+#pragma unroll
+                for (int e = 0; e < 4; e++) acc16[MF ? i : 0][MF ? j : 0][e] = 0.f;
+    }
+    const int li = lane & 15, lk = lane >> 4;
     half8 af[4][2], b0a[4], b0b[4], b1[4];                    // A sub-tile fragments [k step][row tile]; B-S0 (two tiles), B-S1
+    // (MF = 1: af[2 ks2 + (i4 >> 1)][i4 & 1] = row tile i4 of 16, K step ks2 of 32;  b[2 ks2 + j2] = column tile j2 of 16)
     auto read_A = [&](const char* As, int sub) {
+        if (MF) {
+#pragma unroll
+            for (int ks2 = 0; ks2 < 2; ks2++)
+#pragma unroll
+                for (int i4 = 0; i4 < 4; i4++) af[2 * ks2 + (i4 >> 1)][i4 & 1] = *(const half8*)(As + swz(wm + sub * 64 + i4 * 16 + li, ks2 * 4 + lk));
+            return;
+        }
 #pragma unroll
         for (int ks = 0; ks < 4; ks++)
 #pragma unroll
             for (int i2 = 0; i2 < 2; i2++) af[ks][i2] = *(const half8*)(As + swz(wm + sub * 64 + i2 * 32 + r, ks * 2 + h));
     };
     auto read_B = [&](const char* Bs, int sub, half8 (&b)[4]) {
+        if (MF) {
+#pragma unroll
+            for (int ks2 = 0; ks2 < 2; ks2++)
+#pragma unroll
+                for (int j2 = 0; j2 < 2; j2++) b[2 * ks2 + j2] = *(const half8*)(Bs + swz(wn + sub * 32 + j2 * 16 + li, ks2 * 4 + lk));
+            return;
+        }
 #pragma unroll
         for (int ks = 0; ks < 4; ks++) b[ks] = *(const half8*)(Bs + swz(wn + sub * 32 + r, ks * 2 + h));
     };
     // MFMA half phase: 8 MFMAs with the two LDS-DMAs of one half tile issued in their shadow (after the 3rd and 6th)
     auto mma = [&](int subA, int subB, const half8 (&b)[4], int tau, int sidx) {
         __builtin_amdgcn_s_setprio(1);
+        if (MF) {
+#pragma unroll
+            for (int ks2 = 0; ks2 < 2; ks2++)
+#pragma unroll
+                for (int i4 = 0; i4 < 4; i4++)
+#pragma unroll
+                    for (int j2 = 0; j2 < 2; j2++)
+                        acc16[MF ? subA * 4 + i4 : 0][MF ? subB * 2 + j2 : 0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(
+                            af[2 * ks2 + (i4 >> 1)][i4 & 1], b[2 * ks2 + j2], acc16[MF ? subA * 4 + i4 : 0][MF ? subB * 2 + j2 : 0], 0, 0, 0);
+            issue(tau, sidx);
+            __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);
+            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);
+            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+            __builtin_amdgcn_s_setprio(0);
+            return;
+        }
 #pragma unroll
         for (int ks = 0; ks < 4; ks++)
 #pragma unroll
@@ -588,6 +636,25 @@ __global__ __launch_bounds__(512) void gemm6_f16_kernel(GemmArgs g, int tilesM, 
     if (kt_on) kt1 = clock64();
 #endif
     const float alpha = g.alpha;
+    if (MF) {                                               // 16 x 16 accumulator tiles: column = lane & 15, rows 4 (lane >> 4) + e
+#pragma unroll
+        for (int i = 0; i < 8; i++)
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int n = bn + wn + j * 16 + li;
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    const int m = bm + wm + i * 16 + 4 * lk + e;
+                    if (m < g.M && n < g.N) {
+                        const float v = alpha * acc16[MF ? i : 0][MF ? j : 0][e];
+                        if (EM == E_STORE_H16) ((half_t*)g.C)[(long)m * g.ldc + n] = (half_t)v;
+                        else if (EM == E_SUB_F32) ((float*)g.C)[(long)m * g.ldc + n] -= v;
+                        else ((float*)g.C)[(long)m * g.ldc + n] = v;
+                    }
+                }
+            }
+        return;
+    }
     if (EM == E_SUB_F32) {
         const bool full = DMA_EPI && bm + BM <= g.M && bn + BN <= g.N && bn >= g.col_lo;      // uniform over the workgroup
         if (full) {
@@ -628,19 +695,25 @@ __global__ __launch_bounds__(512) void gemm6_f16_kernel(GemmArgs g, int tilesM, 
         }
 }
 
-template <int EM, int DMA_EPI>
+template <int EM, int DMA_EPI, int MF = 0>
 static void launch6(const GemmArgs& g, hipStream_t s) {
     constexpr int LDS = 2 * 2 * 256 * 128;
-    MPQR_ONCE_PER_DEVICE((void)hipFuncSetAttribute((const void*)gemm6_f16_kernel<EM, DMA_EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+    MPQR_ONCE_PER_DEVICE((void)hipFuncSetAttribute((const void*)gemm6_f16_kernel<EM, DMA_EPI, MF>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
     const int tilesM = (g.M + 255) / 256, tilesN = (g.N + 255) / 256;
     const int groups = ((tilesM + 3) / 4) * ((tilesN + 7) / 8);
-    hipLaunchKernelGGL((gemm6_f16_kernel<EM, DMA_EPI>), dim3(groups * 32), dim3(512), LDS, s, g, tilesM, tilesN);
+    hipLaunchKernelGGL((gemm6_f16_kernel<EM, DMA_EPI, MF>), dim3(groups * 32), dim3(512), LDS, s, g, tilesM, tilesN);
 }
 
 // Large-shape path.  Preconditions (checked by the caller, driver.hip): no split-K, K % 64 == 0, and the
 // operand buffers are readable up to the next multiple of 256 rows (tiles are loaded unmasked; rows past M / N
 // only feed outputs that the epilogue masks).  config: 0 = 256x256x64 / 512 threads, 1 = 256x128x32 / 256 threads.
 bool launch_gemm2_f16(AMode am, EMode em, const GemmArgs& g, hipStream_t s, int config) {
+    if (am == A_H16 && config == 16 && (g.K % 64) == 0 && !g.Ct && !g.A2 && !g.C2 && !g.cscale && !g.eye_minus) {   // experiment: 16x16x32 MFMA shape
+        if (em == E_SUB_F32) { launch6<E_SUB_F32, 0, 1>(g, s); return true; }
+        if (em == E_STORE_F32) { launch6<E_STORE_F32, 0, 1>(g, s); return true; }
+        if (em == E_STORE_H16) { launch6<E_STORE_H16, 0, 1>(g, s); return true; }
+        return false;
+    }
     if (am == A_H16 && config != 2 && config != 1) {          // config 2 keeps the register-staged kernel (A/B comparison)
         static const int dma_epi = []() { const char* e = getenv("MPQR_DMA_EPILOGUE"); return e ? atoi(e) : 1; }();
         static const int use6 = []() { const char* e = getenv("MPQR_GEMM6"); return e ? atoi(e) : 1; }();

@@ -48,6 +48,13 @@ def main():
         "hbm_bytes_per_launch": (2.0 * sum(f) / max(len(f), 1) + sum(w) / max(len(w), 1)) * 1024.0,
         "note": "FETCH_SIZE doubled (gfx950 reports half of wide coalesced reads); one factorisation of 16384x16384, r=128",
     }
+    try:                                                       # ties the profile to the build it was taken on (bench.py: roofline.traffic_source)
+        import os
+        sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        import bench
+        out["kernel_source_sha"] = bench.gemm_source_sha()
+    except Exception:
+        pass
     print(json.dumps(out, indent=1))
     if len(sys.argv) > 4:
         json.dump(out, open(sys.argv[4], "w"), indent=1)
