@@ -117,6 +117,7 @@ def main():
     ap.add_argument("--outer-block", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-dropin", action="store_true", help="skip the PCIe-inclusive timing of the drop-in call (dropin_ms)")
+    ap.add_argument("--no-alone", action="store_true", help="skip the kernel-alone / MFMA-rate context measurements (roofline.mfma_measured, .kernel_alone)")
     ap.add_argument("--no-lookahead", action="store_true")
     ap.add_argument("--precision", default=None, choices=["fp16", "fp8", "fp32"],
                     help="operand precision of the trailing-update GEMMs (default: fp8 for c5 = BASELINE config 5, fp16 otherwise)")
@@ -196,6 +197,25 @@ def main():
                 "tn_achieved": (tm["flops_far_tn"] / (tm["ms_far_tn"] * 1e-3) / 1e12) if tm["ms_far_tn"] > 0 else None}
         if args.config == "c4" and not args.outer_block and prec_name == "fp16":
             roof["traffic"], roof["traffic_source"] = _pmc_traffic()
+        if prec_name == "fp16" and not args.no_alone:
+            # Context for `frac` (never `value`): (1) what the matrix pipes of THIS box deliver on random operands -- a bare MFMA loop from
+            # registers, both fp16 shapes, with the clock the chip holds meanwhile (the 2.5 PFLOP/s peak is width x 2.4 GHz); (2) the
+            # dominant kernel ALONE on the GPU at the shapes this factorisation launches it with (mpqr_bench_gemm): the difference to
+            # `achieved` is what running beside the panel chain costs it
+            p32, g32 = h.bench_mfma_peak(0)
+            p16, g16 = h.bench_mfma_peak(1)
+            roof["mfma_measured"] = {"unit": "TFLOP/s", "32x32x16_f16": p32, "32x32x16_clock_ghz": g32, "16x16x32_f16": p16, "16x16x32_clock_ghz": g16,
+                                     "note": "bare MFMA loop, random fp16 operands in registers, 8 waves per CU; nominal peak 2500 = width x 2.4 GHz"}
+            if m >= 4096 and n >= 4096:
+                Mr, Nr = m // 256 * 256, max(256, (n - 3 * (args.outer_block or 1024)) // 256 * 256)
+                kb = args.outer_block or 1024
+                al = {}
+                for name, (kern, mode, M_, N_, K_) in {"far_nn_K%d" % kb: (6, 2, Mr, Nr, kb), "far_nn_K%d" % (2 * kb): (6, 2, Mr, Nr, 2 * kb),
+                                                         "q_nn_K%d_shadow" % (2 * kb): (6, 3, Mr, Mr, 2 * kb), "far_tn_fp32_N%d" % (2 * kb): (2, 1, Nr, 2 * kb, Mr),
+                                                         "q_tn_N%d" % (2 * kb): (16, 1, Mr, 2 * kb, Mr)}.items():
+                    ms_ = h.bench_gemm(kern, mode, M_, N_, K_, iters=4)
+                    al[name] = {"M": M_, "N": N_, "K": K_, "ms": ms_, "tflops": 2.0 * M_ * N_ * K_ / (ms_ * 1e-3) / 1e12}
+                roof["kernel_alone"] = al
         # The far launches against the HBM roof: algorithmic bytes = fp32 C read + write (8 M N) + both fp16 operands once
         # (2 K (M + N)), summed by the library over the far updates it launched (pairs of blocks beyond the next two).
         alg = tm["gbytes_far_nn"] * 1e9

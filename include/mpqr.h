@@ -158,6 +158,11 @@ int mpqr_gemm_test_f32(mpqr_handle_t h, const float* A, const float* B, float* C
  * mode:   0: C = A B (fp32 store), 1: fp16 store, 2: C -= A B (fp32 read-modify-write), 3: mode 2 + the transposed fp16 shadow store.
  * M, N multiples of 256, K of 64.  Replaces nothing in the reference (its GEMM tests check values only, Cuda/mmult.cuh:387-435). */
 int mpqr_bench_gemm(mpqr_handle_t h, int kernel, int mode, int M, int N, int K, int iters, float* ms_per_launch);
+/* measurement aid (bench.py: roofline.mfma_measured): a bare MFMA loop on random fp16 operands held in registers, one 512-thread
+ * workgroup per CU, shape 0 = v_mfma_f32_32x32x16_f16, 1 = v_mfma_f32_16x16x32_f16 -> TFLOP/s of the whole device and the shader clock
+ * it holds meanwhile (GHz).  The dense peak of MI355X_MICROARCH.md (2.5 PFLOP/s) is width x 2.4 GHz; under load the chip lowers its
+ * clock, differently per shape: this is the attainable denominator next to the nominal one (SURVEY.md 8d asks for the cross-check). */
+int mpqr_bench_mfma_peak(mpqr_handle_t h, int shape, float* tflops, float* ghz);
 /* results: A_out is (m+1) x n in the reference's shifted-reflector layout, Q is m x m */
 int mpqr_get_factor_host(mpqr_handle_t h, float* A_out);
 int mpqr_get_q_host(mpqr_handle_t h, float* Q);

@@ -69,6 +69,7 @@ SIGNATURES = {
     "mpqr_bench_leaf_solve": (_i, [_H, _i, _i, C.POINTER(C.c_float)]),
     "mpqr_gemm_test_f32": (_i, [_H, _f32, _f32, _f32, _i, _i, _i, _i, _i]),
     "mpqr_bench_gemm": (_i, [_H, _i, _i, _i, _i, _i, _i, C.POINTER(C.c_float)]),
+    "mpqr_bench_mfma_peak": (_i, [_H, _i, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     "mpqr_get_factor_host": (_i, [_H, _f32]),
     "mpqr_get_q_host": (_i, [_H, _f32]),
     "mpqr_get_r_host": (_i, [_H, _f32]),

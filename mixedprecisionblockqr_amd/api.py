@@ -82,6 +82,12 @@ class Handle:
         self._chk(L.lib().mpqr_bench_gemm(self._h, kernel, mode, M, N, K, iters, C.byref(ms)))
         return ms.value
 
+    def bench_mfma_peak(self, shape=0):
+        """(TFLOP/s, GHz) of a bare fp16 MFMA loop on random operands (include/mpqr.h: mpqr_bench_mfma_peak)."""
+        tf, ghz = C.c_float(), C.c_float()
+        self._chk(L.lib().mpqr_bench_mfma_peak(self._h, shape, C.byref(tf), C.byref(ghz)))
+        return tf.value, ghz.value
+
     def bench_leaf_solve(self, w=128, iters=50):
         """Mean launch time (us) of the serial core of one Gram-Householder leaf of width w, timed alone."""
         us = C.c_float()

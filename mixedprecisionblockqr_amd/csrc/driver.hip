@@ -1796,7 +1796,7 @@ int mpqr_bench_leaf_solve(mpqr_handle_t h, int w, int iters, float* us_per_launc
 // quantisation kernel and zero-padded to the sizes the kernels may read (256 rows, the k step).
 int mpqr_gemm_test_f32(mpqr_handle_t h, const float* A, const float* B, float* C, int M, int N, int K, int kernel, int mode) {
     if (!h || !A || !B || !C || M < 1 || N < 1 || K < 1 || (mode != 0 && mode != 2)) return MPQR_ERR_INVALID;
-    if (kernel != 1 && kernel != 2 && kernel != 6 && kernel != 8) return MPQR_ERR_INVALID;
+    if (kernel != 1 && kernel != 2 && kernel != 6 && kernel != 8 && kernel != 16) return MPQR_ERR_INVALID;
     if (kernel == 2 && mode != 0) return MPQR_ERR_INVALID;
     if (mode == 2 && (M % 32) != 0) return fail(h, MPQR_ERR_INVALID, "mpqr_gemm_test_f32: the read-modify-write epilogue needs M % 32 == 0");
     HIPCHK(h, hipSetDevice(h->device));
@@ -1823,7 +1823,7 @@ int mpqr_gemm_test_f32(mpqr_handle_t h, const float* A, const float* B, float* C
         const EMode em = mode == 2 ? E_SUB_F32 : E_STORE_F32;
         bool ok = true;
         if (kernel == 1) ok = launch_gemm_f16(A_H16, em, g, h->s0);
-        else if (kernel == 6) ok = launch_gemm2_f16(A_H16, em, g, h->s0, 0);
+        else if (kernel == 6 || kernel == 16) ok = launch_gemm2_f16(A_H16, em, g, h->s0, kernel == 16 ? 16 : 32);   // 32: the 32x32x16 form of every epilogue
         else if (kernel == 2) {
             if (bad(hipMalloc(&dAf, Af.size() * 4)) || bad(hipMemcpy(dAf, Af.data(), Af.size() * 4, hipMemcpyHostToDevice))) break;
             g.A = dAf; g.lda = Mp;
@@ -1841,6 +1841,41 @@ int mpqr_gemm_test_f32(mpqr_handle_t h, const float* A, const float* B, float* C
         for (int i = 0; i < M; i++) for (int j = 0; j < N; j++) C[(size_t)i * N + j] = Cp[(size_t)i * Np + j];
     } while (0);
     (void)hipFree(dA); (void)hipFree(dB); (void)hipFree(dC); (void)hipFree(dAf); (void)hipFree(dA8); (void)hipFree(dB8);
+    return rc;
+}
+
+// measurement aid: what the matrix pipes of this device deliver on random fp16 operands (include/mpqr.h)
+int mpqr_bench_mfma_peak(mpqr_handle_t h, int shape, float* tflops, float* ghz) {
+    if (!h || !tflops || !ghz || (shape != 0 && shape != 1)) return MPQR_ERR_INVALID;
+    HIPCHK(h, hipSetDevice(h->device));
+    hipDeviceProp_t prop;
+    HIPCHK(h, hipGetDeviceProperties(&prop, h->device));
+    const int nwg = prop.multiProcessorCount, iters = 8192, reps = 6;
+    half_t* dsrc = nullptr; float* dout = nullptr; long* dclk = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    int rc = MPQR_OK;
+    auto bad = [&](hipError_t e) { if (e != hipSuccess && rc == MPQR_OK) rc = fail(h, MPQR_ERR_HIP, hipGetErrorString(e)); return e != hipSuccess; };
+    do {
+        std::vector<half_t> hb((size_t)1 << 20);
+        uint64_t x = 88172645463325252ull;
+        for (auto& v : hb) { x ^= x << 13; x ^= x >> 7; x ^= x << 17; v = (half_t)(((float)(x >> 40) / 16777216.f - 0.5f) * 2.f); }
+        if (bad(hipMalloc((void**)&dsrc, hb.size() * 2 + 4096)) || bad(hipMalloc((void**)&dout, (size_t)nwg * 512 * 4)) || bad(hipMalloc((void**)&dclk, (size_t)nwg * 16))) break;
+        if (bad(hipMemcpy(dsrc, hb.data(), hb.size() * 2, hipMemcpyHostToDevice)) || bad(hipEventCreate(&e0)) || bad(hipEventCreate(&e1))) break;
+        for (int r = 0; r < 3; r++) launch_mfma_peak(shape, dsrc, dout, dclk, nwg, iters, h->s0);          // let the clock settle
+        if (bad(hipEventRecord(e0, h->s0))) break;
+        for (int r = 0; r < reps; r++) launch_mfma_peak(shape, dsrc, dout, dclk, nwg, iters, h->s0);
+        float ms = 0.f;
+        if (bad(hipEventRecord(e1, h->s0)) || bad(hipStreamSynchronize(h->s0)) || bad(hipGetLastError()) || bad(hipEventElapsedTime(&ms, e0, e1))) break;
+        std::vector<long> clk((size_t)2 * nwg);
+        if (bad(hipMemcpy(clk.data(), dclk, clk.size() * 8, hipMemcpyDeviceToHost))) break;
+        double g = 0;
+        for (int b = 0; b < nwg; b++) g += (double)clk[2 * b] / (double)std::max<long>(clk[2 * b + 1], 1) * 0.1;   // s_memrealtime: 100 MHz
+        *ghz = (float)(g / nwg);
+        *tflops = (float)((double)reps * nwg * 8 * (double)iters * 2.0 * 128 * 64 * 32 / (ms * 1e-3) / 1e12);
+    } while (0);
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    (void)hipFree(dsrc); (void)hipFree(dout); (void)hipFree(dclk);
     return rc;
 }
 
@@ -1883,7 +1918,7 @@ int mpqr_bench_gemm(mpqr_handle_t h, int kernel, int mode, int M, int N, int K, 
         float ms = 0.f;
         for (int it = -2; it < iters; it++) {
             if (it == 0 && bad(hipEventRecord(e0, h->s0))) break;
-            const bool ok = kernel == 2 ? launch_gemm2_f16(A_F32T, em, g, h->s0, 0) : launch_gemm2_f16(A_H16, em, g, h->s0, kernel == 16 ? 16 : 0);
+            const bool ok = kernel == 2 ? launch_gemm2_f16(A_F32T, em, g, h->s0, 0) : launch_gemm2_f16(A_H16, em, g, h->s0, kernel == 16 ? 16 : 32);
             if (!ok) { rc = fail(h, MPQR_ERR_INVALID, "mpqr_bench_gemm: no kernel for this (kernel, mode)"); break; }
         }
         if (rc) break;

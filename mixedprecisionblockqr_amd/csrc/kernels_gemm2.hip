@@ -433,10 +433,11 @@ __device__ __forceinline__ void epilogue_sub_f32_dma(ACC (&acc)[4][2], char* sme
 //     tiles (48-64 KiB) are always in flight behind counted s_waitcnt vmcnt(8 / 6); the region a DMA overwrites was
 //     last read at least one full phase earlier by either group, and the data a phase reads was waited for by every
 //     wave before the barrier that precedes it.
-// MF = 1 (experiment, mpqr_bench_gemm kernel 16): the same pipeline on v_mfma_f32_16x16x32_f16 -- a quadrant is 4 x 2 tiles of 16 x 16
+// MF = 1 (the store epilogues' default, round 4): the same pipeline on v_mfma_f32_16x16x32_f16 -- a quadrant is 4 x 2 tiles of 16 x 16
 // over two K steps of 32 (16 MFMAs of 16 cycles instead of 8 of 32); fragment registers and LDS reads are the same in number, lane
 // l reads row l & 15, 16-byte chunk 4 ks + (l >> 4).  On random data the chip holds a higher clock on this shape
-// (MI355X_MICROARCH.md, DVFS give-back (7); tools/ubench_mfma.hip).  Store epilogues only.
+// (MI355X_MICROARCH.md, DVFS give-back (7); tools/ubench_mfma.hip).  The operands are passed SWAPPED, so a lane holds four
+// consecutive columns of a row of C: 16-byte (fp32) / 8-byte (fp16) stores.
 template <int EM, int DMA_EPI, int MF = 0>
 __global__ __launch_bounds__(512) void gemm6_f16_kernel(GemmArgs g, int tilesM, int tilesN) {
     using namespace g2;
@@ -548,8 +549,10 @@ __global__ __launch_bounds__(512) void gemm6_f16_kernel(GemmArgs g, int tilesM, 
                 for (int i4 = 0; i4 < 4; i4++)
 #pragma unroll
                     for (int j2 = 0; j2 < 2; j2++)
+                        // operands SWAPPED (D^T = B-fragment x A-fragment): lane (li, lk) then holds C[m = 16 i + li][n = 16 j + 4 lk .. + 3],
+                        // four CONSECUTIVE COLUMNS of a row-major C -> 16-byte loads and stores in the epilogue
                         acc16[MF ? subA * 4 + i4 : 0][MF ? subB * 2 + j2 : 0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(
-                            af[2 * ks2 + (i4 >> 1)][i4 & 1], b[2 * ks2 + j2], acc16[MF ? subA * 4 + i4 : 0][MF ? subB * 2 + j2 : 0], 0, 0, 0);
+                            b[2 * ks2 + j2], af[2 * ks2 + (i4 >> 1)][i4 & 1], acc16[MF ? subA * 4 + i4 : 0][MF ? subB * 2 + j2 : 0], 0, 0, 0);
             issue(tau, sidx);
             __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);
             __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
@@ -636,21 +639,42 @@ __global__ __launch_bounds__(512) void gemm6_f16_kernel(GemmArgs g, int tilesM, 
     if (kt_on) kt1 = clock64();
 #endif
     const float alpha = g.alpha;
-    if (MF) {                                               // 16 x 16 accumulator tiles: column = lane & 15, rows 4 (lane >> 4) + e
+    if (MF) {                                               // 16 x 16 accumulator tiles, transposed: row m = lane & 15, columns 4 (lane >> 4) + e
+        typedef float F4 __attribute__((ext_vector_type(4)));
+        typedef half_t H4 __attribute__((ext_vector_type(4)));
+        const bool inner = bm + BM <= g.M && bn + BN <= g.N && (g.ldc & 3) == 0;     // interior tile: 16- / 8-byte stores
 #pragma unroll
         for (int i = 0; i < 8; i++)
 #pragma unroll
             for (int j = 0; j < 4; j++) {
-                const int n = bn + wn + j * 16 + li;
+                const int m = bm + wm + i * 16 + li, n0 = bn + wn + j * 16 + 4 * lk;
+                const long o = (long)m * g.ldc + n0;
+                F4 v;
 #pragma unroll
                 for (int e = 0; e < 4; e++) {
-                    const int m = bm + wm + i * 16 + 4 * lk + e;
-                    if (m < g.M && n < g.N) {
-                        const float v = alpha * acc16[MF ? i : 0][MF ? j : 0][e];
-                        if (EM == E_STORE_H16) ((half_t*)g.C)[(long)m * g.ldc + n] = (half_t)v;
-                        else if (EM == E_SUB_F32) ((float*)g.C)[(long)m * g.ldc + n] -= v;
-                        else ((float*)g.C)[(long)m * g.ldc + n] = v;
+                    v[e] = alpha * acc16[MF ? i : 0][MF ? j : 0][e];
+                    if (EM == E_STORE_H16 && g.cscale) v[e] *= g.cscale[(long)min(n0 + e, g.N - 1) * g.cscale_ld];      // tau_n (unit-diagonal fp16 T)
+                    if (EM == E_STORE_F32 && g.eye_minus) v[e] = (m == n0 + e ? 1.f : 0.f) - v[e];
+                }
+                if (EM == E_STORE_H16) {
+                    H4 hv, lv;
+#pragma unroll
+                    for (int e = 0; e < 4; e++) { hv[e] = (half_t)v[e]; lv[e] = (half_t)(v[e] - (float)hv[e]); }
+                    if (inner) { *(H4*)((half_t*)g.C + o) = hv; if (g.C2) *(H4*)(g.C2 + o) = lv; }
+                    else if (m < g.M) {
+#pragma unroll
+                        for (int e = 0; e < 4; e++)
+                            if (n0 + e < g.N) { ((half_t*)g.C)[o + e] = hv[e]; if (g.C2) g.C2[o + e] = lv[e]; }
                     }
+                } else if (EM == E_STORE_F32) {
+                    if (inner) *(F4*)((float*)g.C + o) = v;
+                    else if (m < g.M) {
+#pragma unroll
+                        for (int e = 0; e < 4; e++) if (n0 + e < g.N) ((float*)g.C)[o + e] = v[e];
+                    }
+                } else if (m < g.M) {                          // E_SUB_F32: test / bench path only (the library's updates use the 32 x 32 DMA epilogue)
+#pragma unroll
+                    for (int e = 0; e < 4; e++) if (n0 + e < g.N && n0 + e >= g.col_lo) ((float*)g.C)[o + e] -= v[e];
                 }
             }
         return;
@@ -708,7 +732,7 @@ static void launch6(const GemmArgs& g, hipStream_t s) {
 // operand buffers are readable up to the next multiple of 256 rows (tiles are loaded unmasked; rows past M / N
 // only feed outputs that the epilogue masks).  config: 0 = 256x256x64 / 512 threads, 1 = 256x128x32 / 256 threads.
 bool launch_gemm2_f16(AMode am, EMode em, const GemmArgs& g, hipStream_t s, int config) {
-    if (am == A_H16 && config == 16 && (g.K % 64) == 0 && !g.Ct && !g.A2 && !g.C2 && !g.cscale && !g.eye_minus) {   // experiment: 16x16x32 MFMA shape
+    if (am == A_H16 && config == 16 && (g.K % 64) == 0 && !g.Ct) {   // mpqr_gemm_test_f32 / mpqr_bench_gemm kernel 16: the 16x16x32 form of every epilogue
         if (em == E_SUB_F32) { launch6<E_SUB_F32, 0, 1>(g, s); return true; }
         if (em == E_STORE_F32) { launch6<E_STORE_F32, 0, 1>(g, s); return true; }
         if (em == E_STORE_H16) { launch6<E_STORE_H16, 0, 1>(g, s); return true; }
@@ -719,8 +743,12 @@ bool launch_gemm2_f16(AMode am, EMode em, const GemmArgs& g, hipStream_t s, int 
         static const int use6 = []() { const char* e = getenv("MPQR_GEMM6"); return e ? atoi(e) : 1; }();
         if (use6 && (g.K % 64) == 0) {
             if (em == E_SUB_F32) { if (dma_epi) launch6<E_SUB_F32, 1>(g, s); else launch6<E_SUB_F32, 0>(g, s); return true; }
-            if (em == E_STORE_F32) { launch6<E_STORE_F32, 0>(g, s); return true; }
-            if (em == E_STORE_H16) { launch6<E_STORE_H16, 0>(g, s); return true; }
+            // store epilogues (X = Q2^T V, W = V T, Q = I - W V^T, Y = X T): v_mfma_f32_16x16x32_f16 -- on random operands the chip holds
+            // 1.87 GHz on this shape against 1.60 on 32x32x16 (tools/ubench_mfma.hip: 1900 vs 1550 TFLOP/s from registers); in this
+            // kernel +5 % (tools/bench_gemm.py).  MPQR_MFMA16=0: the 32x32x16 form (A/B hook, run by the opt-in test)
+            static const int mf16 = []() { const char* e = getenv("MPQR_MFMA16"); return e ? atoi(e) : 1; }();
+            if (em == E_STORE_F32) { if (mf16 && config != 32) launch6<E_STORE_F32, 0, 1>(g, s); else launch6<E_STORE_F32, 0>(g, s); return true; }
+            if (em == E_STORE_H16) { if (mf16 && config != 32) launch6<E_STORE_H16, 0, 1>(g, s); else launch6<E_STORE_H16, 0>(g, s); return true; }
         }
     }
 #define MPQR_CASE2(A_, E_)                                                  \

@@ -373,4 +373,73 @@ void launch_qr_f64(double* A, double* Q, int m, int n, double* work, hipStream_t
     hipLaunchKernelGGL(qr_f64_kernel, dim3(1), dim3(1024), 0, s, A, Q, m, n, work);
 }
 
+// ------------------------------------------------------------------ MFMA rate of this box on random operands (measurement aid)
+// The 2.5 PFLOP/s dense fp16 figure is width x 2.4 GHz; under an MFMA-dense load the chip lowers its clock, by an amount that depends on
+// the operand values and on the MFMA shape (MI355X_MICROARCH.md, DVFS give-back; tools/ubench_mfma.hip).  One wave = a 128 x 64 tile's
+// worth of independent accumulators, operands in registers, 8 waves per workgroup, one workgroup per CU: what the matrix pipes deliver
+// when nothing else limits them.  SHAPE 0: v_mfma_f32_32x32x16_f16, 1: v_mfma_f32_16x16x32_f16.
+typedef half_t half8m __attribute__((ext_vector_type(8)));
+typedef float floatx16m __attribute__((ext_vector_type(16)));
+typedef float floatx4m __attribute__((ext_vector_type(4)));
+template <int SHAPE>
+__global__ __launch_bounds__(512) void mfma_peak_kernel(const half_t* __restrict__ src, float* __restrict__ out, long* __restrict__ clk, int iters) {
+    const int tid = threadIdx.x;
+    constexpr int NA = SHAPE ? 8 : 4, NB = SHAPE ? 4 : 2;
+    half8m a[NA], b[NB];
+#pragma unroll
+    for (int i = 0; i < NA; i++) a[i] = *(const half8m*)(src + ((((long)blockIdx.x * 512 + tid) * 12 + i) * 8) % (1 << 20));
+#pragma unroll
+    for (int j = 0; j < NB; j++) b[j] = *(const half8m*)(src + ((((long)blockIdx.x * 512 + tid) * 12 + 8 + j) * 8) % (1 << 20));
+    floatx16m acc32[SHAPE ? 1 : 4][SHAPE ? 1 : 2];
+    floatx4m acc16[SHAPE ? 8 : 1][SHAPE ? 4 : 1];
+#pragma unroll
+    for (int i = 0; i < (SHAPE ? 1 : 4); i++)
+#pragma unroll
+        for (int j = 0; j < (SHAPE ? 1 : 2); j++)
+#pragma unroll
+            for (int e = 0; e < 16; e++) acc32[i][j][e] = 0.f;
+#pragma unroll
+    for (int i = 0; i < (SHAPE ? 8 : 1); i++)
+#pragma unroll
+        for (int j = 0; j < (SHAPE ? 4 : 1); j++)
+#pragma unroll
+            for (int e = 0; e < 4; e++) acc16[i][j][e] = 0.f;
+    const long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+    for (int it = 0; it < iters; it++) {                         // one iteration = 128 x 64 x 32 MACs per wave in either shape
+        if (SHAPE) {
+#pragma unroll
+            for (int i = 0; i < 8; i++)
+#pragma unroll
+                for (int j = 0; j < 4; j++) acc16[SHAPE ? i : 0][SHAPE ? j : 0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[SHAPE ? i : 0], b[SHAPE ? j : 0], acc16[SHAPE ? i : 0][SHAPE ? j : 0], 0, 0, 0);
+        } else {
+#pragma unroll
+            for (int rep = 0; rep < 2; rep++)
+#pragma unroll
+                for (int i = 0; i < 4; i++)
+#pragma unroll
+                    for (int j = 0; j < 2; j++) acc32[SHAPE ? 0 : i][SHAPE ? 0 : j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i], b[j], acc32[SHAPE ? 0 : i][SHAPE ? 0 : j], 0, 0, 0);
+        }
+    }
+    const long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < (SHAPE ? 1 : 4); i++)
+#pragma unroll
+        for (int j = 0; j < (SHAPE ? 1 : 2); j++)
+#pragma unroll
+            for (int e = 0; e < 16; e++) s += acc32[i][j][e];
+#pragma unroll
+    for (int i = 0; i < (SHAPE ? 8 : 1); i++)
+#pragma unroll
+        for (int j = 0; j < (SHAPE ? 4 : 1); j++)
+#pragma unroll
+            for (int e = 0; e < 4; e++) s += acc16[i][j][e];
+    out[(long)blockIdx.x * 512 + tid] = s;
+    if (tid == 0) { clk[2 * blockIdx.x] = t1 - t0; clk[2 * blockIdx.x + 1] = r1 - r0; }
+}
+void launch_mfma_peak(int shape, const half_t* src, float* out, long* clk, int nwg, int iters, hipStream_t s) {
+    if (shape) hipLaunchKernelGGL(mfma_peak_kernel<1>, dim3(nwg), dim3(512), 0, s, src, out, clk, iters);
+    else hipLaunchKernelGGL(mfma_peak_kernel<0>, dim3(nwg), dim3(512), 0, s, src, out, clk, iters);
+}
+
 }  // namespace mpqr

@@ -180,6 +180,10 @@ void launch_diff_norms(const float* A, long lda, const float* B, long ldb, int m
 void launch_gram_minus_identity(const float* G, long ldg, int m, double* out, hipStream_t s);
 void launch_lower_norm(const float* R, long ldr, int m, int n, double* out, hipStream_t s);
 
+// measurement aid: bare MFMA loop on random operands (shape 0: 32x32x16, 1: 16x16x32), nwg workgroups of 8 waves; clk[2 b], clk[2 b + 1] =
+// shader-clock and 100 MHz ticks workgroup b spent in the loop
+void launch_mfma_peak(int shape, const half_t* src /* 2^20 halves */, float* out /* nwg x 512 */, long* clk /* 2 nwg */, int nwg, int iters, hipStream_t s);
+
 // fp64 column-major Householder QR (C++/main.cpp path)
 void launch_qr_f64(double* A, double* Q, int m, int n, double* work, hipStream_t s);
 

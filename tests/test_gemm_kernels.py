@@ -9,7 +9,8 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 
-KERNELS = {1: "gemm_f16 (128 tile)", 2: "gemm2 A_F32T (256 tile, fp32 source transposed while staged)", 6: "gemm6 (256 tile ping-pong)"}
+KERNELS = {1: "gemm_f16 (128 tile)", 2: "gemm2 A_F32T (256 tile, fp32 source transposed while staged)", 6: "gemm6 (256 tile ping-pong)",
+           16: "gemm6 on v_mfma_f32_16x16x32_f16 (operands swapped: 16-byte epilogue accesses)"}
 
 
 def _h16(x):
@@ -60,8 +61,8 @@ def test_reference_sweep_against_h_mmult(kernel):
     print(f"{KERNELS[kernel]}: max |C - h_mmult| over the sweep {worst:.2e}")
 
 
-@pytest.mark.parametrize("kernel", [1, 6])
-@pytest.mark.parametrize("shape", [(320, 200, 130), (288, 511, 64), (1024, 130, 200), (160, 80, 37), (544, 260, 1030)])
+@pytest.mark.parametrize("kernel", [1, 6, 16])
+@pytest.mark.parametrize("shape", [(320, 200, 130), (288, 511, 64), (1024, 130, 200), (160, 80, 37), (544, 260, 1030), (768, 512, 192)])
 def test_in_place_update_on_odd_shapes(kernel, shape):
     """C -= A B with the read-modify-write epilogue (the trailing update's form, Cuda/mmult.cu:236-288 + the copy-back
     mmult.cuh:104-151) on shapes that end inside a tile: N and K arbitrary, M a multiple of 32 only (the epilogue's documented

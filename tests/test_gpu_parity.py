@@ -792,6 +792,7 @@ def test_distributed_schedule_on_one_gpu(mp, po, m, n, r, ko, world, la):
 OPT_IN = [
     {},                                            # the default path, the others are compared with it
     {"MPQR_GEMM6": "0"},                           # register-staged 256-tile kernel instead of the LDS-DMA ping-pong one
+    {"MPQR_MFMA16": "0"},                          # store-epilogue GEMMs on v_mfma_f32_32x32x16_f16 (round 3) instead of 16x16x32
     {"MPQR_TSTREAM": "0"},                         # compact-WY T on the chain stream
     {"MPQR_EXT_LOOKAHEAD": "0"},                   # block boundary: first leaf of the next block through the far update
     {"MPQR_QSHADOW": "0", "MPQR_QPAIR": "0"},      # Q formation block by block from the fp32 Q (round-1 form)

@@ -26,6 +26,15 @@ CASES = [
     ("16x16x32: store f32, K=8192", 16, 0, 16384, 16384, 8192),
     ("16x16x32: Q tn shape, store f16", 16, 1, 16384, 2048, 16384),
     ("16x16x32: far nn K=2048, register RMW", 16, 2, 16384, 13312, 2048),
+    # the read-modify-write epilogue nearly alone (K = 64: one K tile): one workgroup, one per CU, thirteen per CU
+    ("epilogue probe: 1 tile, DMA ring", 6, 2, 256, 256, 64),
+    ("epilogue probe: 256 tiles, DMA ring", 6, 2, 4096, 4096, 64),
+    ("epilogue probe: 3328 tiles, DMA ring", 6, 2, 16384, 13312, 64),
+    ("epilogue probe: 1 tile, 16-B registers", 16, 2, 256, 256, 64),
+    ("epilogue probe: 256 tiles, 16-B registers", 16, 2, 4096, 4096, 64),
+    ("epilogue probe: 3328 tiles, 16-B registers", 16, 2, 16384, 13312, 64),
+    ("store probe: 3328 tiles f32 store", 6, 0, 16384, 13312, 64),
+    ("store probe: 3328 tiles f32 store 16-B", 16, 0, 16384, 13312, 64),
 ]
 
 
@@ -34,7 +43,9 @@ def main():
     h = mp.Handle(0)
     rows = []
     for label, k, md, M, N, K in CASES:
-        ms = h.bench_gemm(k, md, M, N, K, iters=3 if quick else 8)
+        if quick and K > 64:
+            continue
+        ms = h.bench_gemm(k, md, M, N, K, iters=8)
         tf = 2.0 * M * N * K / (ms * 1e-3) / 1e12
         rows.append({"case": label, "kernel": KN[k], "epilogue": MD[md], "M": M, "N": N, "K": K, "ms": ms, "tflops": tf, "frac_of_2500": tf / 2500.0})
         print(f"{label:42s} {M:6d} x {N:6d} x {K:6d}  {ms:8.3f} ms  {tf:7.1f} TFLOP/s  {tf / 25.0:5.1f} % of 2.5 PF   [{KN[k]}; {MD[md]}]", flush=True)
