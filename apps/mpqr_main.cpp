@@ -140,6 +140,7 @@ static int run_multi_gpu(int world, int m, int n, int r, uint64_t seed, int step
     const bool comm_on = world > 1 || getenv("MPQR_MG_FORCE_BCAST") != nullptr;   // the env switch exercises RCCL on a 1-GPU box
     HostBarrier bar(world);
     std::vector<float> amax(world, 0.f);
+    std::vector<int> flagged(world, 0);
     std::vector<double> ms(world, 0.0);
     std::atomic<bool> failed{false};
     // --check (default): every rank hands its column shards of the input, of the factor and of Q to the host after the timed loop;
@@ -175,7 +176,7 @@ static int run_multi_gpu(int world, int m, int n, int r, uint64_t seed, int step
         int nb = 0;
         // one factorisation.  The host never waits for a broadcast: pack -> ev_pack -> the communication stream waits; broadcast ->
         // ev_bcast -> the chain stream waits -> unpack -> ev_unp[buffer] -> the next broadcast into that buffer waits.
-        auto factor = [&]() -> bool {
+        auto factor_once = [&]() -> bool {
             if (!ok_q(mpqr_dist_local_absmax(h, &amax[rank]), "mpqr_dist_local_absmax")) return false;
             if (!bar.wait()) return false;
             float gmax = 0.f; for (float v : amax) gmax = std::max(gmax, v);
@@ -203,6 +204,16 @@ static int run_multi_gpu(int world, int m, int n, int r, uint64_t seed, int step
                 } else if (!ok_q(mpqr_dist_update_part(h, s, 1), "mpqr_dist_update_part")) return false;
             }
             return ok_q(mpqr_dist_form_q(h), "mpqr_dist_form_q") && ok_h(hipStreamSynchronize(cs), "hipStreamSynchronize") && ok_q(mpqr_sync(h), "mpqr_sync");
+        };
+        // the leaf flags are asked once, after the block loop (no host synchronisation per block); any rank's flag makes every rank
+        // repeat the factorisation with its tall leaves on the column-by-column kernels (as mixedprecisionblockqr_amd/dist.py::factor)
+        auto factor = [&]() -> bool {
+            if (!factor_once()) return false;
+            if (!ok_q(mpqr_dist_flags(h, &flagged[rank]), "mpqr_dist_flags") || !bar.wait()) return false;
+            bool any = false; for (int v : flagged) any = any || v != 0;
+            if (!bar.wait()) return false;
+            if (!any) return true;
+            return ok_q(mpqr_dist_set_robust(h, 1), "mpqr_dist_set_robust") && factor_once();
         };
         do {                                                             // one exit path: everything below the loop is released once
             if (!ok_h(hipSetDevice(rank), "hipSetDevice") || !ok_q(mpqr_create(&h, rank), "mpqr_create") ||

@@ -253,6 +253,8 @@ int  mpqr_part_global_index(int lcol, int block, int world, int rank);
  *         owner:  mpqr_dist_factor_block(s); mpqr_dist_pack_block(s, buf)
  *         all:    broadcast(buf, root = mpqr_dist_block_owner(s)); mpqr_dist_unpack_block(s, buf); mpqr_dist_update(s)
  *     mpqr_dist_form_q                      (no communication)
+ *     mpqr_sync; mpqr_dist_flags -> all-reduce(max): a flagged (ill-conditioned tall leaf) factorisation is repeated after
+ *     mpqr_dist_set_robust(1) on every rank -- no rank synchronises its host inside the block loop
  */
 int  mpqr_dist_plan(mpqr_handle_t h, int m, int n, int r, int world, int rank, const mpqr_opts* opts);
 int  mpqr_dist_block(mpqr_handle_t h);              /* columns per distributed block                     */
@@ -265,6 +267,8 @@ int  mpqr_dist_generate_matrix(mpqr_handle_t h, uint64_t seed);   /* this rank's
 int  mpqr_dist_local_absmax(mpqr_handle_t h, float* out);
 int  mpqr_dist_begin(mpqr_handle_t h, float global_absmax);
 int  mpqr_dist_factor_block(mpqr_handle_t h, int s);
+int  mpqr_dist_flags(mpqr_handle_t h, int* any);      /* synchronises; 1: a Gram-Householder leaf of this rank flagged itself since mpqr_dist_begin */
+int  mpqr_dist_set_robust(mpqr_handle_t h, int on);   /* every tall leaf on the column-by-column kernels from now on (reset by a new input)         */
 long mpqr_dist_block_bytes(mpqr_handle_t h, int s);
 int  mpqr_dist_pack_block(mpqr_handle_t h, int s, void* device_buf);
 int  mpqr_dist_unpack_block(mpqr_handle_t h, int s, const void* device_buf);

@@ -111,6 +111,8 @@ SIGNATURES = {
     "mpqr_dist_local_absmax": (_i, [_H, C.POINTER(_f)]),
     "mpqr_dist_begin": (_i, [_H, _f]),
     "mpqr_dist_factor_block": (_i, [_H, _i]),
+    "mpqr_dist_flags": (_i, [_H, C.POINTER(C.c_int)]),
+    "mpqr_dist_set_robust": (_i, [_H, _i]),
     "mpqr_dist_block_bytes": (_l, [_H, _i]),
     "mpqr_dist_pack_block": (_i, [_H, _i, _p]),
     "mpqr_dist_unpack_block": (_i, [_H, _i, _p]),

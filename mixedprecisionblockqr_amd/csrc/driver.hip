@@ -1360,10 +1360,12 @@ static int plan_common(mpqr_handle_t h, int m, int n, int r, const mpqr_opts* op
         }
     }
     {
-        // opt-in (MPQR_ASHADOW=1): measured at 16384^2 the far X = A2^T V gains less (6.3 -> 5.2 ms; N = 1024 gives only four
-        // column tiles per row panel) than the shadow stores cost the far A2 -= V Y^T (4.6 -> 5.4 ms), and the chain beside
-        // them does not get faster: 49.4 vs 49.3 ms on the same box.  Q formation (K = 2048) is where the shadow pays.
-        static const int as_on = []() { const char* e = getenv("MPQR_ASHADOW"); return e ? atoi(e) : 0; }();
+        // fp16 shadow of the trailing matrix, At[column][row] = fp16(s A): every far update's epilogue writes it, the next far update's
+        // X = A2^T V reads it by LDS-DMA like any fp16 operand (round 4 default; MPQR_ASHADOW=0: X converts and transposes the fp32 matrix
+        // while staging it).  Alone on the GPU the fp32-staging kernel runs at 640-660 TFLOP/s, the all-DMA one at 920, and the shadow stores
+        // cost the update 830 -> 750 (tools/bench_gemm.py); beside the chain: far X 6.8 -> 5.2 ms, far update 4.1 -> 4.5 ms, step 39.25 ->
+        // 38.97 ms (round 2, older kernels: even).  0.5 GB at 16384^2.
+        static const int as_on = []() { const char* e = getenv("MPQR_ASHADOW"); return e ? atoi(e) : 1; }();
         if (as_on && world == 1 && o.lookahead && o.precision == MPQR_PREC_FP16) {
             h->ldat = h->m_pad;
             if ((rc = dalloc(h, &h->At, (size_t)(h->n_pad + 256) * h->ldat))) return rc;
@@ -2416,14 +2418,14 @@ int mpqr_dist_set_local_matrix_host(mpqr_handle_t h, const float* A_local, long 
                                    (size_t)h->nloc * sizeof(float), h->m, hipMemcpyHostToDevice, h->s0));
     }
     HIPCHK(h, hipStreamSynchronize(h->s0));
-    h->factored = false; h->q_formed = false; h->have_input = true;
+    h->factored = false; h->q_formed = false; h->have_input = true; h->robust = false;
     return MPQR_OK;
 }
 
 int mpqr_dist_generate_matrix(mpqr_handle_t h, uint64_t seed) {
     int rc = need_plan(h, true); if (rc) return rc;
     if (h->nloc > 0) launch_generate(h->dA0, h->lda, h->m, h->nloc, seed, h->n, h->Ko, h->world, h->rank, h->s0);
-    h->factored = false; h->q_formed = false; h->have_input = true;
+    h->factored = false; h->q_formed = false; h->have_input = true; h->robust = false;
     return MPQR_OK;
 }
 
@@ -2456,45 +2458,47 @@ int mpqr_dist_begin(mpqr_handle_t h, float absmax) {
         HIPCHK(h, hipEventRecord(h->ev_dist_far, h->s1));
     }
     if ((rc = clear_leaf_flags(h))) return rc;
+    for (int b = 0; b < h->flag_words; b++) __atomic_store_n(h->hflag_host + b, 0, __ATOMIC_RELAXED);   // (the previous factorisation was synchronised: mpqr_dist_flags)
+    h->cur_block = 0; h->watch_flags = false;
     if ((rc = clear_reflectors(h))) return rc;
     h->factored = false; h->q_formed = false;
     return MPQR_OK;
 }
 
-// owner only: factor superblock s of the (already updated) local columns
+// owner only: factor superblock s of the (already updated) local columns.  Nothing is synchronised: an ill-conditioned tall leaf raises
+// its flag word (mapped host memory) and the factorisation carries on; the host asks ONCE, after the last block (mpqr_dist_flags), and a
+// flagged factorisation is repeated with every tall leaf on the column-by-column kernels (mpqr_dist_set_robust) -- rare, and the same on
+// every rank.  (Rounds 1-3 read the flags back after every block: one host synchronisation per block on the owner, 16 per factorisation,
+// each of them a bubble in front of the next broadcast; the forced-N=1 path ran 12 % behind the single-GPU path for it.)
 int mpqr_dist_factor_block(mpqr_handle_t h, int s) {
     int rc = need_plan(h, true); if (rc) return rc;
     if (s < 0 || s >= (int)h->tops.size()) return fail(h, MPQR_ERR_INVALID, "bad block index");
     if (s % h->world != h->rank) return fail(h, MPQR_ERR_STATE, "this rank does not own that block");
     const Node nd = h->nodes[h->tops[s]];
     const int lc0 = mpqr_part_local_index(nd.c0, h->Ko, h->world);
-    // save the block's columns so an ill-conditioned tall leaf can be redone on the robust kernels
-    const size_t wbytes = (size_t)(nd.c1 - nd.c0) * sizeof(float);
-    int rcs = ensure_stage(h, (size_t)h->m_pad * (nd.c1 - nd.c0)); if (rcs) return rcs;
-    HIPCHK(h, hipMemcpy2DAsync(h->dstage, wbytes, h->dA + lc0, h->lda * sizeof(float), wbytes, h->m_pad,
-                               hipMemcpyDeviceToDevice, h->s0));
     h->Aeff = h->dA + (lc0 - nd.c0);
-    bool saved_robust = h->robust;
     const bool timed = h->chain_used + 2 <= h->chain_ev.size();
     if (timed) HIPCHK(h, hipEventRecord(h->chain_ev[h->chain_used], h->s0));
-    for (int attempt = 0; attempt < 2; attempt++) {
-        if ((rc = factor_node(h, h->tops[s], true))) { h->robust = saved_robust; h->Aeff = h->dA; return rc; }
-        int f = 0;
-        if ((rc = any_leaf_flag(h, &f))) { h->robust = saved_robust; h->Aeff = h->dA; return rc; }
-        if (!f || h->robust) break;
-        // restore the block and redo it column by column
-        h->robust = true;
-        if ((rc = clear_leaf_flags(h))) return rc;
-        HIPCHK(h, hipMemcpy2DAsync(h->dA + lc0, h->lda * sizeof(float), h->dstage, wbytes, wbytes, h->m_pad,
-                                   hipMemcpyDeviceToDevice, h->s0));
-        HIPCHK(h, hipMemset2DAsync(h->Vh + nd.c0, h->ldvh * sizeof(half_t), 0, (size_t)(nd.c1 - nd.c0) * sizeof(half_t),
-                                   h->m_pad, h->s0));
-        HIPCHK(h, hipMemsetAsync(h->Vt + (size_t)nd.c0 * h->ldvt, 0, (size_t)(nd.c1 - nd.c0) * h->ldvt * sizeof(half_t), h->s0));
-    }
+    rc = factor_node(h, h->tops[s], true);
     if (timed) { HIPCHK(h, hipEventRecord(h->chain_ev[h->chain_used + 1], h->s0)); h->chain_used += 2; }
-    h->robust = saved_robust;
     h->Aeff = h->dA;
+    if (rc) return rc;
     HIPCHK(h, hipGetLastError());
+    return MPQR_OK;
+}
+
+// after mpqr_sync: did any Gram-Householder leaf of this rank's blocks flag itself since mpqr_dist_begin?
+int mpqr_dist_flags(mpqr_handle_t h, int* any) {
+    int rc = need_plan(h, true); if (rc) return rc;
+    if (!any) return MPQR_ERR_INVALID;
+    HIPCHK(h, hipStreamSynchronize(h->s0));
+    *any = flag_words_set(h, h->flag_words) ? 1 : 0;
+    return MPQR_OK;
+}
+// on != 0: every tall leaf of the following factorisations takes the column-by-column kernels (all ranks must agree)
+int mpqr_dist_set_robust(mpqr_handle_t h, int on) {
+    int rc = need_plan(h, true); if (rc) return rc;
+    h->robust = on != 0;
     return MPQR_OK;
 }
 

@@ -133,6 +133,14 @@ class GpuEngine:
         self._chain.wait_stream(self.torch.cuda.current_stream(self.device))      # the broadcast has landed
         self._chk(L.lib().mpqr_dist_unpack_block_async(self._h, s, C.c_void_p(buf.data_ptr())))
 
+    def flagged(self):
+        """1 if a Gram-Householder leaf of this rank's blocks found its columns too ill conditioned (synchronises)."""
+        v = C.c_int()
+        self._chk(L.lib().mpqr_dist_flags(self._h, C.byref(v)))
+        return v.value
+
+    def set_robust(self, on): self._chk(L.lib().mpqr_dist_set_robust(self._h, 1 if on else 0))
+
     def update(self, s): self._chk(L.lib().mpqr_dist_update(self._h, s))
     def update_part(self, s, part): self._chk(L.lib().mpqr_dist_update_part(self._h, s, part))
 
@@ -155,6 +163,16 @@ class GpuEngine:
 
 
 def factor(engine, comm, form_q=True, lookahead=True):
+    """The distributed factorisation: the block loop below, and -- only if a tall leaf somewhere flagged itself as too ill conditioned for
+    the Gram-Householder kernels (asked ONCE, after the loop: no rank synchronises its host per block) -- the same loop again with
+    every tall leaf on the column-by-column kernels."""
+    _factor_once(engine, comm, form_q, lookahead)
+    if hasattr(engine, "flagged") and comm.allreduce_max(engine.flagged()) > 0:
+        engine.set_robust(True)
+        _factor_once(engine, comm, form_q, lookahead)
+
+
+def _factor_once(engine, comm, form_q=True, lookahead=True):
     """The distributed block loop.  Every rank calls this with its own engine.
 
     Look-ahead: after block s has been broadcast, the owner of block s+1 updates THAT block's columns

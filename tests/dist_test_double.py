@@ -12,7 +12,7 @@ from oracle import pyoracle as po
 
 
 class OracleEngine:
-    def __init__(self, m, n, r, world, rank, outer_block=64):
+    def __init__(self, m, n, r, world, rank, outer_block=64, flag_once_on_rank=-1):
         self.m, self.n, self.r, self.world, self.rank = m, n, r, world, rank
         ko = max(outer_block, 32)
         self.ko = r if r >= ko else (ko // r) * r
@@ -21,6 +21,8 @@ class OracleEngine:
         self.A0 = np.zeros((m, len(self.cols)), np.float32)
         self.VT = {}
         self.log = []                      # call sequence, for the look-ahead order test
+        self.robust = False                # set_robust(): every tall leaf on the column-by-column kernels (the oracle has only those)
+        self._flag_pending = flag_once_on_rank == rank     # test hook: this rank reports a flagged leaf after its first pass
 
     def block(self): return self.ko
     def num_blocks(self): return (self.n + self.ko - 1) // self.ko
@@ -112,6 +114,17 @@ class OracleEngine:
         self.Q = Q
 
     def sync(self): pass
+
+    def flagged(self):
+        """GpuEngine.flagged(): 1 if one of this rank's Gram-Householder leaves flagged itself (here: the test hook, once)."""
+        self.log.append(("flagged",))
+        f = 1 if (self._flag_pending and not self.robust) else 0
+        self._flag_pending = False
+        return f
+
+    def set_robust(self, on):
+        self.log.append(("set_robust", bool(on)))
+        self.robust = bool(on)
 
     def local_factor(self):
         out = np.zeros((self.m + 1, len(self.cols)), np.float32)

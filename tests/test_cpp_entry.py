@@ -99,6 +99,11 @@ def test_cpp_multi_gpu_host_driver_on_one_gpu(tmp_path):
         mt = re.search(r"multi-GPU block QR: 1 GPU\(s\), 4096 x 3072, r = 128, outer block (\d+), (\w+): ([0-9.]+) ms per factorisation incl. Q, ([0-9.]+) GFLOP/s", p.stdout)
         assert mt, p.stdout
         assert mt.group(2) == dtype and float(mt.group(3)) > 0 and float(mt.group(4)) > 100.0
+        # the N > 1 host evaluates the reference's three criteria (Cuda/qr.cu:115-196) on the gathered result, p = operand precision
+        crit = {k: (float(v), ok == "True") for k, v, ok in CRIT.findall(p.stdout)}
+        assert len(crit) == 3 and all(ok for _, ok in crit.values()), (dtype, crit, p.stdout)
+        be = crit["||A - QR||/||A||"][0]
+        assert (be <= 1e-3) if dtype == "fp16" else (2e-3 <= be <= 6e-2), (dtype, be)        # fp8: the honest e4m3 error, not a residual / sqrt(n)
 
 
 

@@ -10,14 +10,14 @@ import torch.multiprocessing as mp
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _worker(rank, world, port, m, n, r, ko, q, la=True):
+def _worker(rank, world, port, m, n, r, ko, q, la=True, flag_rank=-1):
     sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from mixedprecisionblockqr_amd import dist as mpdist
     from dist_test_double import OracleEngine
-    eng = OracleEngine(m, n, r, world, rank, outer_block=ko)
+    eng = OracleEngine(m, n, r, world, rank, outer_block=ko, flag_once_on_rank=flag_rank)
     eng.generate(1234)
     comm = mpdist.TorchComm()
     mpdist.factor(eng, comm, lookahead=la)
@@ -81,3 +81,27 @@ def test_single_rank_degenerates_to_serial(po):
     A0, Q0, _ = po.householder_qr(po.generate(70, 50, seed=5))
     np.testing.assert_allclose(eng.local_factor(), A0, atol=2e-5)
     np.testing.assert_allclose(eng.local_q(), Q0, atol=2e-5)
+
+
+def test_flagged_rank_makes_every_rank_repeat_the_factorisation_on_the_robust_kernels(po):
+    """No rank synchronises inside the block loop (round 4): the leaf flags are asked once, after the loop, and ANY rank's flag
+    (all-reduce max) makes EVERY rank repeat the factorisation with its tall leaves on the column-by-column kernels -- the broadcasts
+    are collective, so the ranks must take the second pass together."""
+    m, n, r, ko, world = 96, 80, 16, 32, 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 500) + 333
+    procs = [ctx.Process(target=_worker, args=(rk, world, port, m, n, r, ko, q, True, 1)) for rk in range(world)]
+    for p in procs: p.start()
+    got = [q.get(timeout=180) for _ in range(world)]
+    for p in procs: p.join(timeout=60)
+    assert all(p.exitcode == 0 for p in procs)
+    A = po.generate(m, n, seed=1234)
+    A0, Q0, _ = po.householder_qr(A)
+    F = np.zeros((m + 1, n), np.float32)
+    for rank, cols, qcols, Fl, Ql, chk, log in got:
+        F[:, cols] = Fl
+        assert log.count(("flagged",)) == 1 and ("set_robust", True) in log, (rank, log)         # both ranks, although only rank 1 flagged
+        assert sum(1 for e in log if e[0] == "factor_block") == 2 * sum(1 for s in range((n + ko - 1) // ko) if s % world == rank)   # two passes
+        assert chk["backward_error_est"] < 1e-5
+    np.testing.assert_allclose(F, A0, atol=3e-5 * np.sqrt(m))

@@ -798,7 +798,7 @@ OPT_IN = [
     {"MPQR_QSHADOW": "0", "MPQR_QPAIR": "0"},      # Q formation block by block from the fp32 Q (round-1 form)
     {"MPQR_QSPLIT": "1"},                          # hi + lo parts of X in Q formation as well
     {"MPQR_FAR_PAIR": "0"},                        # far updates block by block (K = outer block) instead of pairwise
-    {"MPQR_ASHADOW": "1", "MPQR_FAR_PAIR": "1"},   # pairwise far updates reading the fp16 shadow of the trailing matrix
+    {"MPQR_ASHADOW": "0"},                         # far X = A2^T V from the fp32 matrix (converted + transposed while staged: round 3 default)
     {"MPQR_EXT_LEAVES": "1"},                      # block boundary: the in-block updates reach ONE leaf of the next block (round 2)
     {"MPQR_DEFER_FAR": "0"},                       # far update enqueued at the block's end instead of behind the next block's first gh_gram
     {"MPQR_LEAF_LA": "1"},                         # leaf-level look-ahead: every leaf's update of the rest of its block on the T stream
@@ -852,7 +852,7 @@ def test_opt_in_schedules_and_kernels():
     # the pairwise schedule really ran: one pass over the far columns per PAIR of blocks moves fewer (algorithmic) bytes of the
     # trailing matrix than one pass per block
     assert far[()] < 0.95 * far[(("MPQR_FAR_PAIR", "0"),)], far
-    assert far[(("MPQR_ASHADOW", "1"), ("MPQR_FAR_PAIR", "1"))] <= 1.3 * far[()], far
+    assert far[()] <= 1.3 * far[(("MPQR_ASHADOW", "0"),)], far      # (the shadow stores add 2 bytes per updated element)
 
 
 @pytest.mark.gpu
