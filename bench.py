@@ -117,7 +117,9 @@ def main():
     ap.add_argument("--outer-block", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-dropin", action="store_true", help="skip the PCIe-inclusive timing of the drop-in call (dropin_ms)")
-    ap.add_argument("--no-alone", action="store_true", help="skip the kernel-alone / MFMA-rate context measurements (roofline.mfma_measured, .kernel_alone)")
+    ap.add_argument("--no-alone", action="store_true", help="skip the MFMA-rate context measurement (roofline.mfma_measured)")
+    ap.add_argument("--alone", action="store_true", help="also time the dominant GEMM kernels alone on the GPU at this run's shapes (roofline.kernel_alone); "
+                    "off by default: those launches carry the same kernel names as the factorisation's and would enter a profiler's per-kernel averages")
     ap.add_argument("--no-lookahead", action="store_true")
     ap.add_argument("--precision", default=None, choices=["fp16", "fp8", "fp32"],
                     help="operand precision of the trailing-update GEMMs (default: fp8 for c5 = BASELINE config 5, fp16 otherwise)")
@@ -206,7 +208,7 @@ def main():
             p16, g16 = h.bench_mfma_peak(1)
             roof["mfma_measured"] = {"unit": "TFLOP/s", "32x32x16_f16": p32, "32x32x16_clock_ghz": g32, "16x16x32_f16": p16, "16x16x32_clock_ghz": g16,
                                      "note": "bare MFMA loop, random fp16 operands in registers, 8 waves per CU; nominal peak 2500 = width x 2.4 GHz"}
-            if m >= 4096 and n >= 4096:
+            if args.alone and m >= 4096 and n >= 4096:
                 Mr, Nr = m // 256 * 256, max(256, (n - 3 * (args.outer_block or 1024)) // 256 * 256)
                 kb = args.outer_block or 1024
                 al = {}
