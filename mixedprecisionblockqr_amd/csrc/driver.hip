@@ -290,10 +290,6 @@ int build_tree(mpqr_handle_t h, int c0, int c1) {
 
 // ---- GEMM wrappers -------------------------------------------------------------
 // large shapes go to the 256 x 256 tile kernel, everything else to the 128 x 128 one
-int gemm2_config() {        // test/tuning hook: MPQR_GEMM2_CONFIG selects the large-kernel tile configuration
-    static const int c = []() { const char* e = getenv("MPQR_GEMM2_CONFIG"); return e ? atoi(e) : 0; }();
-    return c;
-}
 // 256 x 256 output tiles from which the 256-wide kernels take a GEMM (test hook: MPQR_GEMM2_MIN_TILES=1 forces them early).
 // apply_node derives from the SAME number whether an update may hand X over as fp16 hi + lo parts, which only those kernels honour.
 static long gemm2_min_tiles() {
@@ -308,7 +304,7 @@ void gemm_dispatch(AMode am, EMode em, const GemmArgs& g, hipStream_t s) {
     const long tiles = (long)(g.M / 256) * (g.N / 256);
     if ((g.nsplit <= 1 || (em == E_STORE_F32 && am == A_F32T)) && (g.nslab_in <= 1) && g.M >= 256 && g.N >= 256 &&
         tiles >= gemm2_min_tiles() && (g.K % 64) == 0 &&
-        launch_gemm2_f16(am, em, g, s, gemm2_config()))
+        launch_gemm2_f16(am, em, g, s, 0))
         return;
     if (!launch_gemm_f16(am, em, g, s) && t_dispatch_handle) t_dispatch_handle->dispatch_error = true;
 }
@@ -1040,21 +1036,9 @@ int form_q(mpqr_handle_t h) {
     return MPQR_OK;
 }
 
-// The far-update stream may use only 3 of every 4 CUs: its GEMM workgroups hold a CU's LDS for ~100 us each, and
-// the latency-bound panel kernels on s0 would otherwise queue behind them (MPQR_UPDATE_CU_MASK=0 disables this).
-hipError_t create_update_stream(hipStream_t* st, int prio) {
-    // MPQR_UPDATE_CU_MASK=0x........ restricts the far-update stream to a CU pattern (32-bit, repeated 8 times); measured
-    // at 16384^2: no effect on the step time for 1/2 .. 7/8 of the CUs, so the default is an unmasked low-priority stream.
-    const char* e = getenv("MPQR_UPDATE_CU_MASK");
-    if (!(e && strlen(e) > 2 && e[0] == '0' && (e[1] == 'x' || e[1] == 'X')))
-        return hipStreamCreateWithPriority(st, hipStreamNonBlocking, prio);
-    uint32_t mask[8];
-    const uint32_t pat = (uint32_t)strtoul(e, nullptr, 16);
-    for (int i = 0; i < 8; i++) mask[i] = pat;
-    hipError_t rc = hipExtStreamCreateWithCUMask(st, 8, mask);
-    if (rc != hipSuccess) return hipStreamCreateWithPriority(st, hipStreamNonBlocking, prio);
-    return rc;
-}
+// the far-update stream: low priority, unmasked (restricting it to 1/2 .. 7/8 of the CUs made the step slower in rounds 2 and 3; only
+// masks that keep CUs on every XCC are honoured by the runtime at all: tools/probe_cumask.hip)
+hipError_t create_update_stream(hipStream_t* st, int prio) { return hipStreamCreateWithPriority(st, hipStreamNonBlocking, prio); }
 
 int check_shape(mpqr_handle_t h, int m, int n, int r) {
     if (!h) return MPQR_ERR_INVALID;
@@ -1188,14 +1172,6 @@ static int plan_common(mpqr_handle_t h, int m, int n, int r, const mpqr_opts* op
     h->qloc = (world == 1) ? m : mpqr_part_local_cols(m, Ko, world, rank);
     h->lda = rup(std::max(h->nloc, 1), 256); h->ldq = rup(std::max(h->qloc, 1), 256);
     h->ldvh = h->n_pad; h->ldvt = h->m_pad;
-    {   // Leading-dimension padding (elements; multiples of 64 keep every row 128-B aligned).  Row strides that are large
-        // powers of two (16384 floats = 64 KiB) put the 256 rows of a GEMM tile on few HBM channels.
-        static const int pad = []() { const char* e = getenv("MPQR_LD_PAD"); return e ? atoi(e) : 0; }();
-        if (pad > 0) {
-            const int p64 = rup(pad, 64);
-            h->lda += p64; h->ldq += p64; h->ldvh += p64; h->ldvt += p64;
-        }
-    }
     // tree over the GLOBAL columns (every rank builds the same one)
     for (int c = 0; c < n; c += Ko) h->tops.push_back(build_tree(h, c, std::min(n, c + Ko)));
     size_t toff = 0; int max_ldt = 64;
@@ -1659,9 +1635,10 @@ int mpqr_factor(mpqr_handle_t h) {
         HIPCHK(h, hipStreamSynchronize(h->s0));
         // Only the FIRST flagged leaf in column order is believed.  Round 4 tried believing every flagged leaf of the first flagged
         // block (one restart per block instead of one per leaf): on the rank-deficient Jacobian stand-in all 8 leaves
-        // of the block flag once the first one has (its reflectors behind the dependent column are noise amplified by 1 / ||u||, the
-        // columns they update overflow fp16), so 8 leaves went to the column-by-column kernels where 1 was ill conditioned.  The
-        // leaves behind a flagged leaf say nothing; every restart repairs exactly one leaf, at the cost of re-running its block.
+        // of the block flag once the first one has, so 8 leaves went to the column-by-column kernels where 1 was ill conditioned
+        // (4.9 x the full-rank time instead of 1.3 x) -- also when the flagged leaf is made to leave an identity transform behind
+        // (C = 0, V_top = 0), i.e. it is not overflowing garbage that trips them: a leaf's flag is only meaningful once every leaf
+        // before it has been applied.  Every restart therefore repairs exactly one leaf, at the cost of re-running its block.
         int bad = -1;                                     // the flagged leaf with the smallest first column
         for (size_t id = 0; id < flags.size(); id++)
             if (flags[id] && !h->leaf_robust[id] && (bad < 0 || h->nodes[id].c0 < h->nodes[bad].c0)) bad = (int)id;

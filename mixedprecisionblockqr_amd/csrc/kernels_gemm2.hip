@@ -730,7 +730,8 @@ static void launch6(const GemmArgs& g, hipStream_t s) {
 
 // Large-shape path.  Preconditions (checked by the caller, driver.hip): no split-K, K % 64 == 0, and the
 // operand buffers are readable up to the next multiple of 256 rows (tiles are loaded unmasked; rows past M / N
-// only feed outputs that the epilogue masks).  config: 0 = 256x256x64 / 512 threads, 1 = 256x128x32 / 256 threads.
+// only feed outputs that the epilogue masks).  config: 0 = the library's choice, 2 = the register-staged kernel for fp16 A as well,
+// 16 / 32 = the ping-pong kernel on 16x16x32 / 32x32x16 for every epilogue (test and bench entries).
 bool launch_gemm2_f16(AMode am, EMode em, const GemmArgs& g, hipStream_t s, int config) {
     if (am == A_H16 && config == 16 && (g.K % 64) == 0 && !g.Ct) {   // mpqr_gemm_test_f32 / mpqr_bench_gemm kernel 16: the 16x16x32 form of every epilogue
         if (em == E_SUB_F32) { launch6<E_SUB_F32, 0, 1>(g, s); return true; }
@@ -739,10 +740,9 @@ bool launch_gemm2_f16(AMode am, EMode em, const GemmArgs& g, hipStream_t s, int 
         return false;
     }
     if (am == A_H16 && config != 2 && config != 1) {          // config 2 keeps the register-staged kernel (A/B comparison)
-        static const int dma_epi = []() { const char* e = getenv("MPQR_DMA_EPILOGUE"); return e ? atoi(e) : 1; }();
         static const int use6 = []() { const char* e = getenv("MPQR_GEMM6"); return e ? atoi(e) : 1; }();
         if (use6 && (g.K % 64) == 0) {
-            if (em == E_SUB_F32) { if (dma_epi) launch6<E_SUB_F32, 1>(g, s); else launch6<E_SUB_F32, 0>(g, s); return true; }
+            if (em == E_SUB_F32) { launch6<E_SUB_F32, 1>(g, s); return true; }
             // store epilogues (X = Q2^T V, W = V T, Q = I - W V^T, Y = X T): v_mfma_f32_16x16x32_f16 -- on random operands the chip holds
             // 1.87 GHz on this shape against 1.60 on 32x32x16 (tools/ubench_mfma.hip: 1900 vs 1550 TFLOP/s from registers); in this
             // kernel +5 % (tools/bench_gemm.py).  MPQR_MFMA16=0: the 32x32x16 form (A/B hook, run by the opt-in test)
@@ -753,8 +753,7 @@ bool launch_gemm2_f16(AMode am, EMode em, const GemmArgs& g, hipStream_t s, int 
     }
 #define MPQR_CASE2(A_, E_)                                                  \
     if (am == A_ && em == E_) {                                             \
-        if (config == 1) launch2<A_, E_, 2, 2, 32>(g, s);                   \
-        else launch2<A_, E_, 2, 4, 64>(g, s);                               \
+        launch2<A_, E_, 2, 4, 64>(g, s);                                    \
         return true;                                                        \
     }
     MPQR_CASE2(A_F32T, E_STORE_F32)
