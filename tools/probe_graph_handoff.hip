@@ -42,6 +42,19 @@ int main() {
         printf("%-34s %8.2f us per kernel pair\n", name, best * 1e3f / N);
         return best;
     };
+    // fork / join with real concurrency: s0: A, C, D   s1: B beside C.   ideal per iteration: A + max(B, C) + D = 3 kernels; serial: 4
+    auto fork_join = [&]() {
+        for (int i = 0; i < N; i++) {
+            hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(64), 0, s0, d, cyc);                       // A
+            (void)hipEventRecord(ea[i], s0); (void)hipStreamWaitEvent(s1, ea[i], 0);
+            hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(64), 0, s1, d + 1, cyc);                   // B (side)
+            (void)hipEventRecord(eb[i], s1);
+            hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(64), 0, s0, d + 2, cyc);                   // C (chain, beside B)
+            (void)hipStreamWaitEvent(s0, eb[i], 0);
+            hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(64), 0, s0, d + 3, cyc);                   // D (needs B and C)
+        }
+    };
+    auto four_serial = [&]() { for (int i = 0; i < 4 * N; i++) hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(64), 0, s0, d, cyc); };
     const float e1 = timed("eager, one stream", one_stream);
     const float e2 = timed("eager, two streams + 2 hand-offs", two_streams);
     // the same two patterns captured into graphs (origin stream s0; s1 joins through the event waits and joins back at the end)
@@ -52,6 +65,15 @@ int main() {
     const float g1t = timed("graph, one stream", [&]() { (void)hipGraphLaunch(x1, s0); });
     const float g2t = timed("graph, two streams + 2 hand-offs", [&]() { (void)hipGraphLaunch(x2, s0); });
     printf("two hand-offs cost: eager %.2f us, graph %.2f us per pair\n", (e2 - e1) * 1e3f / N, (g2t - g1t) * 1e3f / N);
+    {
+        const float f0 = timed("eager, 4 kernels serial / iteration", four_serial);
+        const float f1 = timed("eager, fork-join (ideal = 3 kernels)", fork_join);
+        hipGraph_t g3; hipGraphExec_t x3;
+        CK(hipStreamBeginCapture(s0, hipStreamCaptureModeThreadLocal)); fork_join(); CK(hipStreamEndCapture(s0, &g3));
+        CK(hipGraphInstantiate(&x3, g3, nullptr, nullptr, 0));
+        const float f2 = timed("graph, fork-join (ideal = 3 kernels)", [&]() { (void)hipGraphLaunch(x3, s0); });
+        printf("fork-join per iteration: serial %.2f, eager %.2f, graph %.2f us (one kernel = %.2f us)\n", f0 * 1e3f / N, f1 * 1e3f / N, f2 * 1e3f / N, f0 * 1e3f / N / 4);
+    }
     auto h0 = std::chrono::steady_clock::now(); two_streams(); auto h1 = std::chrono::steady_clock::now(); (void)hipDeviceSynchronize();
     printf("host time to enqueue the eager two-stream pattern: %.2f us per pair\n", std::chrono::duration<double, std::micro>(h1 - h0).count() / N);
     return 0;
