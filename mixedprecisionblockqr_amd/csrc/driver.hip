@@ -125,6 +125,7 @@ struct mpqr_handle_s {
     int n_gh_leaves = 0;                     // Gram-Householder leaves launched by the last mpqr_factor (all passes)
     int restart_block = 0;                   // top-level block the last pass of mpqr_factor started from
     int n_q_ident_rows = 0;                  // rows of X copied from V in the last Q formation (identity columns of Q)
+    hipError_t async_err = hipSuccess; const char* async_what = "";   // first failed enqueue call of the current C-ABI call (HIPQ)
     bool dispatch_error = false;             // a GEMM enqueued on behalf of this handle found no kernel (gemm_dispatch)
     bool q_inited = false;                   // Q = I (and its fp16 shadow) was set up early, on the far stream beside the first panels
     std::vector<size_t> far_mark, chain_mark;   // event-pool positions at the start of every top-level block (a restart rewinds to them)
@@ -196,6 +197,14 @@ thread_local std::string g_create_err;
             (h)->err = buf_;                                                                     \
             return MPQR_ERR_HIP;                                                                 \
         }                                                                                        \
+    } while (0)
+
+// enqueue calls inside the block loop (event records / waits, device-to-device copies) cannot return from the middle of the schedule:
+// the FIRST failure is kept in the handle and reported by the C-ABI entry that enqueued it (mpqr_factor, mpqr_sync, the mpqr_dist_* steps)
+#define HIPQ(h, call)                                                                                     \
+    do {                                                                                                  \
+        hipError_t e_ = (call);                                                                           \
+        if (e_ != hipSuccess && (h)->async_err == hipSuccess) { (h)->async_err = e_; (h)->async_what = #call; } \
     } while (0)
 
 int fail(mpqr_handle_t h, int code, const char* msg) {
@@ -407,7 +416,7 @@ void apply_node(mpqr_handle_t h, const Node& nd, float* C, long ldc, int clo, in
     const long slab = (long)M1 * Kr;
     g1.nsplit = choose_split(M1, Kr, Kw, lane == 2 ? h->xt2_elems : h->xt_elems, slab);
     g1.slab_out_stride = slab;
-    if (record) (void)hipEventRecord(e0, st);
+    if (record) HIPQ(h, hipEventRecord(e0, st));
     hipStream_t st1 = (h->op1_stream && lane == 0) ? h->op1_stream : st;     // flat schedule: X on the side stream, T on the chain
     // MPQR_PREC_FP8: the two large GEMMs of a FAR update take e4m3 operands (kernels_fp8.hip); shapes the fp8 kernel does
     // not cover (K not a multiple of 128) stay on the fp16 path
@@ -459,9 +468,9 @@ void apply_node(mpqr_handle_t h, const Node& nd, float* C, long ldc, int clo, in
             const int idc = (h->q_ident_cols > 0 && clo == clo_al && nd.a0 == nd.c0 && rlo == nd.c0 && clo == nd.c0) ?
                             std::min({h->q_ident_cols, M1 - 256, (nd.c1 - nd.c0) / 256 * 256}) : 0;
             if (idc >= 256 && (long)((M1 - idc) / 256) * (Kr / 256) >= gemm2_min_tiles()) {   // (the rest still goes to the 256-wide kernel)
-                (void)hipMemcpy2DAsync(Xhi, (size_t)Kr * sizeof(half_t), h->Vh + (long)nd.c0 * h->ldvh + nd.a0, h->ldvh * sizeof(half_t),
-                                       (size_t)Kr * sizeof(half_t), idc, hipMemcpyDeviceToDevice, st1);
-                if (Xlo) (void)hipMemsetAsync(Xlo, 0, (size_t)idc * Kr * sizeof(half_t), st1);
+                HIPQ(h, hipMemcpy2DAsync(Xhi, (size_t)Kr * sizeof(half_t), h->Vh + (long)nd.c0 * h->ldvh + nd.a0, h->ldvh * sizeof(half_t),
+                                       (size_t)Kr * sizeof(half_t), idc, hipMemcpyDeviceToDevice, st1));
+                if (Xlo) HIPQ(h, hipMemsetAsync(Xlo, 0, (size_t)idc * Kr * sizeof(half_t), st1));
                 g1.A = h->shadow + (long)(clo_al + idc) * h->ldshadow + rlo;
                 g1.C = Xhi + (long)idc * Kr; if (Xlo) g1.C2 = Xlo + (long)idc * Kr;
                 g1.M = M1 - idc;
@@ -477,10 +486,10 @@ void apply_node(mpqr_handle_t h, const Node& nd, float* C, long ldc, int clo, in
     gemm_dispatch(A_F32T, E_STORE_F32, g1, st1);
     if (g1.nsplit > 1 && !fuse_xt) launch_slab_reduce(Xt, g1.nsplit, slab, slab, Xt, st1);
     }
-    if (st1 != st) { (void)hipEventRecord(h->ev_x, st1); (void)hipStreamWaitEvent(st, h->ev_x, 0); }
-    if (record) (void)hipEventRecord(e1, st);
+    if (st1 != st) { HIPQ(h, hipEventRecord(h->ev_x, st1)); HIPQ(h, hipStreamWaitEvent(st, h->ev_x, 0)); }
+    if (record) HIPQ(h, hipEventRecord(e1, st));
     // op2: Yt[M1 x Kr] = fp16( Xt * T' ) -- the first use of T: it was built on the T stream beside op1
-    if (st1 == st && h->tq_on && nd.id >= 0 && nd.id < (int)h->ev_T.size()) (void)hipStreamWaitEvent(st, h->ev_T[nd.id], 0);
+    if (st1 == st && h->tq_on && nd.id >= 0 && nd.id < (int)h->ev_T.size()) HIPQ(h, hipStreamWaitEvent(st, h->ev_T[nd.id], 0));
     GemmArgs g2{};
     g2.A = Xt; g2.lda = Kr; g2.nslab_in = 1; g2.slab_in_stride = slab;
     g2.Bt = (trans_t ? h->Tth : h->Th) + nd.toff; g2.ldb = nd.tld;
@@ -502,7 +511,7 @@ void apply_node(mpqr_handle_t h, const Node& nd, float* C, long ldc, int clo, in
     g3.col_lo = clo - clo_al; g3.alpha = 1.0f / in_scale; g3.in_scale = 1.f; g3.nsplit = 1;
     if (a_shadow) { g3.Ct = h->At + (long)clo_al * h->ldat + rlo; g3.ldct = h->ldat; g3.ct_scale = in_scale; }
     if (h->shadow && h->shadow_write && lane == 0 && !far) { g3.Ct = h->shadow + (long)clo_al * h->ldshadow + rlo; g3.ldct = h->ldshadow; g3.ct_scale = in_scale; }
-    if (record) (void)hipEventRecord(e2, st);
+    if (record) HIPQ(h, hipEventRecord(e2, st));
     if (f8) {
         launch_quant_h16_fp8(Yt, Kr, h->Y8, h->ld8k, M1, Kr, 0.25f, st);                       // 2^-2 Y
         GemmArgs f3 = g3;
@@ -512,7 +521,7 @@ void apply_node(mpqr_handle_t h, const Node& nd, float* C, long ldc, int clo, in
     } else
     gemm_dispatch(A_H16, E_SUB_F32, g3, st);
     if (record) {
-        (void)hipEventRecord(e3, st);
+        HIPQ(h, hipEventRecord(e3, st));
         h->far_flops.push_back(2.0 * M1 * (double)Kr * Kw);
         h->far_bytes.push_back((g3.Ct ? 10.0 : 8.0) * M1 * (double)Kw + 2.0 * Kr * ((double)M1 + Kw));
     }
@@ -570,8 +579,8 @@ int robust_tall_leaf(mpqr_handle_t h, const Node nd, bool do_panel) {
 
 // chain stream -> T stream: everything enqueued on s0 so far (reflectors of the nodes below) is visible to sT
 static void t_stream_follows_chain(mpqr_handle_t h) {
-    (void)hipEventRecord(h->ev_v, h->s0);
-    (void)hipStreamWaitEvent(h->sT, h->ev_v, 0);
+    HIPQ(h, hipEventRecord(h->ev_v, h->s0));
+    HIPQ(h, hipStreamWaitEvent(h->sT, h->ev_v, 0));
 }
 
 int factor_rec(mpqr_handle_t h, int id, bool do_panel) {
@@ -588,7 +597,7 @@ int factor_rec(mpqr_handle_t h, int id, bool do_panel) {
         const bool robust_leaf = h->robust || (id < (int)h->leaf_robust.size() && h->leaf_robust[id]);
         if (do_panel && robust_leaf && !h->force32 && tall) {
             rc = robust_tall_leaf(h, nd, do_panel);
-            if (tq) { t_stream_follows_chain(h); (void)hipEventRecord(h->ev_T[id], h->sT); }
+            if (tq) { t_stream_follows_chain(h); HIPQ(h, hipEventRecord(h->ev_T[id], h->sT)); }
             return rc;
         }
         bool have_s = false;
@@ -605,7 +614,7 @@ int factor_rec(mpqr_handle_t h, int id, bool do_panel) {
             if (h->Vf) launch_extract_vf(h->Aeff, h->lda, h->vdiag, h->Vf, h->n_pad, h->m, nd.c0, nd.c1, h->s0);
             have_s = fused;
             if (h->wait_after_first_leaf) {          // look-ahead: the block's other columns arrive with this event
-                (void)hipStreamWaitEvent(h->s0, h->wait_after_first_leaf, 0);
+                HIPQ(h, hipStreamWaitEvent(h->s0, h->wait_after_first_leaf, 0));
                 h->wait_after_first_leaf = nullptr;
             }
         }
@@ -624,7 +633,7 @@ int factor_rec(mpqr_handle_t h, int id, bool do_panel) {
             launch_t_leaf(h->S, nslab, slab, nd.ldt, nd.a0, nd.c0, nd.c1, h->Tf + nd.toff, h->Th + nd.toff, h->Tth + nd.toff,
                           nd.ldt, st);
         }
-        if (tq) (void)hipEventRecord(h->ev_T[id], h->sT);
+        if (tq) HIPQ(h, hipEventRecord(h->ev_T[id], h->sT));
         return MPQR_OK;
     }
     const Node L = h->nodes[nd.left], R = h->nodes[nd.right];
@@ -657,7 +666,7 @@ int factor_rec(mpqr_handle_t h, int id, bool do_panel) {
     }
     launch_t_assemble(h->Tf + nd.toff, h->Th + nd.toff, h->Tth + nd.toff, nd.ldt, nd.a0, h->Tf + L.toff, L.ldt, L.a0,
                       nd.c0, L.c1, h->Tf + R.toff, R.ldt, R.a0, nd.c1, h->tmp2, R.ldt, st);
-    if (tq) (void)hipEventRecord(h->ev_T[id], h->sT);
+    if (tq) HIPQ(h, hipEventRecord(h->ev_T[id], h->sT));
     return MPQR_OK;
 }
 
@@ -737,9 +746,9 @@ int factor_block_flat(mpqr_handle_t h, int top, const std::vector<int>& leaves) 
             // column-by-column kernels through a private sub-tree; its root T (contiguous, ldt^2) goes into the diagonal block
             const size_t keep = h->nodes[id].toff;
             if ((rc = robust_tall_leaf(h, h->nodes[id], true))) return rc;
-            (void)hipMemcpy2DAsync(h->Tf + lf.toff, (size_t)ld * 4, h->Tf + keep, (size_t)lf.ldt * 4, (size_t)lf.ldt * 4, lf.ldt, hipMemcpyDeviceToDevice, h->s0);
-            (void)hipMemcpy2DAsync(h->Th + lf.toff, (size_t)ld * 2, h->Th + keep, (size_t)lf.ldt * 2, (size_t)lf.ldt * 2, lf.ldt, hipMemcpyDeviceToDevice, h->s0);
-            (void)hipMemcpy2DAsync(h->Tth + lf.toff, (size_t)ld * 2, h->Tth + keep, (size_t)lf.ldt * 2, (size_t)lf.ldt * 2, lf.ldt, hipMemcpyDeviceToDevice, h->s0);
+            HIPQ(h, hipMemcpy2DAsync(h->Tf + lf.toff, (size_t)ld * 4, h->Tf + keep, (size_t)lf.ldt * 4, (size_t)lf.ldt * 4, lf.ldt, hipMemcpyDeviceToDevice, h->s0));
+            HIPQ(h, hipMemcpy2DAsync(h->Th + lf.toff, (size_t)ld * 2, h->Th + keep, (size_t)lf.ldt * 2, (size_t)lf.ldt * 2, lf.ldt, hipMemcpyDeviceToDevice, h->s0));
+            HIPQ(h, hipMemcpy2DAsync(h->Tth + lf.toff, (size_t)ld * 2, h->Tth + keep, (size_t)lf.ldt * 2, (size_t)lf.ldt * 2, lf.ldt, hipMemcpyDeviceToDevice, h->s0));
             if (tq) t_stream_follows_chain(h);
         } else {
             Range rg("mpqr:panel");
@@ -755,7 +764,7 @@ int factor_block_flat(mpqr_handle_t h, int top, const std::vector<int>& leaves) 
             launch_gh_apply(a, h->Cv, h->Sp, h->s0);
             h->n_gh_leaves++;
             if (h->wait_after_first_leaf && !tq) {       // look-ahead: the block's other columns arrive with this event
-                (void)hipStreamWaitEvent(h->s0, h->wait_after_first_leaf, 0);
+                HIPQ(h, hipStreamWaitEvent(h->s0, h->wait_after_first_leaf, 0));
                 h->wait_after_first_leaf = nullptr;
             }
             Range rt("mpqr:wy_T");
@@ -795,14 +804,14 @@ int factor_block_flat(mpqr_handle_t h, int top, const std::vector<int>& leaves) 
             if (h->wait_after_first_leaf) {
                 // Only X = C2^T V_j reads those columns first, and it runs on the side stream: that stream waits, the chain stream goes
                 // on with T_j and meets the dependency through the X event (the robust leaf path, which works on the chain stream, waits there)
-                (void)hipStreamWaitEvent(tq && !robust_leaf ? h->sT : h->s0, h->wait_after_first_leaf, 0);
-                if (tq && robust_leaf) (void)hipStreamWaitEvent(h->sT, h->wait_after_first_leaf, 0);
+                HIPQ(h, hipStreamWaitEvent(tq && !robust_leaf ? h->sT : h->s0, h->wait_after_first_leaf, 0));
+                if (tq && robust_leaf) HIPQ(h, hipStreamWaitEvent(h->sT, h->wait_after_first_leaf, 0));
                 h->wait_after_first_leaf = nullptr;
             }
         }
         const int own_end = la_split ? std::min(next_c1, upd_end) : (pre_split ? cpre : upd_end);
         const bool have_rest = (la_split || pre_split) && own_end < upd_end;
-        if (have_rest && la_split) (void)hipEventRecord(h->ev_def, h->s0);   // T_j and V_j are complete here: the rest may start beside the urgent part
+        if (have_rest && la_split) HIPQ(h, hipEventRecord(h->ev_def, h->s0));   // T_j and V_j are complete here: the rest may start beside the urgent part
         if (lf.c1 < own_end) {
             Range rg("mpqr:in_block_update");
             h->op1_stream = tq ? h->sT : nullptr;
@@ -811,14 +820,14 @@ int factor_block_flat(mpqr_handle_t h, int top, const std::vector<int>& leaves) 
         }
         if (have_rest) {                                   // the rest, on the T stream
             Range rg("mpqr:in_block_update_deferred");
-            if (!la_split) (void)hipEventRecord(h->ev_def, h->s0);
-            (void)hipStreamWaitEvent(h->sT, h->ev_def, 0);
+            if (!la_split) HIPQ(h, hipEventRecord(h->ev_def, h->s0));
+            HIPQ(h, hipStreamWaitEvent(h->sT, h->ev_def, 0));
             int lo = own_end;
             if (pre_split && lo < cpre) {                   // columns the previous block already brought up to date: no far update to wait for
                 apply_node(h, lf, h->Aeff, h->lda, lo, cpre, true, h->a_scale, false, 2);
                 lo = cpre;
             }
-            if (pre_split && h->wait_after_first_leaf) (void)hipStreamWaitEvent(h->sT, h->wait_after_first_leaf, 0);   // (kept: the last pre-updated leaf waits too)
+            if (pre_split && h->wait_after_first_leaf) HIPQ(h, hipStreamWaitEvent(h->sT, h->wait_after_first_leaf, 0));   // (kept: the last pre-updated leaf waits too)
             apply_node(h, lf, h->Aeff, h->lda, lo, upd_end, true, h->a_scale, false, 2);
         }
         // background, behind this leaf's X GEMM in the side stream's queue: the PREVIOUS leaf's column block of T
@@ -833,8 +842,8 @@ int factor_block_flat(mpqr_handle_t h, int top, const std::vector<int>& leaves) 
     if (tq) {
         // the block's T first: the far update waits for it (every event operation costs its stream ~6 us); the leaves' T's
         // are diagonal blocks of it
-        (void)hipEventRecord(h->ev_T[top], h->sT);
-        if (!h->defer_join) for (int id : leaves) (void)hipEventRecord(h->ev_T[id], h->sT);
+        HIPQ(h, hipEventRecord(h->ev_T[top], h->sT));
+        if (!h->defer_join) for (int id : leaves) HIPQ(h, hipEventRecord(h->ev_T[id], h->sT));
     }
     return MPQR_OK;
 }
@@ -854,8 +863,8 @@ int factor_node(mpqr_handle_t h, int id, bool do_panel) {
     const bool flat = do_panel && is_top && flat_block_ok(h, id, leaves);
     const int rc = flat ? factor_block_flat(h, id, leaves) : factor_rec(h, id, do_panel);
     if (h->tq_on && !(h->defer_join && !h->force32)) {
-        (void)hipEventRecord(h->ev_join, h->sT);
-        (void)hipStreamWaitEvent(h->s0, h->ev_join, 0);
+        HIPQ(h, hipEventRecord(h->ev_join, h->sT));
+        HIPQ(h, hipStreamWaitEvent(h->s0, h->ev_join, 0));
     }
     return rc;
 }
@@ -901,8 +910,8 @@ static void merge_pair(mpqr_handle_t h, int pid, hipStream_t st) {
     const Node nd = h->nodes[pid];
     const Node L = h->nodes[nd.left], R = h->nodes[nd.right];
     if (h->tq_on) {                                       // the children's T's come from the T stream (blocks factored here)
-        if (L.id < (int)h->ev_T.size()) (void)hipStreamWaitEvent(st, h->ev_T[L.id], 0);
-        if (R.id < (int)h->ev_T.size()) (void)hipStreamWaitEvent(st, h->ev_T[R.id], 0);
+        if (L.id < (int)h->ev_T.size()) HIPQ(h, hipStreamWaitEvent(st, h->ev_T[L.id], 0));
+        if (R.id < (int)h->ev_T.size()) HIPQ(h, hipStreamWaitEvent(st, h->ev_T[R.id], 0));
     }
     int nslab; long slab;
     gram(h, L, R, &nslab, &slab, st, h->S2, h->s2_elems);
@@ -925,7 +934,7 @@ static void merge_pair(mpqr_handle_t h, int pid, hipStream_t st) {
     launch_sgemm(s2, st);
     launch_t_assemble(h->Tf + nd.toff, h->Th + nd.toff, h->Tth + nd.toff, nd.ldt, nd.a0, h->Tf + L.toff, L.ldt, L.a0,
                       nd.c0, L.c1, h->Tf + R.toff, R.ldt, R.a0, nd.c1, h->tmp2b, R.ldt, st, nz, zs);
-    if (h->tq_on && nd.id < (int)h->ev_T.size()) (void)hipEventRecord(h->ev_T[nd.id], st);
+    if (h->tq_on && nd.id < (int)h->ev_T.size()) HIPQ(h, hipEventRecord(h->ev_T[nd.id], st));
 }
 
 // prefix step: T of blocks 0..k from T of blocks 0..k-1 (in place, leading block of the same arena) and T of block k
@@ -936,11 +945,11 @@ static void merge_prefix(mpqr_handle_t h, int pid, hipStream_t st) {
     const int ld = nd.tld, o = L.ldt, w = R.ldt;
     float* const Tr = h->Tf + nd.toff; half_t* const Thr = h->Th + nd.toff; half_t* const Tthr = h->Tth + nd.toff;
     if (h->tq_on) {                                       // (a distributed rank that has not factored a block yet has no T events)
-        if (L.id < (int)h->ev_T.size()) (void)hipStreamWaitEvent(st, h->ev_T[L.id], 0);
-        if (R.id < (int)h->ev_T.size()) (void)hipStreamWaitEvent(st, h->ev_T[R.id], 0);
+        if (L.id < (int)h->ev_T.size()) HIPQ(h, hipStreamWaitEvent(st, h->ev_T[L.id], 0));
+        if (R.id < (int)h->ev_T.size()) HIPQ(h, hipStreamWaitEvent(st, h->ev_T[R.id], 0));
     }
     if (L.tld != ld) {                                    // first step: block 0's own T becomes the leading block
-        (void)hipMemcpy2DAsync(Tr, (size_t)ld * 4, h->Tf + L.toff, (size_t)L.tld * 4, (size_t)o * 4, o, hipMemcpyDeviceToDevice, st);
+        HIPQ(h, hipMemcpy2DAsync(Tr, (size_t)ld * 4, h->Tf + L.toff, (size_t)L.tld * 4, (size_t)o * 4, o, hipMemcpyDeviceToDevice, st));
         launch_t_colblock_h16(Tr, Thr, Tthr, ld, o, 0, o, st);
     }
     int nslab; long slab;
@@ -955,17 +964,17 @@ static void merge_prefix(mpqr_handle_t h, int pid, hipStream_t st) {
     s2.B = h->tmp1b; s2.ldb = w; s2.transB = 0;
     s2.C = Tr + o; s2.ldc = ld; s2.M = o; s2.N = w; s2.K = o; s2.alpha = -1.f; s2.beta = 0.f; s2.upperA = 1;
     launch_sgemm(s2, st);
-    (void)hipMemcpy2DAsync(Tr + (size_t)o * ld + o, (size_t)ld * 4, h->Tf + R.toff, (size_t)R.tld * 4, (size_t)w * 4, w,
-                           hipMemcpyDeviceToDevice, st);  // diagonal block = T_k
+    HIPQ(h, hipMemcpy2DAsync(Tr + (size_t)o * ld + o, (size_t)ld * 4, h->Tf + R.toff, (size_t)R.tld * 4, (size_t)w * 4, w,
+                           hipMemcpyDeviceToDevice, st));  // diagonal block = T_k
     launch_t_colblock_h16(Tr, Thr, Tthr, ld, o + w, o, w, st);   // fp16 T and T^T of the new column block (diagonal block included)
-    if (h->tq_on && nd.id < (int)h->ev_T.size()) (void)hipEventRecord(h->ev_T[nd.id], st);
+    if (h->tq_on && nd.id < (int)h->ev_T.size()) HIPQ(h, hipEventRecord(h->ev_T[nd.id], st));
 }
 
 // Q = I - (V T) V^T over all reflectors at once (tall matrices; the tree of merged T's is complete: pairs_ready)
 static int form_q_one_shot(mpqr_handle_t h) {
     const Node rt = h->nodes[h->qroot];
     const int Kr = rt.ldt, rlo = rdown(rt.c0, 64);
-    if (h->tq_on && rt.id < (int)h->ev_T.size()) (void)hipStreamWaitEvent(h->s0, h->ev_T[rt.id], 0);
+    if (h->tq_on && rt.id < (int)h->ev_T.size()) HIPQ(h, hipStreamWaitEvent(h->s0, h->ev_T[rt.id], 0));
     hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr, e3 = nullptr;
     const bool rec = h->factored && h->far_used + 4 <= h->far_ev.size();
     if (rec) {
@@ -980,16 +989,16 @@ static int form_q_one_shot(mpqr_handle_t h) {
     w.C = h->Wh; w.ldc = h->n_pad;
     w.M = h->m_pad - rlo; w.N = Kr; w.K = Kr; w.alpha = 1.f; w.in_scale = 1.f; w.nsplit = 1; w.tri = 2;
     w.cscale = h->Tf + rt.toff; w.cscale_ld = (long)rt.tld + 1;
-    if (rec) (void)hipEventRecord(e0, h->s0);
+    if (rec) HIPQ(h, hipEventRecord(e0, h->s0));
     gemm_dispatch(A_H16, E_STORE_H16, w, h->s0);
-    if (rec) { (void)hipEventRecord(e1, h->s0); (void)hipEventRecord(e2, h->s0); }
+    if (rec) { HIPQ(h, hipEventRecord(e1, h->s0)); HIPQ(h, hipEventRecord(e2, h->s0)); }
     GemmArgs q{};                                         // Q[m x m] = I - W V^T   (V[j][k] = 0 for k > j)
     q.A = h->Wh; q.lda = h->n_pad;
     q.Bt = h->Vh + (long)rlo * h->ldvh + rt.a0; q.ldb = h->ldvh;
     q.C = h->dQ + (long)rlo * h->ldq + rlo; q.ldc = h->ldq;
     q.M = h->m - rlo; q.N = h->m - rlo; q.K = Kr; q.alpha = 1.f; q.in_scale = 1.f; q.nsplit = 1; q.tri = 2; q.eye_minus = 1;
     gemm_dispatch(A_H16, E_STORE_F32, q, h->s0);
-    if (rec) (void)hipEventRecord(e3, h->s0);
+    if (rec) HIPQ(h, hipEventRecord(e3, h->s0));
     h->q_formed = true;
     return MPQR_OK;
 }
@@ -1379,7 +1388,14 @@ int mpqr_plan(mpqr_handle_t h, int m, int n, int r, const mpqr_opts* opts) {
     return plan_common(h, m, n, r, opts, 1, 0);
 }
 
-static bool dispatch_failed(mpqr_handle_t h) { const bool f = h->dispatch_error; h->dispatch_error = false; return f; }
+static bool dispatch_failed(mpqr_handle_t h) {
+    bool f = h->dispatch_error; h->dispatch_error = false;
+    if (h->async_err != hipSuccess) {                       // an enqueue call failed: say which one (the caller's message names the phase)
+        fprintf(stderr, "mpqr: %s failed: %s\n", h->async_what, hipGetErrorString(h->async_err));
+        h->async_err = hipSuccess; f = true;
+    }
+    return f;
+}
 static int need_plan(mpqr_handle_t h, bool dist = false) {
     if (!h) return MPQR_ERR_INVALID;
     t_dispatch_handle = h;                                  // GEMMs enqueued by this call report to this handle
@@ -1658,7 +1674,7 @@ int mpqr_factor(mpqr_handle_t h) {
     h->n_gh_leaves = gh_total;
     h->n_robust_leaves = 0;
     for (char c : h->leaf_robust) h->n_robust_leaves += c ? 1 : 0;
-    if (dispatch_failed(h)) return fail(h, MPQR_ERR_STATE, "a GEMM of the factorisation found no kernel for its operand staging / epilogue");
+    if (dispatch_failed(h)) return fail(h, MPQR_ERR_STATE, "a GEMM of the factorisation found no kernel for its operand staging / epilogue, or an enqueue call failed (stderr)");
     return MPQR_OK;
 }
 
@@ -2206,9 +2222,9 @@ int mpqr_wy_transform_f32(mpqr_handle_t h, const float* A, int m, int n, int go,
         float *dV = nullptr, *dT = nullptr, *dW = nullptr, *dQp = nullptr;
         if ((rc = dalloc(h, &dV, V.size())) || (rc = dalloc(h, &dT, Tl.size())) || (rc = dalloc(h, &dW, V.size())) ||
             (rc = dalloc(h, &dQp, (size_t)W * W))) { if (dV) (void)hipFree(dV); if (dT) (void)hipFree(dT); if (dW) (void)hipFree(dW); return rc; }
-        (void)hipMemcpyAsync(dV, V.data(), V.size() * 4, hipMemcpyHostToDevice, h->s0);
-        (void)hipMemcpyAsync(dT, Tl.data(), Tl.size() * 4, hipMemcpyHostToDevice, h->s0);
-        (void)hipMemsetAsync(dQp, 0, (size_t)W * W * 4, h->s0);
+        HIPQ(h, hipMemcpyAsync(dV, V.data(), V.size() * 4, hipMemcpyHostToDevice, h->s0));
+        HIPQ(h, hipMemcpyAsync(dT, Tl.data(), Tl.size() * 4, hipMemcpyHostToDevice, h->s0));
+        HIPQ(h, hipMemsetAsync(dQp, 0, (size_t)W * W * 4, h->s0));
         launch_set_identity(dQp, W, W, W, h->s0);
         SgemmArgs a{}; a.A = dV; a.lda = pw; a.B = dT; a.ldb = pw; a.C = dW; a.ldc = pw; a.M = W; a.N = pw; a.K = pw;
         a.alpha = 1.f; a.beta = 0.f; a.nslab_a = 1;
@@ -2551,39 +2567,39 @@ int mpqr_dist_update_part(mpqr_handle_t h, int s, int part) {
     if (part == 2 || !two_streams) {
         if (part == 0) { /* covered by part 1 below */ }
         else {
-            if (two_streams) (void)hipStreamWaitEvent(h->s0, h->ev_dist_far, 0);         // earlier far-stream parts first
+            if (two_streams) HIPQ(h, hipStreamWaitEvent(h->s0, h->ev_dist_far, 0));         // earlier far-stream parts first
             apply_node(h, nd, h->dA, h->lda, lc0, h->nloc, true, h->a_scale, true, 0, true);
         }
     } else if (part == 0) {
         // block s+1's columns carry every earlier update once the previous far-stream part is done
-        (void)hipStreamWaitEvent(h->s0, h->ev_dist_far, 0);
+        HIPQ(h, hipStreamWaitEvent(h->s0, h->ev_dist_far, 0));
         apply_node(h, nd, h->dA, h->lda, lc0, lc1, true, h->a_scale, false, 0, true);
     } else {
-        (void)hipEventRecord(h->ev_dist_chain, h->s0);                                   // the block's V, T (unpack / factor) are on the chain stream
-        (void)hipStreamWaitEvent(h->s1, h->ev_dist_chain, 0);
+        HIPQ(h, hipEventRecord(h->ev_dist_chain, h->s0));                                   // the block's V, T (unpack / factor) are on the chain stream
+        HIPQ(h, hipStreamWaitEvent(h->s1, h->ev_dist_chain, 0));
         apply_node(h, nd, h->dA, h->lda, lc1, h->nloc, true, h->a_scale, true, 1, true);
-        (void)hipEventRecord(h->ev_dist_far, h->s1);
+        HIPQ(h, hipEventRecord(h->ev_dist_far, h->s1));
     }
     if (part != 0 && h->opts.form_q && h->S2 && s < (int)h->qpair.size() && h->qpair[s] >= 0) {
         // Q formation works on pairs of blocks: T of the pair (s-1, s), behind this rank's update with block s
         hipStream_t ms = (part == 1 && two_streams) ? h->s1 : h->s0;
         if (ms == h->s1) {                                 // V, T of block s are on the chain stream (factor / unpack)
-            (void)hipEventRecord(h->ev_dist_chain, h->s0); (void)hipStreamWaitEvent(h->s1, h->ev_dist_chain, 0);
+            HIPQ(h, hipEventRecord(h->ev_dist_chain, h->s0)); HIPQ(h, hipStreamWaitEvent(h->s1, h->ev_dist_chain, 0));
         }
         merge_pair(h, h->qpair[s], ms);
-        if (ms == h->s1) (void)hipEventRecord(h->ev_dist_far, h->s1);
+        if (ms == h->s1) HIPQ(h, hipEventRecord(h->ev_dist_far, h->s1));
     }
     if (part != 0 && h->opts.form_q && h->S2 && h->qroot >= 0 && s < (int)h->qmerge_after.size() && !h->qmerge_after[s].empty()) {
         // tall matrices: T of blocks 0..s from T of blocks 0..s-1 (every rank builds the whole T itself: it holds every block's V and T),
         // for the one-shot Q formation of its column shard (mpqr_dist_form_q)
         hipStream_t ms = (part == 1 && two_streams) ? h->s1 : h->s0;
-        if (ms == h->s1) { (void)hipEventRecord(h->ev_dist_chain, h->s0); (void)hipStreamWaitEvent(h->s1, h->ev_dist_chain, 0); }
+        if (ms == h->s1) { HIPQ(h, hipEventRecord(h->ev_dist_chain, h->s0)); HIPQ(h, hipStreamWaitEvent(h->s1, h->ev_dist_chain, 0)); }
         for (int id : h->qmerge_after[s]) merge_prefix(h, id, ms);
-        if (ms == h->s1) (void)hipEventRecord(h->ev_dist_far, h->s1);
+        if (ms == h->s1) HIPQ(h, hipEventRecord(h->ev_dist_far, h->s1));
     }
     if (last && part != 0) {
         h->pairs_ready = h->opts.form_q && h->S2 != nullptr;
-        if (two_streams) (void)hipStreamWaitEvent(h->s0, h->ev_dist_far, 0);
+        if (two_streams) HIPQ(h, hipStreamWaitEvent(h->s0, h->ev_dist_far, 0));
         HIPCHK(h, hipEventRecord(h->ev[1], h->s0)); h->factored = true;
     }
     HIPCHK(h, hipGetLastError());
@@ -2595,7 +2611,7 @@ int mpqr_dist_update(mpqr_handle_t h, int s) { return mpqr_dist_update_part(h, s
 int mpqr_dist_form_q(mpqr_handle_t h) {
     int rc = need_plan(h, true); if (rc) return rc;
     if (!h->factored) return fail(h, MPQR_ERR_STATE, "factor first");
-    if (h->Xt1) (void)hipStreamWaitEvent(h->s0, h->ev_dist_far, 0);
+    if (h->Xt1) HIPQ(h, hipStreamWaitEvent(h->s0, h->ev_dist_far, 0));
     HIPCHK(h, hipMemsetAsync(h->dQ, 0, (size_t)h->m_pad * h->ldq * sizeof(float), h->s0));
     launch_identity_cyclic(h->dQ, h->ldq, h->m, h->qloc, h->Ko, h->world, h->rank, h->s0);
     if (h->Qt) {                                           // transposed fp16 shadow of the local columns (as in form_q)
@@ -2609,7 +2625,7 @@ int mpqr_dist_form_q(mpqr_handle_t h) {
         // Q[:, J] -= W V[J, :]^T into the identity it already holds (read-modify-write: every GEMM kernel of the library has that epilogue).
         const Node rt = h->nodes[h->qroot];
         const int Kr = rt.ldt;
-        if (h->tq_on && rt.id < (int)h->ev_T.size()) (void)hipStreamWaitEvent(h->s0, h->ev_T[rt.id], 0);
+        if (h->tq_on && rt.id < (int)h->ev_T.size()) HIPQ(h, hipStreamWaitEvent(h->s0, h->ev_T[rt.id], 0));
         GemmArgs w{};                                       // W[m x Kr] = V T   (T upper triangular: k <= n)
         w.A = h->Vh + rt.a0; w.lda = h->ldvh;
         w.Bt = h->Tth + rt.toff; w.ldb = rt.tld;
