@@ -2442,7 +2442,7 @@ int mpqr_dist_begin(mpqr_handle_t h, float absmax) {
     if (absmax > 0.f && std::isfinite(absmax)) { int e; frexpf(absmax * sqrtf((float)h->m), &e); sc = ldexpf(1.f, 8 - e); }
     h->a_scale = sc;
     h->far_used = 0; h->far_flops.clear(); h->far_bytes.clear(); h->chain_used = 0; h->v8_node = -1;
-    h->pairs_ready = false; h->n_passes = 1; h->n_robust_leaves = 0;
+    h->pairs_ready = false; h->n_passes = 1; h->n_robust_leaves = 0; h->n_gh_leaves = 0;
     HIPCHK(h, hipEventRecord(h->ev[0], h->s0));
     HIPCHK(h, hipMemcpyAsync(h->dA, h->dA0, (size_t)h->m_pad * h->lda * sizeof(float), hipMemcpyDeviceToDevice, h->s0));
     if (h->Xt1) {                                   // far stream starts behind the copy-in; its "done" event starts signalled

@@ -787,6 +787,36 @@ def test_distributed_schedule_on_one_gpu(mp, po, m, n, r, ko, world, la):
         assert relF(V[:, :first], V0[:, :first]) <= 3e-3
 
 
+def test_distributed_path_repeats_a_flagged_factorisation_on_the_robust_kernels(mp, po):
+    """The distributed block loop never synchronises its host per block (round 4): an ill-conditioned tall leaf raises its mapped flag
+    word, the flags are asked once after the loop and the factorisation is repeated with every tall leaf on the column-by-column
+    kernels (dist.factor; with more ranks the flag is all-reduced so that every rank takes the second pass: tests/test_dist_gloo.py).
+    1500 x 480, r = 32, an exactly dependent column and a zero column: A = QR within the tolerance, Q orthogonal."""
+    from mixedprecisionblockqr_amd import dist as mpdist
+    rng = np.random.default_rng(11)
+    m, n = 1500, 480
+    A = rng.standard_normal((m, n)).astype(np.float32)
+    A[:, 7] = A[:, 3]; A[:, 300] = 0
+    eng = mpdist.GpuEngine(0, m, n, 32, 1, 0, outer_block=128)
+    try:
+        eng.set_local(A)
+        mpdist.factor(eng, mpdist.NullComm())
+        assert eng.flagged() == 0                      # the pass that was kept ran on the robust kernels: nothing flags
+        F, Q = eng.local_factor(), eng.local_q()
+        eng.set_local(rng.standard_normal((m, n)).astype(np.float32))       # a new input resets the robust mode ...
+        mpdist.factor(eng, mpdist.NullComm())
+        assert eng.flagged() == 0
+        t = eng.timings()
+        assert t["n_gh_leaves"] >= 1                    # ... and a clean matrix stays on the Gram-Householder leaves
+    finally:
+        eng.close()
+    R = np.triu(F[:m])
+    mt = po.metrics(A, R, Q)
+    assert np.isfinite(F).all() and np.isfinite(Q).all()
+    assert mt["backward_error_f64"] <= 1e-3 and mt["q_error_fro"] <= 2e-3 * np.sqrt(m), mt
+    assert (F[:, 300] == 0).all()                       # zero column skipped, as qr.cu:242-244
+
+
 # ---- opt-in schedules and kernels (measured alternatives kept behind MPQR_* switches): every one of them must still
 # produce the same factorisation.  The switches are read once per process, hence one child interpreter per setting.
 OPT_IN = [

@@ -18,11 +18,11 @@ def per_launch(path, counter, needle, big_only=False):
     rows = list(csv.DictReader(open(path)))
     solve = [r for r in rows if "gh_solve" in r["Kernel_Name"]]
     chain_q = solve[0]["Queue_Id"] if solve else None
-    # the chain queue's launches count from Q formation on: the first identity_kernel behind the factorisation's first solve (the
-    # solves bench.py times alone afterwards, mpqr_bench_leaf_solve, come later still and must not move that mark)
-    first_solve = min(int(r["Dispatch_Id"]) for r in solve) if solve else -1
-    ident = [int(r["Dispatch_Id"]) for r in rows if "identity_kernel" in r["Kernel_Name"] and int(r["Dispatch_Id"]) > first_solve]
-    last_solve = min(ident) if ident else (max(int(r["Dispatch_Id"]) for r in solve) if solve else -1)
+    # the chain queue's launches count from Q formation on: everything behind the factorisation's LAST gh_apply (round 4: Q = I is set
+    # up at the start of the factorisation, so the identity kernels no longer mark the Q phase; the solves bench.py times alone
+    # afterwards, mpqr_bench_leaf_solve, launch no gh_apply and so do not move the mark)
+    applies = [int(r["Dispatch_Id"]) for r in rows if "gh_apply" in r["Kernel_Name"]]
+    last_solve = max(applies) if applies else (max(int(r["Dispatch_Id"]) for r in solve) if solve else -1)
     tcol = [r for r in rows if "t_colblock_h16" in r["Kernel_Name"]]      # the T stream (round 3: it also runs the deferred in-block updates)
     t_q = tcol[0]["Queue_Id"] if tcol else None
     vals = []

@@ -10,8 +10,12 @@ ab = [i for i, r in enumerate(rows) if 'absmax' in r['Kernel_Name']]          # 
 lo = ab[-1]
 hi = next((i for i in range(lo, len(rows)) if 'lower_norm' in rows[i]['Kernel_Name'] or 'strip_r' in rows[i]['Kernel_Name'] or 'pack_factor' in rows[i]['Kernel_Name']), len(rows))
 run = rows[lo:hi]
-ident = next(i for i, r in enumerate(run) if 'identity' in r['Kernel_Name'])
-q = run[ident:]
+# Q formation = everything behind the last gh_apply of the run (round 4: Q = I is set up at the START of the factorisation, the identity
+# kernels no longer mark the phase)
+last_apply = max(i for i, r in enumerate(run) if 'gh_apply' in r['Kernel_Name'])
+q = run[last_apply + 1:]
+first = next((i for i, r in enumerate(q) if 'gemm6_f16_kernel<1, 0' in r['Kernel_Name'] or 'gemm2_f16_kernel' in r['Kernel_Name']), 0)   # first X = Q2^T V
+q = q[max(first - 2, 0):]
 cut = next((i for i, r in enumerate(q) if 'gh_solve' in r['Kernel_Name'] or 'absmax' in r['Kernel_Name']), len(q))   # (bench.py's stand-alone solve timing follows)
 q = q[:cut]
 lastg = max((i for i, r in enumerate(q) if 'gemm' in r['Kernel_Name']), default=len(q) - 1)      # (memsets of the metric pass may follow)
