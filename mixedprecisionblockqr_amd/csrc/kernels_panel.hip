@@ -296,11 +296,19 @@ __global__ __launch_bounds__(256) void gh_gram_kernel(LeafArgs a, double* __rest
     KT_DECL; KT();
     const int row0 = a.c0 + (blockIdx.x >> 1) * GH_ROWS;   // ALL leaf rows, top block included: G = Gram of the remaining rows at k = c0
     const int hb = blockIdx.x & 1;                        // which half of G's rows this workgroup produces
+    // all 16 loads of a thread first (clamped row, masked afterwards), then the conversions and LDS stores: with the load inside the bounds
+    // branch the compiler emitted load -> s_waitcnt vmcnt(0) -> store sixteen times, one memory latency each -- 14-24 k cycles of this
+    // kernel's ~30 k (in-kernel stamps tools/ktrace_solve.sh; ISA: hipcc -S)
+    float4 gv[16];
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+        const int id = tid + 256 * i, lr = id >> 5, c4 = id & 31, row = min(row0 + lr, a.mrows - 1);
+        gv[i] = *(const float4*)(a.A + (long)row * a.lda + a.cb + 4 * c4);
+    }
 #pragma unroll
     for (int i = 0; i < 16; i++) {
         const int id = tid + 256 * i, lr = id >> 5, c4 = id & 31, row = row0 + lr;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (row < a.mrows) v = *(const float4*)(a.A + (long)row * a.lda + a.cb + 4 * c4);
+        const float4 v = (row < a.mrows) ? gv[i] : make_float4(0.f, 0.f, 0.f, 0.f);
         double* d = &tile[lr * GH_TD + 4 * c4];
         *(double2*)d = make_double2((double)v.x, (double)v.y);
         *(double2*)(d + 2) = make_double2((double)v.z, (double)v.w);
@@ -442,11 +450,16 @@ __global__ __launch_bounds__(256) void gh_apply_kernel(LeafArgs a, const float* 
         const int e4 = tid + 256 * q, wi = e4 >> 5, wk = (e4 & 31) * 4;
         *(float4*)&Cs[wi * GH_TS + wk] = *(const float4*)&Cv[wi * GW + wk];
     }
+    float4 av[8];                                          // (loads first, as in gh_gram: eight serialised latencies otherwise)
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        const int id = tid + 256 * i, lr = id >> 5, c4 = id & 31, row = min(row0 + lr, a.mrows - 1);
+        av[i] = *(const float4*)(a.A + (long)row * a.lda + a.cb + 4 * c4);
+    }
 #pragma unroll
     for (int i = 0; i < 8; i++) {
         const int id = tid + 256 * i, lr = id >> 5, c4 = id & 31, row = row0 + lr;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (row < a.mrows) v = *(const float4*)(a.A + (long)row * a.lda + a.cb + 4 * c4);
+        const float4 v = (row < a.mrows) ? av[i] : make_float4(0.f, 0.f, 0.f, 0.f);
         float* d = &As[lr * 129 + 4 * c4];
         d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
     }
@@ -693,15 +706,29 @@ __global__ __launch_bounds__(1024) void t_panel_kernel(const float* __restrict__
     const int w = c1 - c0, off = c0 - a0;
     const int nblk = (w + 31) / 32;          // active 32-blocks
     KT_DECL; KT();
+    // the 16 loads of a thread first (unconditional: clamped addresses, masked afterwards), THEN the LDS stores: with the loads inside the
+    // branches the compiler kept load -> use in program order and the kernel's load phase took 16.8 k cycles for 64 KB (one miss
+    // latency per load: S was just written by gh_reduce_f32 on other CUs) -- in-kernel stamps, tools/ktrace_solve.sh
+    float sv[TP * TP / 1024];
 #pragma unroll
-    for (int q = 0; q < TP * TP / 1024; q++) {              // fully unrolled: the 16 loads of a thread are in flight together
+    for (int q = 0; q < TP * TP / 1024; q++) {
+        const int e = tid + 1024 * q;
+        const int i = min(e >> 7, w - 1), j = min(e & 127, w - 1);
+        sv[q] = S[(long)(off + i) * lds_ + off + j];
+    }
+    if (nslab > 1) {
+#pragma unroll
+        for (int q = 0; q < TP * TP / 1024; q++) {
+            const int e = tid + 1024 * q;
+            const int i = min(e >> 7, w - 1), j = min(e & 127, w - 1);
+            for (int sl = 1; sl < nslab; sl++) sv[q] += S[(long)sl * slab_stride + (long)(off + i) * lds_ + off + j];
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < TP * TP / 1024; q++) {
         const int e = tid + 1024 * q;
         const int i = e >> 7, j = e & 127;
-        float v = 0.f;
-        if (i < w && j < w && j >= i) {
-            v = S[(long)(off + i) * lds_ + off + j];
-            for (int sl = 1; sl < nslab; sl++) v += S[(long)sl * slab_stride + (long)(off + i) * lds_ + off + j];
-        }
+        float v = (i < w && j < w && j >= i) ? sv[q] : 0.f;
         if (i == j) { tdiag[i] = (i < w) ? (v > 0.f ? 2.0f / v : 0.f) : 1.f; v = 0.f; }
         Ss[i * TPS + j] = v;
         Ts[i * TPS + j] = 0.f;

@@ -421,12 +421,21 @@ __global__ __launch_bounds__(S3_THREADS) void gh_solve3_kernel(LeafArgs a, const
     const int nb = (w + 15) / 16, ncol = 16 * nb;
     KT_DECL; KT();
     // G and B in leaf coordinates, padded with the identity / zero: the padding decouples
-    auto Gw = [&](int i, int j) -> double { return (i < w && j < w) ? G[(off + i) * GW + off + j] : (i == j ? 1.0 : 0.0); };
-    auto Bw = [&](int i, int j) -> float { return (i < w && j < w) ? a.A[(long)(a.c0 + i) * a.lda + a.c0 + j] : 0.f; };
+    // (the loads are unconditional -- clamped index, value selected afterwards -- so that a lane's 20 - 50 of them are in flight together:
+    //  behind a branch each one waited for the previous, ~20 k cycles of set-up per launch; tools/ktrace_solve.sh)
+    auto Gw = [&](int i, int j) -> double {
+        const double g = G[(off + min(i, w - 1)) * GW + off + min(j, w - 1)];
+        return (i < w && j < w) ? g : (i == j ? 1.0 : 0.0);
+    };
+    auto Bw = [&](int i, int j) -> float {
+        const float b = a.A[(long)(a.c0 + min(i, w - 1)) * a.lda + a.c0 + min(j, w - 1)];
+        return (i < w && j < w) ? b : 0.f;
+    };
 
     for (int e = tid; e < TP * TPS; e += S3_THREADS) Ws[e] = 0.f;
     if (tid < GW) { vdl[tid] = 0.f; tdiag[tid] = 1.f; sgn[tid] = 1.f; cmask[tid] = 1; }
     if (tid == 0) lflag = 0;
+    KT();
 
     // Every role runs the same sequence of workgroup barriers (one after the set-up, two per round); the roles' code paths are
     // separate so that each gets its own register allocation.
@@ -434,14 +443,29 @@ __global__ __launch_bounds__(S3_THREADS) void gh_solve3_kernel(LeafArgs a, const
     if (wave == 0) {
         // ================================================= Cholesky chain
         int bad = 0;
+        {   // all 34 loads of a lane first, then the LDS stores: written as load -> store pairs the compiler kept them in program order and
+            // the wave paid one memory latency per load (G was just written by gh_reduce on other CUs: misses) -- 21 k of the kernel's
+            // ~155 k cycles before the first round could start (in-kernel stamps, tools/ktrace_solve.sh)
+            double gv[2][17];
 #pragma unroll
-        for (int s = 0; s < 2; s++) {
-            const int col = lane + 64 * s;
-            thr[col] = GH_RHO_MIN * Gw(col, col);            // rho threshold: ||a_j||^2 over all leaf rows
+            for (int s = 0; s < 2; s++) {
+                const int col = lane + 64 * s;
+                gv[s][16] = Gw(col, col);
 #pragma unroll
-            for (int rr = 0; rr < 16; rr++) buf[rr * S3_BS + col] = Gw(rr, col);   // row panel 0
+                for (int rr = 0; rr < 16; rr++) gv[s][rr] = Gw(rr, col);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int s = 0; s < 2; s++) {
+                const int col = lane + 64 * s;
+                thr[col] = GH_RHO_MIN * gv[s][16];            // rho threshold: ||a_j||^2 over all leaf rows
+#pragma unroll
+                for (int rr = 0; rr < 16; rr++) buf[rr * S3_BS + col] = gv[s][rr];   // row panel 0
+            }
         }
+        KT();
         s3_barrier();
+        KT();
         for (int r = 0; r <= nb; r++) {
             S3T(0, 2 * r);
             if (r < nb) {
@@ -498,23 +522,42 @@ __global__ __launch_bounds__(S3_THREADS) void gh_solve3_kernel(LeafArgs a, const
         double4s Nacc[5];
         float4s Bacc[8];
         int NI[5], NJ[5];
+        bool NV[5]; int NP[5][4]; bool BV[8][4];
 #pragma unroll
         for (int t = 0; t < 5; t++) {
             const int I = (t <= uh) ? t : t + (u - uh);
             const int J = (u - I) & 7;
             const bool valid = I < 8 && J >= I && J < nb;
             NI[t] = valid ? I : 99; NJ[t] = J;                  // 99: never selected
+            NV[t] = valid;
 #pragma unroll
-            for (int e = 0; e < 4; e++) Nacc[t][e] = valid ? Gw(16 * I + lk + 4 * e, 16 * J + li) : 0.0;
+            for (int e = 0; e < 4; e++) {                   // raw (clamped) load now, padding / masking AFTER the first barrier: a select here would wait for the load
+                const int gi = 16 * min(I, 7) + lk + 4 * e, gj = 16 * J + li;
+                NP[t][e] = (gi < w && gj < w) ? 2 : (gi == gj ? 1 : 0);        // 2: the loaded value, 1: identity padding, 0: zero
+                Nacc[t][e] = G[(off + min(gi, w - 1)) * GW + off + min(gj, w - 1)];
+            }
         }
 #pragma unroll
         for (int I = 0; I < 8; I++) {
             const int J = (u - I) & 7;
 #pragma unroll
-            for (int e = 0; e < 4; e++) Bacc[I][e] = (I < nb && J < nb) ? Bw(16 * I + 4 * lk + e, 16 * J + li) : 0.f;
+            for (int e = 0; e < 4; e++) {
+                const int bi = 16 * I + 4 * lk + e, bj = 16 * J + li;
+                BV[I][e] = I < nb && J < nb && bi < w && bj < w;
+                Bacc[I][e] = a.A[(long)(a.c0 + min(bi, w - 1)) * a.lda + a.c0 + min(bj, w - 1)];
+            }
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the top block is overwritten with R later on
+        // (no wait for these loads here: the first round's Cholesky chain needs wave 0's panel only and runs while they are still in
+        //  flight; the accumulators are masked -- their first use -- behind the barrier, two rounds before the top block is overwritten with R)
         s3_barrier();
+#pragma unroll
+        for (int t = 0; t < 5; t++)
+#pragma unroll
+            for (int e = 0; e < 4; e++) Nacc[t][e] = !NV[t] ? 0.0 : (NP[t][e] == 2 ? Nacc[t][e] : (NP[t][e] == 1 ? 1.0 : 0.0));
+#pragma unroll
+        for (int I = 0; I < 8; I++)
+#pragma unroll
+            for (int e = 0; e < 4; e++) Bacc[I][e] = BV[I][e] ? Bacc[I][e] : 0.f;
         // R[k][j] = -sgn(u0_k) c_kj (j >= k): wave u sends out rows 2u, 2u + 1 of every block.  The Cholesky rows are read (fp32)
         // in the round the Householder waves work on the block; the signs exist one barrier later, so the stores wait in
         // registers until the next round
@@ -676,7 +719,7 @@ __global__ __launch_bounds__(S3_THREADS) void gh_solve3_kernel(LeafArgs a, const
         const int i = (e >> 7) - off, k = (e & 127) - off;
         Cv[e] = (i >= 0 && i <= k && k < w && cmask[k]) ? Ts[i * TPS + k] : 0.f;
     }
-    KT(); KT_DUMP(7, "gh_solve3 load|loop|out|inverse|cstore");
+    KT(); KT_DUMP(7, "gh_solve3 zero|loads|barrier0|loop|out|inverse|cstore");
 #ifdef MPQR_KTRACE
     __syncthreads();
     if (tid == 0 && atomicSub(&g_s3_trace_left, 1) > 0) {
