@@ -291,6 +291,19 @@ __global__ __launch_bounds__(256) void sgemm_mfma_kernel(SgemmArgs g) {
             reg[i] = v;
         }
     };
+    // Fast form of load_op for the common case -- one slab, 16-byte aligned rows, the whole TB x SK piece inside the operand: the loads
+    // are unconditional, so a thread's loads of BOTH operands are in flight together.  (load_op's bounds / slab branches made the
+    // compiler wait for every load before issuing the next: 50 of 51 loads of sgemm_mfma_kernel<64> serialised in the ISA, and these
+    // GEMMs -- the column blocks of the block-level T, two per leaf beside the chain and on its critical path at every block boundary --
+    // are short chains of K steps whose time is that latency.)
+    auto fast_op = [&](const float* P, long ld, bool kcontig, int x0, int k0, float4* reg) {
+#pragma unroll
+        for (int i = 0; i < NL; i++) {
+            const int id = tid + 256 * i;
+            if (kcontig) reg[i] = *(const float4*)(P + (long)(x0 + (id >> 2)) * ld + k0 + (id & 3) * 4);
+            else reg[i] = *(const float4*)(P + (long)(k0 + id / (TB / 4)) * ld + x0 + (id % (TB / 4)) * 4);
+        }
+    };
     auto store_op = [&](float (*Ls)[LDT], bool kcontig, const float4* reg) {
 #pragma unroll
         for (int i = 0; i < NL; i++) {
@@ -314,16 +327,25 @@ __global__ __launch_bounds__(256) void sgemm_mfma_kernel(SgemmArgs g) {
             for (int e = 0; e < 16; e++) acc[i][j][e] = 0.f;
 
     const bool a_kc = !g.transA, b_kc = g.transB;
+    // uniform over the workgroup: every K step of this workgroup reads full, aligned, single-slab pieces of both operands
+    const bool k_full = (k_lo % SK) == 0 && k_hi <= g.K && ((k_hi - k_lo) % SK) == 0;
+    const bool fast = k_full && a_vec && b_vec && g.nslab_a <= 1 && nsb <= 1 && bm + TB <= g.M && bn + TB <= g.N;
     if (k_lo < k_hi) {
-        load_op(g.A, g.lda, a_kc, bm, g.M, k_lo, a_vec, g.nslab_a, g.slab_a, ra);
-        load_op(g.B, g.ldb, b_kc, bn, g.N, k_lo, b_vec, nsb, g.slab_b, rb);
+        if (fast) { fast_op(g.A, g.lda, a_kc, bm, k_lo, ra); fast_op(g.B, g.ldb, b_kc, bn, k_lo, rb); }
+        else {
+            load_op(g.A, g.lda, a_kc, bm, g.M, k_lo, a_vec, g.nslab_a, g.slab_a, ra);
+            load_op(g.B, g.ldb, b_kc, bn, g.N, k_lo, b_vec, nsb, g.slab_b, rb);
+        }
         store_op(As, a_kc, ra); store_op(Bs, b_kc, rb);
         __syncthreads();
         for (int k0 = k_lo; k0 < k_hi; k0 += SK) {
             const bool more = k0 + SK < k_hi;
             if (more) {
-                load_op(g.A, g.lda, a_kc, bm, g.M, k0 + SK, a_vec, g.nslab_a, g.slab_a, ra);
-                load_op(g.B, g.ldb, b_kc, bn, g.N, k0 + SK, b_vec, nsb, g.slab_b, rb);
+                if (fast) { fast_op(g.A, g.lda, a_kc, bm, k0 + SK, ra); fast_op(g.B, g.ldb, b_kc, bn, k0 + SK, rb); }
+                else {
+                    load_op(g.A, g.lda, a_kc, bm, g.M, k0 + SK, a_vec, g.nslab_a, g.slab_a, ra);
+                    load_op(g.B, g.ldb, b_kc, bn, g.N, k0 + SK, b_vec, nsb, g.slab_b, rb);
+                }
             }
 #pragma unroll
             for (int ks = 0; ks < SK / 2; ks++) {

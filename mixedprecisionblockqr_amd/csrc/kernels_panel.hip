@@ -66,6 +66,12 @@ __global__ __launch_bounds__(256) void leaf_step_kernel(LeafArgs a, int k, int n
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int cg = tid & 7, rl = tid >> 3;
     const int kq = k - a.cb;
+    // the workgroup's rows of the window first (clamped, masked in phase 1): eight loads in flight behind phase 0, instead of eight
+    // memory latencies in a row inside phase 1 (the load sat in the bounds branch: load -> s_waitcnt vmcnt(0) -> use, eight times)
+    float4 vin[RPW / 32];
+#pragma unroll
+    for (int p = 0; p < RPW / 32; p++)
+        vin[p] = *(const float4*)(a.A + (long)min(k + (int)blockIdx.x * RPW + p * 32 + rl, a.mrows - 1) * a.lda + a.cb + 4 * cg);
 
     // ---- phase 0: every workgroup sums the previous launch's partials (tiny, L2-resident)
     {
@@ -110,8 +116,7 @@ __global__ __launch_bounds__(256) void leaf_step_kernel(LeafArgs a, int k, int n
         const int row = row0 + p * 32 + rl;
         const bool valid = row < a.mrows;
         float* ptr = a.A + (long)row * a.lda + a.cb + 4 * cg;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (valid) v = *(const float4*)ptr;
+        float4 v = valid ? vin[p] : make_float4(0.f, 0.f, 0.f, 0.f);
         const float comp = pick(v, kq & 3);
         const float aik = __shfl(comp, (lane & ~7) | (kq >> 2));
         const float vi = (aik + (row == k ? alpha : 0.f)) * inv;
