@@ -133,6 +133,7 @@ struct mpqr_handle_s {
     float* rbTf = nullptr; half_t* rbTh = nullptr; half_t* rbTth = nullptr; size_t rb_elems = 0;   // T arena of a robust leaf's sub-tree
     bool force32 = false;         // tree building: only 32-column leaves (sub-tree of a robustly factored tall leaf)
     int gh_min_rows = 128;        // leaves with more rows than this below their first column use Gram-Householder
+    bool tail_leaf = true;        // the last <= 128 rows as one leaf_tail_kernel leaf (MPQR_TAIL_LEAF=0: 32-column leaves, as before round 4)
     float* tmp1 = nullptr; float* tmp2 = nullptr; size_t tmp_elems = 0;
     float* Tf = nullptr; half_t* Th = nullptr; half_t* Tth = nullptr; size_t t_elems = 0;
     double* dmetric = nullptr;   // 8 doubles
@@ -256,10 +257,13 @@ void free_plan(mpqr_handle_t h) {
 // ---- column-range tree
 // A node starting at column c0 is "tall" when more than gh_min_rows rows lie below its diagonal: tall leaves are
 // up to 128 columns wide (Gram-Householder), short ones up to 32 (one workgroup, register resident).
-int leaf_width(mpqr_handle_t h, int c0) { return (!h->force32 && h->m - c0 > h->gh_min_rows) ? 128 : 32; }
+// The last <= 128 rows of a (nearly) square matrix have no tall part: one 128-wide "tail" leaf (leaf_tail_kernel, plain Householder in
+// one workgroup) instead of four 32-column leaves and their merges.
+bool is_tail(mpqr_handle_t h, int c0) { return !h->force32 && h->tail_leaf && h->m - c0 <= 128; }
+int leaf_width(mpqr_handle_t h, int c0) { return (!h->force32 && (h->m - c0 > h->gh_min_rows || is_tail(h, c0))) ? 128 : 32; }
 bool is_leaf(mpqr_handle_t h, int c0, int c1) {
     const int lw = leaf_width(h, c0);
-    return (c1 - c0) <= lw && (c0 / lw) == ((c1 - 1) / lw) && (lw == 32 || h->m - c1 >= 1);
+    return (c1 - c0) <= lw && (c0 / lw) == ((c1 - 1) / lw) && (lw == 32 || h->m - c1 >= 1 || is_tail(h, c0));
 }
 
 int pick_split(mpqr_handle_t h, int c0, int c1, int r) {
@@ -593,7 +597,8 @@ int factor_rec(mpqr_handle_t h, int id, bool do_panel) {
     hipStream_t st = tq ? h->sT : h->s0;
     if (nd.left < 0) {
         if (do_panel && pass_is_flagged(h)) return MPQR_ABORT_PASS;
-        const bool tall = leaf_width(h, nd.c0) == 128;
+        const bool tail = is_tail(h, nd.c0);             // (plain Householder: never flagged, nothing to make robust)
+        const bool tall = leaf_width(h, nd.c0) == 128 && !tail;
         const bool robust_leaf = h->robust || (id < (int)h->leaf_robust.size() && h->leaf_robust[id]);
         if (do_panel && robust_leaf && !h->force32 && tall) {
             rc = robust_tall_leaf(h, nd, do_panel);
@@ -604,12 +609,13 @@ int factor_rec(mpqr_handle_t h, int id, bool do_panel) {
         LeafArgs a{};
         if (do_panel) {
             Range rg("mpqr:panel");
-            a.A = h->Aeff; a.lda = h->lda; a.mrows = h->m; a.cb = rdown(nd.c0, tall ? 128 : 32); a.c0 = nd.c0; a.c1 = nd.c1;
+            a.A = h->Aeff; a.lda = h->lda; a.mrows = h->m; a.cb = rdown(nd.c0, tall || tail ? 128 : 32); a.c0 = nd.c0; a.c1 = nd.c1;
             a.Vh = h->Vh; a.ldvh = h->ldvh; a.Vt = h->Vt; a.ldvt = h->ldvt; a.vdiag = h->vdiag;
             a.P = h->P; a.maxwg = h->maxwg; a.hostflag = h->hflag_dev + h->cur_block;
             const bool fused = tall && !h->Vf;    // fp16 mode: the Gram of the rounded reflectors comes out of gh_apply
             int* flag = h->dflag + (id < h->nflag ? id : 0);
             if (tall) { launch_leaf_gram_householder(a, h->Gp, h->Gs, h->Cv, flag, fused ? h->Sp : nullptr, nullptr, h->s0); h->n_gh_leaves++; }
+            else if (tail) launch_leaf_tail(a, h->Sleaf, h->s0);
             else launch_leaf_factor(a, h->s0);
             if (h->Vf) launch_extract_vf(h->Aeff, h->lda, h->vdiag, h->Vf, h->n_pad, h->m, nd.c0, nd.c1, h->s0);
             have_s = fused;
@@ -620,7 +626,11 @@ int factor_rec(mpqr_handle_t h, int id, bool do_panel) {
         }
         Range rg("mpqr:wy_T");
         if (tq) t_stream_follows_chain(h);
-        if (have_s) {
+        if (do_panel && tail && !h->Vf) {                  // the tail kernel left S itself (window coordinates, like the reduced partials below)
+            const int sh = nd.a0 - a.cb;
+            launch_t_leaf(h->Sleaf + (long)sh * 128 + sh, 1, 0, 128, nd.a0, nd.c0, nd.c1, h->Tf + nd.toff, h->Th + nd.toff,
+                          h->Tth + nd.toff, nd.ldt, st);
+        } else if (have_s) {
             // S = sum of gh_apply's partial Grams, in window coordinates (128 x 128 from a.cb); the node's aligned
             // range starts at a0 >= cb
             launch_gh_reduce_f32(h->Sp, gh_num_partials(a), h->S, st);
@@ -740,8 +750,27 @@ int factor_block_flat(mpqr_handle_t h, int top, const std::vector<int>& leaves) 
         const int o = lf.c0 - tp.c0;                       // reflectors of the block before this leaf
         lf.toff = tp.toff + (size_t)o * (ld + 1);          // the leaf's T = diagonal block of the block's T
         lf.tld = ld;
-        const bool robust_leaf = h->robust || (id < (int)h->leaf_robust.size() && h->leaf_robust[id]);
-        if (robust_leaf) {
+        const bool tail = is_tail(h, lf.c0);
+        const bool robust_leaf = !tail && (h->robust || (id < (int)h->leaf_robust.size() && h->leaf_robust[id]));
+        if (tail) {
+            // the matrix's last <= 128 rows: plain Householder in one workgroup, S for its T from the same kernel
+            Range rg("mpqr:panel");
+            if (h->far_hook) { auto fh = std::move(h->far_hook); h->far_hook = nullptr; if ((rc = fh())) return rc; }
+            LeafArgs a{};
+            a.A = h->Aeff; a.lda = h->lda; a.mrows = h->m; a.cb = rdown(lf.c0, 128); a.c0 = lf.c0; a.c1 = lf.c1;
+            a.Vh = h->Vh; a.ldvh = h->ldvh; a.Vt = h->Vt; a.ldvt = h->ldvt; a.vdiag = h->vdiag;
+            a.P = h->P; a.maxwg = h->maxwg; a.hostflag = nullptr;
+            if (h->wait_after_first_leaf && (!tq || (int)j >= std::min<int>(h->pre_leaves, (int)leaves.size()))) {
+                HIPQ(h, hipStreamWaitEvent(h->s0, h->wait_after_first_leaf, 0));      // its columns still wait for the previous block's far update
+                h->wait_after_first_leaf = nullptr;
+            }
+            launch_leaf_tail(a, h->Sleaf, h->s0);
+            Range rt("mpqr:wy_T");
+            if (tq) t_stream_follows_chain(h);
+            const int sh = lf.a0 - a.cb;
+            launch_t_leaf(h->Sleaf + (long)sh * 128 + sh, 1, 0, 128, lf.a0, lf.c0, lf.c1, h->Tf + lf.toff, h->Th + lf.toff,
+                          h->Tth + lf.toff, lf.ldt, h->s0, ld);
+        } else if (robust_leaf) {
             if (h->far_hook) { auto fh = std::move(h->far_hook); h->far_hook = nullptr; if ((rc = fh())) return rc; }   // (see below)
             // column-by-column kernels through a private sub-tree; its root T (contiguous, ldt^2) goes into the diagonal block
             const size_t keep = h->nodes[id].toff;
@@ -1172,6 +1201,7 @@ static int plan_common(mpqr_handle_t h, int m, int n, int r, const mpqr_opts* op
         h->tq_on = h->sT != nullptr && o.precision != MPQR_PREC_FP32 && !(e && atoi(e) == 0);
     }
     if (const char* e = getenv("MPQR_GH_MIN_ROWS")) h->gh_min_rows = atoi(e);      // tuning hook
+    if (const char* e = getenv("MPQR_TAIL_LEAF")) h->tail_leaf = atoi(e) != 0;       // A/B hook
     h->m_pad = rup(m, 256); h->n_pad = rup(n, 256);
     int Ko = o.outer_block > 0 ? o.outer_block : 1024;
     Ko = std::max(Ko, 32);

@@ -600,6 +600,141 @@ void launch_leaf_gram_householder(const LeafArgs& a, double* Gp, double* G, floa
     if (Sp && S) launch_gh_reduce_f32(Sp, gh_num_partials(a), S, s);
 }
 
+// ------------------------------------------------------------------ the last leaf of a (nearly) square matrix: <= 128 rows left
+// Columns [c0, c1) with at most 128 rows from row c0 down (m - c0 <= 128): no tall part, so no Gram-Householder (its Cholesky recursion
+// needs >= w rows below the top block), and as 32-column leaf_wg leaves it cost four launches of ~52 us plus their in-leaf updates and
+// three levels of T merges -- ~1 ms between the last tall leaf and the start of Q formation (kernel trace, 2048^2 and 16384^2 alike).
+// Here: the rows x w block in the registers of one workgroup (thread = column j x group of 16 rows), the same Householder arithmetic as
+// leaf_wg_kernel (u, alpha = sgn(u0) ||u||, v = (u + alpha e1) / ||u + alpha e1||, w_j = 2 v^T a_j), two barriers per column:
+//   A  the owners of column k publish it (ucol), the owners of row k publish that (rowk)          | barrier
+//   B  every thread: partial u^T a_j over its 16 rows -> part[g][j]                                | barrier
+//   C  every thread: sums the partials of column j and of column k, forms alpha / inv / w_j itself, updates its 16 entries
+// Row groups above row k have nothing left to do and only keep the barriers.  Outputs as a Gram-Householder leaf's: R and V in A, the
+// fp16 copies V / V^T, vdiag, and S = V^T V of the fp16-ROUNDED reflectors (window coordinates, exact-f32 MFMA out of LDS) for t_panel.
+__global__ __launch_bounds__(1024) void leaf_tail_kernel(LeafArgs a, float* __restrict__ Sout) {
+    float* Vs = (float*)gh_smem;                               // [TP][TPS]: the rounded reflectors as fp32, row-major
+    __shared__ __attribute__((aligned(16))) float ucol[TP];
+    __shared__ float part[8][TP], rowk[2][TP], vdl[TP];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int j = tid & 127;
+    const int g = __builtin_amdgcn_readfirstlane(tid >> 7);      // rows 16 g .. 16 g + 15: the same for a whole wave
+    const int w = a.c1 - a.c0, rows = a.mrows - a.c0, off = a.c0 - a.cb;
+    float c[16];
+#pragma unroll
+    for (int i = 0; i < 16; i++)                                 // unconditional loads (clamped), masked below: all 16 in flight together
+        c[i] = a.A[(long)(a.c0 + min(16 * g + i, rows - 1)) * a.lda + a.c0 + min(j, w - 1)];
+#pragma unroll
+    for (int q = 0; q < TP * TP / 1024; q++) Sout[tid + 1024 * q] = 0.f;      // the window outside the leaf stays zero
+    if (tid < TP) vdl[tid] = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; i++) c[i] = (16 * g + i < rows && j < w) ? c[i] : 0.f;
+    for (int k = 0; k < w; k++) {
+        const int par = k & 1, gk = k >> 4, ik = k & 15;
+        if (g >= gk) {
+            if (j == k) {
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    float4 t;
+                    t.x = (16 * g + 4 * q + 0 >= k) ? c[4 * q + 0] : 0.f; t.y = (16 * g + 4 * q + 1 >= k) ? c[4 * q + 1] : 0.f;
+                    t.z = (16 * g + 4 * q + 2 >= k) ? c[4 * q + 2] : 0.f; t.w = (16 * g + 4 * q + 3 >= k) ? c[4 * q + 3] : 0.f;
+                    *(float4*)&ucol[16 * g + 4 * q] = t;
+                }
+            }
+            if (g == gk) {
+                float rk = c[0];
+#pragma unroll
+                for (int i = 1; i < 16; i++) rk = (ik == i) ? c[i] : rk;
+                rowk[par][j] = rk;
+            }
+        }
+        __syncthreads();
+        float u[16], p = 0.f;
+        if (g >= gk) {
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const float4 t = *(const float4*)&ucol[16 * g + 4 * q];
+                u[4 * q] = t.x; u[4 * q + 1] = t.y; u[4 * q + 2] = t.z; u[4 * q + 3] = t.w;
+            }
+#pragma unroll
+            for (int i = 0; i < 16; i++) p += u[i] * c[i];
+        }
+        part[g][j] = p;
+        __syncthreads();
+        if (g >= gk) {
+            float sj = 0.f, sk = 0.f;
+#pragma unroll
+            for (int q = 0; q < 8; q++) { sj += part[q][j]; sk += part[q][k]; }
+            const float akk = rowk[par][k], rj = rowk[par][j];
+            float alpha = 0.f, inv = 0.f;
+            if (sk != 0.f) {
+                const float nu = sqrtf(sk);
+                alpha = (akk >= 0.f) ? nu : -nu;
+                inv = 1.0f / sqrtf(2.0f * (sk + fabsf(akk) * nu));
+            }
+            if (g == gk) {                                       // u + alpha e1: row k is one of this group's
+#pragma unroll
+                for (int i = 0; i < 16; i++) u[i] += (ik == i) ? alpha : 0.f;
+            }
+            const float wj = (j > k && j < w) ? 2.0f * (sj + alpha * rj) * inv : 0.f;
+#pragma unroll
+            for (int i = 0; i < 16; i++) {
+                const float vi = u[i] * inv;                     // zero above row k (ucol is)
+                c[i] -= vi * wj;
+                if (j == k && sk != 0.f && 16 * g + i >= k) c[i] = (16 * g + i == k) ? -alpha : vi;
+                if (j == k && 16 * g + i == k) vdl[k] = vi;
+            }
+        }
+    }
+    __syncthreads();
+    // outputs: A (R on and above the diagonal, the reflectors below), fp16 V / V^T with the diagonal entries from vdl, Vs for S
+    {
+        const float vd = j < w ? vdl[j] : 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+            const int r = 16 * g + i;
+            half_t hv = (half_t)0.f;
+            if (r < rows && j < w) {
+                a.A[(long)(a.c0 + r) * a.lda + a.c0 + j] = c[i];
+                if (r >= j) {
+                    hv = (half_t)(r == j ? vd : c[i]);
+                    a.Vh[(long)(a.c0 + r) * a.ldvh + a.c0 + j] = hv;
+                    a.Vt[(long)(a.c0 + j) * a.ldvt + a.c0 + r] = hv;
+                }
+            }
+            Vs[r * TPS + j] = (float)hv;
+        }
+        if (g == 0 && j < w) a.vdiag[a.c0 + j] = vd;
+    }
+    __syncthreads();
+    // S[i][j] = sum_r V[r][i] V[r][j], upper 32 x 32 tiles (wave t: tile (t / 4, t % 4)); both operands are read along rows of Vs
+    {
+        const int ti = wave >> 2, tj = wave & 3;
+        if (tj >= ti && 32 * ti < w && 32 * tj < w) {
+            const int r = lane & 31, kk = lane >> 5;
+            floatx16p acc;
+#pragma unroll
+            for (int e = 0; e < 16; e++) acc[e] = 0.f;
+            for (int k1 = 0; k1 < rows; k1 += 16) {              // (rows beyond `rows` are zero in Vs)
+                float av[8], bv[8];
+#pragma unroll
+                for (int q = 0; q < 8; q++) { av[q] = Vs[(k1 + 2 * q + kk) * TPS + 32 * ti + r]; bv[q] = Vs[(k1 + 2 * q + kk) * TPS + 32 * tj + r]; }
+#pragma unroll
+                for (int q = 0; q < 8; q++) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q], bv[q], acc, 0, 0, 0);
+            }
+#pragma unroll
+            for (int e = 0; e < 16; e++) {
+                const int i = 32 * ti + (e & 3) + 8 * (e >> 2) + 4 * kk, jj = 32 * tj + r;
+                if (i < w && jj < w) Sout[(long)(off + i) * TP + off + jj] = acc[e];
+            }
+        }
+    }
+}
+
+void launch_leaf_tail(const LeafArgs& a, float* S, hipStream_t s) {
+    MPQR_ONCE_PER_DEVICE((void)hipFuncSetAttribute((const void*)leaf_tail_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, TP * TPS * 4));
+    hipLaunchKernelGGL(leaf_tail_kernel, dim3(1), dim3(1024), TP * TPS * 4, s, a, S);
+}
+
 void launch_leaf_factor(const LeafArgs& a, hipStream_t s) {
     if (a.c1 <= a.c0) return;
     const int rows = a.mrows - a.c0;

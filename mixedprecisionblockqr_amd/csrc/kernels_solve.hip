@@ -427,11 +427,6 @@ __global__ __launch_bounds__(S3_THREADS) void gh_solve3_kernel(LeafArgs a, const
         const double g = G[(off + min(i, w - 1)) * GW + off + min(j, w - 1)];
         return (i < w && j < w) ? g : (i == j ? 1.0 : 0.0);
     };
-    auto Bw = [&](int i, int j) -> float {
-        const float b = a.A[(long)(a.c0 + min(i, w - 1)) * a.lda + a.c0 + min(j, w - 1)];
-        return (i < w && j < w) ? b : 0.f;
-    };
-
     for (int e = tid; e < TP * TPS; e += S3_THREADS) Ws[e] = 0.f;
     if (tid < GW) { vdl[tid] = 0.f; tdiag[tid] = 1.f; sgn[tid] = 1.f; cmask[tid] = 1; }
     if (tid == 0) lflag = 0;

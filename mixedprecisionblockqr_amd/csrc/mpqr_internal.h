@@ -120,6 +120,9 @@ struct LeafArgs {
     int* hostflag;              // Gram-Householder leaves: word in mapped host memory that a flagged leaf also raises (or nullptr)
 };
 void launch_leaf_factor(const LeafArgs& a, hipStream_t s);   // robust path: one workgroup (<=2048 rows) or one launch per column
+// the last leaf of a (nearly) square matrix: at most 128 rows from row c0 down, up to 128 columns inside the 128-aligned window a.cb; one
+// workgroup; also writes S = V^T V of the fp16-rounded reflectors (128 x 128 fp32, window coordinates) for launch_t_leaf
+void launch_leaf_tail(const LeafArgs& a, float* S, hipStream_t s);
 // tall leaves (up to 128 columns inside a 128-aligned window, a.cb): Gram-Householder, 4 launches; raises *flag
 // when the leaf is too ill-conditioned for it
 // If Sp != nullptr the apply kernel also emits the Gram matrix of the fp16 reflectors (window coordinates,

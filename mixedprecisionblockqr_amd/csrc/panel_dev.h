@@ -83,24 +83,14 @@ __device__ __forceinline__ void tri_inverse_128(float* Ss, const float* tdiag, f
     // (eight blocks: two per wave, one per half of the first 32 lanes ... of waves 0-3)
     if (wave < nblk && lane < 32) {
         const int base = 32 * wave + 16 * (lane >> 4), a = lane & 15;
-        // the block's strictly upper 16 x 16 part and its diagonal into registers first (broadcast reads, all in flight together), then
-        // the recurrence without a memory operation in it: read just in time, the 120 LDS reads cost a latency each (7 - 12 k of the
-        // stage's cycles, in-kernel stamps: tools/ktrace_solve.sh)
-        float su[16][16], td[16];
-#pragma unroll
-        for (int q = 0; q < 16; q++) {
-            td[q] = tdiag[base + q];
-#pragma unroll
-            for (int i = q + 1; i < 16; i++) su[q][i] = Ss[(base + q) * TPS + base + i];
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         float tr[16];
 #pragma unroll
         for (int i = 0; i < 16; i++) {
-            const float tii = td[i];
+            const float tii = tdiag[base + i];
             float ps[4] = {0.f, 0.f, 0.f, 0.f};            // four partial sums: a quarter of the dependent chain
 #pragma unroll
-            for (int q = 0; q < i; q++) ps[q & 3] += tr[q] * su[q][i];
+            for (int q = 0; q < i; q++) ps[q & 3] += tr[q] * Ss[(base + q) * TPS + base + i];      // broadcast reads; preloading the block into registers
+                                                                                                      // measured the same in gh_solve3 and spills in t_panel
             const float sum = (ps[0] + ps[1]) + (ps[2] + ps[3]);
             tr[i] = (a < i) ? -tii * sum : (a == i ? tii : 0.f);
         }

@@ -266,6 +266,38 @@ def test_ragged_tall_leaves_match_oracle(mp, h, po, m, n, r):
     assert np.all(R[np.tril_indices(n, -1)[0], np.tril_indices(n, -1)[1]] == 0)
 
 
+@pytest.mark.parametrize("m,n,r", [(640, 640, 128), (700, 700, 64), (1100, 1100, 128), (513, 513, 128), (996, 936, 64), (1153, 1152, 128)])
+def test_tail_leaf_of_square_matrices_matches_oracle(mp, h, po, m, n, r):
+    """The last <= 128 rows of a (nearly) square matrix are one leaf_tail_kernel leaf (plain Householder in one workgroup, S = V^T V for
+    its T from the same kernel): full 128 x 128, partial widths (60, 76), a single column, more rows than columns (100 x 40), one spare
+    row.  Element-level agreement with the oracle's compact-WY block loop where forward errors stay O(u) (a square random matrix is ill
+    conditioned in its last columns: leading 3/4), everything through the reference's criteria; the last reflector of a square matrix is
+    the scalar one (v = +-1, R_nn = -a_nn)."""
+    A = po.generate(m, n, seed=2468)
+    Ao, Q, R = run_gpu(mp, h, A, r)
+    A0, Q0, R0 = po.block_qr(A, r, "compact32", omp=True)
+    assert np.isfinite(Ao).all() and np.isfinite(Q).all()
+    V = po.extract_V(Ao, m, n, 0, n); V0 = po.extract_V(A0, m, n, 0, n)
+    D, first = align_pivot_signs(V, V0, R, R0, n)
+    k = 3 * n // 4
+    Dm = np.ones(m, np.float32); Dm[:n] = D
+    assert relF((R * Dm[:, None])[:k, :k], R0[:k, :k]) <= 3e-3
+    assert relF(Q[:, :k] * D[None, :k], Q0[:, :k]) <= 5e-3
+    assert relF(V[:, :min(first, k)], V0[:, :min(first, k)]) <= 5e-3
+    # the tail's reflectors themselves: unit norm, zero above the diagonal, |R_kk| = the norm they removed
+    t0 = (m - 1) // 128 * 128                       # first column with at most 128 rows from the diagonal down
+    for c in range(min(t0, n), n):
+        v = V[:, c].astype(np.float64)
+        assert np.all(v[:c] == 0) and abs(np.linalg.norm(v) - 1.0) <= 2e-3, (c, np.linalg.norm(v))
+    if m == n:
+        assert abs(abs(V[n - 1, n - 1]) - 1.0) <= 1e-3
+    mt = po.metrics(A, R, Q)
+    for key in ("backward_error", "q_error_max_signed", "lower_trapezoid"):
+        assert po.lib().orc_error_passes(mt[key], m, 11), (key, mt)
+    assert mt["backward_error_f64"] <= 1e-3 and mt["q_error_fro"] <= 2e-3 * np.sqrt(m) + 1e-4, mt
+    assert np.all(R[np.tril_indices(n, -1)[0], np.tril_indices(n, -1)[1]] == 0)
+
+
 def test_ill_conditioned_tall_leaf_falls_back(mp, h, po):
     """A tall panel with (nearly) dependent columns must not be trusted to the Gram-Householder leaf: gh_solve flags
     THAT leaf and the driver repeats the pass with only the flagged leaves on the column-by-column kernels."""
@@ -831,6 +863,7 @@ OPT_IN = [
     {"MPQR_ASHADOW": "0"},                         # far X = A2^T V from the fp32 matrix (converted + transposed while staged: round 3 default)
     {"MPQR_EXT_LEAVES": "1"},                      # block boundary: the in-block updates reach ONE leaf of the next block (round 2)
     {"MPQR_DEFER_FAR": "0"},                       # far update enqueued at the block's end instead of behind the next block's first gh_gram
+    {"MPQR_TAIL_LEAF": "0"},                       # the last <= 128 rows as 32-column leaves + merges (before round 4's leaf_tail_kernel)
     {"MPQR_LEAF_LA": "1"},                         # leaf-level look-ahead: every leaf's update of the rest of its block on the T stream
     {"MPQR_RESTART": "0", "MPQR_WATCH_FLAGS": "0"},   # robust fallback as in round 2 (no early stop, every pass from block 0)
 ]
