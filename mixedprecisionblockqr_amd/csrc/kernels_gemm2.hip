@@ -438,7 +438,7 @@ __device__ __forceinline__ void epilogue_sub_f32_dma(ACC (&acc)[4][2], char* sme
 // l reads row l & 15, 16-byte chunk 4 ks + (l >> 4).  On random data the chip holds a higher clock on this shape
 // (MI355X_MICROARCH.md, DVFS give-back (7); tools/ubench_mfma.hip).  The operands are passed SWAPPED, so a lane holds four
 // consecutive columns of a row of C: 16-byte (fp32) / 8-byte (fp16) stores.
-template <int EM, int DMA_EPI, int MF = 0>
+template <int EM, int DMA_EPI, int MF = 0, int DR = 0>
 __global__ __launch_bounds__(512) void gemm6_f16_kernel(GemmArgs g, int tilesM, int tilesN) {
     using namespace g2;
     typedef float floatx4 __attribute__((ext_vector_type(4)));
@@ -553,12 +553,14 @@ __global__ __launch_bounds__(512) void gemm6_f16_kernel(GemmArgs g, int tilesM, 
                         // four CONSECUTIVE COLUMNS of a row-major C -> 16-byte loads and stores in the epilogue
                         acc16[MF ? subA * 4 + i4 : 0][MF ? subB * 2 + j2 : 0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(
                             b[2 * ks2 + j2], af[2 * ks2 + (i4 >> 1)][i4 & 1], acc16[MF ? subA * 4 + i4 : 0][MF ? subB * 2 + j2 : 0], 0, 0, 0);
-            issue(tau, sidx);
-            __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);
-            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);
-            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+            if (!DR) {
+                issue(tau, sidx);
+                __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);
+                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);
+                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+            }
             __builtin_amdgcn_s_setprio(0);
             return;
         }
@@ -567,12 +569,14 @@ __global__ __launch_bounds__(512) void gemm6_f16_kernel(GemmArgs g, int tilesM, 
 #pragma unroll
             for (int i2 = 0; i2 < 2; i2++)
                 acc[subA * 2 + i2][subB] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[ks][i2], b[ks], acc[subA * 2 + i2][subB], 0, 0, 0);
-        issue(tau, sidx);
-        __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
-        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-        __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
-        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+        if (!DR) {
+            issue(tau, sidx);
+            __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+        }
         __builtin_amdgcn_s_setprio(0);
     };
     // One K tile = four phases.  Phase f = 4 t + p reads (fragment half phase) and then computes (MFMA half phase):
@@ -588,7 +592,11 @@ __global__ __launch_bounds__(512) void gemm6_f16_kernel(GemmArgs g, int tilesM, 
         const char* As = g2_smem + (t & 1) * BUF;
         const char* Bs = As + A_BYTES;
         const char* Bn = g2_smem + ((t + 1) & 1) * BUF + A_BYTES;
+        // DR: the half tile is issued by the wave in its FRAGMENT half phase (e = f + 6: what the MFMA half phase of phase f - 1 issued in
+        // the other form, a quarter phase later): an LDS-DMA takes ~60 cycles to issue and the wave is in order, so between a wave's own
+        // MFMAs it opens a bubble in the matrix pipe; the reading wave has the slack.  Same number of half tiles outstanding at every wait.
         read_A(As, 0);
+        if (DR) issue(t + 1, 2);
         asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();
@@ -596,6 +604,7 @@ __global__ __launch_bounds__(512) void gemm6_f16_kernel(GemmArgs g, int tilesM, 
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();
         read_B(Bs, 1, b1);
+        if (DR) issue(t + 1, 3);
         asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();
@@ -603,6 +612,7 @@ __global__ __launch_bounds__(512) void gemm6_f16_kernel(GemmArgs g, int tilesM, 
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();
         read_A(As, 1);
+        if (DR) issue(t + 2, 0);
         asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();
@@ -610,6 +620,7 @@ __global__ __launch_bounds__(512) void gemm6_f16_kernel(GemmArgs g, int tilesM, 
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();
         read_B(Bn, 0, b0n);
+        if (DR) issue(t + 2, 1);
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();
         mma(1, 0, b0, t + 2, 2);
@@ -623,8 +634,9 @@ __global__ __launch_bounds__(512) void gemm6_f16_kernel(GemmArgs g, int tilesM, 
     if (kt_on) { kt0 = clock64(); rt0 = __builtin_amdgcn_s_memrealtime(); }
 #endif
     // prologue: half tiles 0..6 (tile 0 complete, A-S0 / B-S0 / B-S1 of tile 1); A-S0(0) and B-S0(0) landed
-    issue(0, 0); issue(0, 1); issue(0, 2); issue(0, 3); issue(1, 0); issue(1, 1); issue(1, 2);
-    asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+    issue(0, 0); issue(0, 1); issue(0, 2); issue(0, 3); issue(1, 0); issue(1, 1);
+    if (!DR) { issue(1, 2); asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); }
+    else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     read_B(g2_smem + A_BYTES, 0, b0a);
     if (wr == 1) __builtin_amdgcn_s_barrier();               // second group: half a phase behind
@@ -719,13 +731,23 @@ __global__ __launch_bounds__(512) void gemm6_f16_kernel(GemmArgs g, int tilesM, 
         }
 }
 
-template <int EM, int DMA_EPI, int MF = 0>
+template <int EM, int DMA_EPI, int MF = 0, int DR = 0>
 static void launch6(const GemmArgs& g, hipStream_t s) {
     constexpr int LDS = 2 * 2 * 256 * 128;
-    MPQR_ONCE_PER_DEVICE((void)hipFuncSetAttribute((const void*)gemm6_f16_kernel<EM, DMA_EPI, MF>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+    // Where a wave issues its LDS-DMAs (kernel comment, "DR"): in the fragment half phase for the 16x16x32 store forms (kernel alone, K = 8192
+    // store 1277 -> 1313, X = Q2^T V 1079 -> 1142 TFLOP/s), between its MFMAs for the 32x32x16 read-modify-write form (825 vs 787 the
+    // other way round; tools/bench_gemm.py, same box).  MPQR_G6_DR=0 / 1 forces one placement for every form (A/B hook).
+    if (!DR && MF) {
+        static const int dr = []() { const char* e = getenv("MPQR_G6_DR"); return e ? atoi(e) : 1; }();
+        if (dr) { launch6<EM, DMA_EPI, MF, 1>(g, s); return; }
+    } else if (!DR) {
+        static const int dr = []() { const char* e = getenv("MPQR_G6_DR"); return e ? atoi(e) : 0; }();
+        if (dr) { launch6<EM, DMA_EPI, MF, 1>(g, s); return; }
+    }
+    MPQR_ONCE_PER_DEVICE((void)hipFuncSetAttribute((const void*)gemm6_f16_kernel<EM, DMA_EPI, MF, DR>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
     const int tilesM = (g.M + 255) / 256, tilesN = (g.N + 255) / 256;
     const int groups = ((tilesM + 3) / 4) * ((tilesN + 7) / 8);
-    hipLaunchKernelGGL((gemm6_f16_kernel<EM, DMA_EPI, MF>), dim3(groups * 32), dim3(512), LDS, s, g, tilesM, tilesN);
+    hipLaunchKernelGGL((gemm6_f16_kernel<EM, DMA_EPI, MF, DR>), dim3(groups * 32), dim3(512), LDS, s, g, tilesM, tilesN);
 }
 
 // Large-shape path.  Preconditions (checked by the caller, driver.hip): no split-K, K % 64 == 0, and the

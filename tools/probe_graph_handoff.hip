@@ -55,7 +55,26 @@ int main() {
         }
     };
     auto four_serial = [&]() { for (int i = 0; i < 4 * N; i++) hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(64), 0, s0, d, cyc); };
+    // what does an event RECORD cost the recording stream?  (a) nobody waits for it; (b) a second stream waits and runs its own kernel
+    auto record_only = [&]() {
+        for (int i = 0; i < N; i++) {
+            hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(64), 0, s0, d, cyc);
+            (void)hipEventRecord(ea[i], s0);
+            hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(64), 0, s0, d, cyc);
+        }
+    };
+    auto record_and_side_waiter = [&]() {
+        for (int i = 0; i < N; i++) {
+            hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(64), 0, s0, d, cyc);
+            (void)hipEventRecord(ea[i], s0); (void)hipStreamWaitEvent(s1, ea[i], 0);
+            hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(64), 0, s1, d + 1, cyc / 2);          // side work nobody on s0 waits for
+            hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(64), 0, s0, d, cyc);
+        }
+    };
     const float e1 = timed("eager, one stream", one_stream);
+    const float r1 = timed("eager, one stream + record per pair", record_only);
+    const float r2 = timed("eager, record + side stream waits", record_and_side_waiter);
+    printf("event record on the chain stream: %.2f us (nobody waits), %.2f us (a side stream waits for it)\n", (r1 - e1) * 1e3f / N, (r2 - e1) * 1e3f / N);
     const float e2 = timed("eager, two streams + 2 hand-offs", two_streams);
     // the same two patterns captured into graphs (origin stream s0; s1 joins through the event waits and joins back at the end)
     hipGraph_t g1, g2; hipGraphExec_t x1, x2;

@@ -5,7 +5,8 @@
 // Three loops, every CU busy, 512-thread workgroups (two waves per SIMD), random fp16 operands:
 //   reg32   v_mfma_f32_32x32x16_f16, operands in registers (the ceiling of gemm6's MFMA shape)
 //   reg16   v_mfma_f32_16x16x32_f16, operands in registers
-//   lds32 / lds16: the same with every operand fragment re-read from LDS (ds_read_b128) as a 128 x 64 wave tile does per K step of 64 / 32
+//   lds32 / lds16: the same with every operand fragment re-read from LDS (ds_read_b128, issued one iteration ahead of its MFMAs, one
+//           s_waitcnt lgkmcnt(0) per iteration) as a 128 x 64 wave tile does per K step of 16 / 32: the ceiling of ANY kernel with this wave tile
 // Prints TFLOP/s and the in-kernel clock (s_memtime / s_memrealtime).  Development tool; build: hipcc --offload-arch=gfx950 -O3.
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -15,6 +16,13 @@
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 typedef float floatx4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ unsigned lds_addr(const void* p) { return (unsigned)(size_t)(const __attribute__((address_space(3))) void*)p; }
+template <int OFF> __device__ __forceinline__ half8 ds_read16(unsigned a) {
+    half8 v;
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(a), "n"(OFF));
+    return v;
+}
 
 constexpr int ITERS = 4096;
 
@@ -34,17 +42,24 @@ __global__ __launch_bounds__(512) void k32(const _Float16* __restrict__ src, flo
     floatx16 acc[4][2];
     for (int i = 0; i < 4; i++) for (int j = 0; j < 2; j++) for (int e = 0; e < 16; e++) acc[i][j][e] = 0.f;
     const long t0 = __builtin_amdgcn_s_memtime(); const long r0 = __builtin_amdgcn_s_memrealtime();
+    const unsigned base = lds_addr(&sm[wave][0][lane][0]);
     for (int it = 0; it < ITERS; it++) {
-        if (LDS) {
-#pragma unroll
-            for (int i = 0; i < 4; i++) a[i] = *(volatile half8*)&sm[wave][i][lane][0];
-#pragma unroll
-            for (int j = 0; j < 2; j++) b[j] = *(volatile half8*)&sm[wave][4 + j][lane][0];
+        half8 an[4], bn[2];
+        if (LDS) {                                                          // next iteration's fragments: in flight behind this one's MFMAs
+            an[0] = ds_read16<0 * 1024>(base); an[1] = ds_read16<1 * 1024>(base); an[2] = ds_read16<2 * 1024>(base); an[3] = ds_read16<3 * 1024>(base);
+            bn[0] = ds_read16<4 * 1024>(base); bn[1] = ds_read16<5 * 1024>(base);
         }
 #pragma unroll
         for (int i = 0; i < 4; i++)
 #pragma unroll
             for (int j = 0; j < 2; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i], b[j], acc[i][j], 0, 0, 0);
+        if (LDS) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int i = 0; i < 4; i++) a[i] = an[i];
+#pragma unroll
+            for (int j = 0; j < 2; j++) b[j] = bn[j];
+        }
     }
     const long t1 = __builtin_amdgcn_s_memtime(); const long r1 = __builtin_amdgcn_s_memrealtime();
     float s = 0.f;
@@ -69,17 +84,25 @@ __global__ __launch_bounds__(512) void k16(const _Float16* __restrict__ src, flo
     floatx4 acc[8][4];
     for (int i = 0; i < 8; i++) for (int j = 0; j < 4; j++) for (int e = 0; e < 4; e++) acc[i][j][e] = 0.f;
     const long t0 = __builtin_amdgcn_s_memtime(); const long r0 = __builtin_amdgcn_s_memrealtime();
+    const unsigned base = lds_addr(&sm[wave][0][lane][0]);
     for (int it = 0; it < ITERS / 2; it++) {                               // one round = K 32 = two rounds of the 32x32x16 loop
+        half8 an[8], bn[4];
         if (LDS) {
-#pragma unroll
-            for (int i = 0; i < 8; i++) a[i] = *(volatile half8*)&sm[wave][i][lane][0];
-#pragma unroll
-            for (int j = 0; j < 4; j++) b[j] = *(volatile half8*)&sm[wave][8 + j][lane][0];
+            an[0] = ds_read16<0 * 1024>(base); an[1] = ds_read16<1 * 1024>(base); an[2] = ds_read16<2 * 1024>(base); an[3] = ds_read16<3 * 1024>(base);
+            an[4] = ds_read16<4 * 1024>(base); an[5] = ds_read16<5 * 1024>(base); an[6] = ds_read16<6 * 1024>(base); an[7] = ds_read16<7 * 1024>(base);
+            bn[0] = ds_read16<8 * 1024>(base); bn[1] = ds_read16<9 * 1024>(base); bn[2] = ds_read16<10 * 1024>(base); bn[3] = ds_read16<11 * 1024>(base);
         }
 #pragma unroll
         for (int i = 0; i < 8; i++)
 #pragma unroll
             for (int j = 0; j < 4; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[i], b[j], acc[i][j], 0, 0, 0);
+        if (LDS) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int i = 0; i < 8; i++) a[i] = an[i];
+#pragma unroll
+            for (int j = 0; j < 4; j++) b[j] = bn[j];
+        }
     }
     const long t1 = __builtin_amdgcn_s_memtime(); const long r1 = __builtin_amdgcn_s_memrealtime();
     float s = 0.f;
