@@ -108,6 +108,10 @@ struct mpqr_handle_s {
     std::vector<hipEvent_t> ev_node, ev_cols;          // per top-level node: reflectors ready / columns up to date
     float* S = nullptr;    size_t s_elems = 0;
     float* Sleaf = nullptr;       // 128 x 128 Gram of a leaf's fp16 reflectors (chain stream; S itself is used by the T stream)
+    int* mid_counter = nullptr;   // arrival counter of leaf_mid_kernel's reduce workgroups (zero between launches)
+    struct MidT { const float* Sp; int nslab; int sh, a0, c0, c1; float* T; half_t* Th; half_t* Tth; int ldt, ld; };
+    const MidT* mid = nullptr;    // set by the flat schedule around one apply_node call: its X GEMM and the leaf's T go out as ONE launch
+    bool leaf_mid = true;         // MPQR_LEAF_MID=0: X on the side stream, Gram sum and T as two launches on the chain (before round 4)
     float* P = nullptr;    int maxwg = 0;
     double* Gp = nullptr; double* Gs = nullptr; float* Cv = nullptr; int* dflag = nullptr;   // Gram-Householder leaf workspace
     float* Sp = nullptr;          // per-workgroup partial Grams of the fp16 reflectors (fused into gh_apply)
@@ -228,7 +232,7 @@ int dalloc(mpqr_handle_t h, T** p, size_t elems) {
 void free_plan(mpqr_handle_t h) {
     void* ptrs[] = {h->dA, h->dA0, h->dQ, h->Vh, h->Vt, h->vdiag, h->Xt, h->Yt, h->S, h->P, h->tmp1, h->tmp2,
                     h->Tf, h->Th, h->Tth, h->dstage, h->Gp, h->Gs, h->Cv, h->dflag, h->Vf, h->Yf, h->Xt1, h->Yt1, h->Sp,
-                    h->rbTf, h->rbTh, h->rbTth, h->Sleaf, h->V8n, h->V8t, h->A8t, h->Y8, h->Xt2, h->Yt2,
+                    h->rbTf, h->rbTh, h->rbTth, h->Sleaf, h->mid_counter, h->V8n, h->V8t, h->A8t, h->Y8, h->Xt2, h->Yt2,
                     h->S2, h->tmp1b, h->tmp2b, h->Qt, h->At, h->Xh, h->Wh, h->Xl, h->Xh1, h->Xl1};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (h->hflag_host) (void)hipHostFree(h->hflag_host);
@@ -239,7 +243,7 @@ void free_plan(mpqr_handle_t h) {
     h->dstage = nullptr; h->stage_elems = 0;
     h->Gp = nullptr; h->Gs = nullptr; h->Cv = nullptr; h->dflag = nullptr; h->Vf = nullptr; h->Yf = nullptr;
     h->Xt1 = nullptr; h->Yt1 = nullptr; h->Sp = nullptr; h->Xt2 = nullptr; h->Yt2 = nullptr; h->xt2_elems = 0;
-    h->rbTf = nullptr; h->rbTh = h->rbTth = nullptr; h->rb_elems = 0; h->nflag = 0; h->leaf_robust.clear(); h->Sleaf = nullptr;
+    h->rbTf = nullptr; h->rbTh = h->rbTth = nullptr; h->rb_elems = 0; h->nflag = 0; h->leaf_robust.clear(); h->Sleaf = nullptr; h->mid_counter = nullptr;
     h->V8n = h->V8t = h->A8t = h->Y8 = nullptr; h->v8_node = -1;
     for (hipEvent_t e : h->chain_ev) (void)hipEventDestroy(e);
     h->chain_ev.clear(); h->chain_used = 0; h->far_used = 0;
@@ -486,6 +490,13 @@ void apply_node(mpqr_handle_t h, const Node& nd, float* C, long ldc, int clo, in
     } else if (x16) {
         g1.C = Xhi; g1.C2 = Xlo;
         gemm_dispatch(A_F32T, E_STORE_H16, g1, st1);
+    } else if (h->mid && lane == 0 && fuse_xt && st1 == st) {
+        // flat schedule: X beside the leaf's Gram sum and T, one launch (kernels_panel.hip: leaf_mid_kernel); one workgroup per CU there
+        const int gx = (M1 + 127) / 128;
+        while (g1.nsplit > 1 && gx * g1.nsplit > 176) g1.nsplit--;
+        const mpqr_handle_s::MidT& mt = *h->mid;
+        launch_leaf_mid(g1, mt.Sp, mt.nslab, h->Sleaf, mt.sh, h->mid_counter, mt.a0, mt.c0, mt.c1, mt.T, mt.Th, mt.Tth, mt.ldt, mt.ld, st);
+        h->mid = nullptr;                                   // consumed
     } else
     gemm_dispatch(A_F32T, E_STORE_F32, g1, st1);
     if (g1.nsplit > 1 && !fuse_xt) launch_slab_reduce(Xt, g1.nsplit, slab, slab, Xt, st1);
@@ -752,6 +763,9 @@ int factor_block_flat(mpqr_handle_t h, int top, const std::vector<int>& leaves) 
         lf.tld = ld;
         const bool tail = is_tail(h, lf.c0);
         const bool robust_leaf = !tail && (h->robust || (id < (int)h->leaf_robust.size() && h->leaf_robust[id]));
+        bool mid_leaf = false, gh_leaf = false, far_wait_pending = false;
+        int gh_partials = 0, gh_sh = 0;
+        mpqr_handle_s::MidT mid_desc{};
         if (tail) {
             // the matrix's last <= 128 rows: plain Householder in one workgroup, S for its T from the same kernel
             Range rg("mpqr:panel");
@@ -796,17 +810,8 @@ int factor_block_flat(mpqr_handle_t h, int top, const std::vector<int>& leaves) 
                 HIPQ(h, hipStreamWaitEvent(h->s0, h->wait_after_first_leaf, 0));
                 h->wait_after_first_leaf = nullptr;
             }
-            Range rt("mpqr:wy_T");
-            // ONE chain -> side-stream hand-off per leaf (each event operation costs the chain stream ~7 us): it publishes
-            // the leaf's reflectors (for the apply's first GEMM and for this leaf's column block of T) and, being later in
-            // the chain stream than the previous leaf's T, that T as well (for the previous leaf's column block).
-            if (tq) t_stream_follows_chain(h);
-            // T_j (Gram reduction + triangular inverse, ~46 us) is the longer of the two things the apply's second GEMM
-            // needs, so it stays on the chain stream and the apply's X = C2^T V (+ slab sum, ~35 us) goes to the side stream
-            launch_gh_reduce_f32(h->Sp, gh_num_partials(a), h->Sleaf, h->s0);
-            const int sh = lf.a0 - a.cb;
-            launch_t_leaf(h->Sleaf + (long)sh * 128 + sh, 1, 0, 128, lf.a0, lf.c0, lf.c1, h->Tf + lf.toff, h->Th + lf.toff,
-                          h->Tth + lf.toff, lf.ldt, h->s0, ld);
+            gh_leaf = true; gh_partials = gh_num_partials(a); gh_sh = lf.a0 - a.cb;
+            far_wait_pending = h->wait_after_first_leaf != nullptr;
         }
         // the chain: this leaf alone onto the rest of the block -- and, under look-ahead, onto the next block's first
         // leaves as well (ext_c1): those leaves then need nothing from this block's far update and the chain crosses the block
@@ -840,12 +845,36 @@ int factor_block_flat(mpqr_handle_t h, int top, const std::vector<int>& leaves) 
         }
         const int own_end = la_split ? std::min(next_c1, upd_end) : (pre_split ? cpre : upd_end);
         const bool have_rest = (la_split || pre_split) && own_end < upd_end;
+        if (gh_leaf) {
+            // T_j = (Gram of the fp16 reflectors: gh_apply's partials, summed)^-1.  Round 4: when this leaf has an in-block update of the plain
+            // kind, its X = C2^T V, the Gram sum and T_j go out as ONE launch on the chain stream (leaf_mid_kernel, from apply_node below): no
+            // side stream for X, no hand-offs around it; the T stream then follows the chain AFTER the update (it only builds the previous
+            // leaf's column block of T).  Not for a leaf whose X still waits for the previous block's far update: there the chain goes on
+            // with T_j while the side stream waits.
+            mid_leaf = h->leaf_mid && tq && !la_split && !far_wait_pending && lf.ldt == 128 && lf.c1 < own_end &&
+                       own_end - rdown(lf.c1, 32) <= 4096 && !h->shadow && !h->Vf && h->opts.precision != MPQR_PREC_FP32;
+            if (mid_leaf) {
+                mid_desc = mpqr_handle_s::MidT{h->Sp, gh_partials, gh_sh, lf.a0, lf.c0, lf.c1, h->Tf + lf.toff, h->Th + lf.toff, h->Tth + lf.toff, lf.ldt, ld};
+            } else {
+                Range rt("mpqr:wy_T");
+                // ONE chain -> side-stream hand-off per leaf: it publishes the leaf's reflectors (for the apply's first GEMM and for this
+                // leaf's column block of T) and, being later in the chain stream than the previous leaf's T, that T as well
+                if (tq) t_stream_follows_chain(h);
+                // T_j (Gram reduction + triangular inverse, ~22 us) stays on the chain stream, the apply's X = C2^T V goes to the side stream
+                launch_gh_reduce_f32(h->Sp, gh_partials, h->Sleaf, h->s0);
+                launch_t_leaf(h->Sleaf + (long)gh_sh * 128 + gh_sh, 1, 0, 128, lf.a0, lf.c0, lf.c1, h->Tf + lf.toff, h->Th + lf.toff,
+                              h->Tth + lf.toff, lf.ldt, h->s0, ld);
+            }
+        }
         if (have_rest && la_split) HIPQ(h, hipEventRecord(h->ev_def, h->s0));   // T_j and V_j are complete here: the rest may start beside the urgent part
         if (lf.c1 < own_end) {
             Range rg("mpqr:in_block_update");
-            h->op1_stream = tq ? h->sT : nullptr;
+            h->op1_stream = (tq && !mid_leaf) ? h->sT : nullptr;
+            h->mid = mid_leaf ? &mid_desc : nullptr;
             apply_node(h, lf, h->Aeff, h->lda, lf.c1, own_end, true, h->a_scale, false);
             h->op1_stream = nullptr;
+            if (h->mid) { h->mid = nullptr; h->dispatch_error = true; }      // (apply_node took another path than predicted: T_j was never built)
+            if (mid_leaf && tq) t_stream_follows_chain(h);
         }
         if (have_rest) {                                   // the rest, on the T stream
             Range rg("mpqr:in_block_update_deferred");
@@ -1202,6 +1231,7 @@ static int plan_common(mpqr_handle_t h, int m, int n, int r, const mpqr_opts* op
     }
     if (const char* e = getenv("MPQR_GH_MIN_ROWS")) h->gh_min_rows = atoi(e);      // tuning hook
     if (const char* e = getenv("MPQR_TAIL_LEAF")) h->tail_leaf = atoi(e) != 0;       // A/B hook
+    if (const char* e = getenv("MPQR_LEAF_MID")) h->leaf_mid = atoi(e) != 0;         // A/B hook
     h->m_pad = rup(m, 256); h->n_pad = rup(n, 256);
     int Ko = o.outer_block > 0 ? o.outer_block : 1024;
     Ko = std::max(Ko, 32);
@@ -1337,6 +1367,8 @@ static int plan_common(mpqr_handle_t h, int m, int n, int r, const mpqr_opts* op
     }
     if ((rc = dalloc(h, &h->S, h->s_elems))) return rc;
     if ((rc = dalloc(h, &h->Sleaf, (size_t)128 * 128))) return rc;
+    if ((rc = dalloc(h, &h->mid_counter, (size_t)1))) return rc;
+    HIPCHK(h, hipMemsetAsync(h->mid_counter, 0, sizeof(int), h->s0));
     if ((rc = dalloc(h, &h->P, (size_t)2 * h->maxwg * 32))) return rc;
     if ((rc = dalloc(h, &h->Gp, (size_t)(h->m_pad / 128 + 2) * 16384))) return rc;
     if ((rc = dalloc(h, &h->Gs, (size_t)16384))) return rc;

@@ -12,191 +12,16 @@
 // Tile 128 x 128 x 64, 256 threads = 4 waves as 2 x 2, each wave 64 x 64 = 2 x 2 MFMA tiles.
 #include "mpqr_internal.h"
 #include "gemm_epilogue.h"
+#include "gemm_body.h"
 
 namespace mpqr {
 
-typedef half_t half8 __attribute__((ext_vector_type(8)));
-typedef half_t half4 __attribute__((ext_vector_type(4)));
-typedef float floatx16 __attribute__((ext_vector_type(16)));
-
-constexpr int BM = 128, BN = 128, BK = 64;
-constexpr int LDSP = BK + 8;   // padded LDS row (halves): 144-B stride is conflict-free for ds_read_b128
-
-typedef uint32_t U4 __attribute__((ext_vector_type(4)));   // a first-class vector: staging arrays of it stay in registers
-
-__device__ __forceinline__ uint32_t pack2(float a, float b) {
-    typedef half_t half2v __attribute__((ext_vector_type(2)));
-    half2v h = {(half_t)a, (half_t)b};
-    return __builtin_bit_cast(uint32_t, h);
-}
+using namespace gemm128;
 
 template <int AM, int EM>
 __global__ __launch_bounds__(256) void gemm_f16_kernel(GemmArgs g) {
     __shared__ __attribute__((aligned(16))) half_t lds[(BM + BN) * LDSP];
-    half_t* As = lds;
-    half_t* Bs = lds + BM * LDSP;
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
-    const int r = lane & 31, h = lane >> 5;
-    const int bm = blockIdx.x * BM, bn = blockIdx.y * BN;
-    const int z = blockIdx.z;
-
-    const int ktiles = g.K / BK;
-    const int per = (ktiles + g.nsplit - 1) / g.nsplit;
-    const int kt0 = z * per;
-    const int kt1 = min(ktiles, kt0 + per);
-
-    // ---- staging registers
-    U4 ra16[4];        // A_H16 / A_F32 (after conversion)
-    float4 raT[8];     // A_F32T
-    U4 rb[4];
-
-    auto load_tile = [&](int kt) {
-        const int k = kt * BK;
-        if (AM == A_H16) {
-            const half_t* A = (const half_t*)g.A;
-#pragma unroll
-            for (int i = 0; i < 4; i++) {
-                int c = tid + 256 * i, row = c >> 3, kc = (c & 7) * 8;
-                int gm = bm + row;
-                U4 v = {0, 0, 0, 0};
-                if (gm < g.M) v = *(const U4*)(A + (long)gm * g.lda + k + kc);
-                ra16[i] = v;
-            }
-        } else if (AM == A_F32T) {
-            const float* A = (const float*)g.A;
-#pragma unroll
-            for (int i = 0; i < 2; i++) {
-                int id = tid + 256 * i, mg = id & 31, kg = id >> 5;
-                int gm = bm + mg * 4;
-#pragma unroll
-                for (int j = 0; j < 4; j++) {
-                    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if (gm < g.M) v = *(const float4*)(A + (long)(k + kg * 4 + j) * g.lda + gm);
-                    raT[i * 4 + j] = v;
-                }
-            }
-        } else {  // A_F32 with slab sum
-            const float* A = (const float*)g.A;
-#pragma unroll
-            for (int i = 0; i < 4; i++) {
-                int c = tid + 256 * i, row = c >> 3, kc = (c & 7) * 8;
-                int gm = bm + row;
-                float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0;
-                if (gm < g.M) {
-                    const float* p = A + (long)gm * g.lda + k + kc;
-                    for (int sl = 0; sl < g.nslab_in; sl++) {
-                        float4 a0 = *(const float4*)(p + (long)sl * g.slab_in_stride);
-                        float4 a1 = *(const float4*)(p + (long)sl * g.slab_in_stride + 4);
-                        s0.x += a0.x; s0.y += a0.y; s0.z += a0.z; s0.w += a0.w;
-                        s1.x += a1.x; s1.y += a1.y; s1.z += a1.z; s1.w += a1.w;
-                    }
-                }
-                const float sc = g.in_scale;
-                U4 v;
-                v.x = pack2(s0.x * sc, s0.y * sc); v.y = pack2(s0.z * sc, s0.w * sc);
-                v.z = pack2(s1.x * sc, s1.y * sc); v.w = pack2(s1.z * sc, s1.w * sc);
-                ra16[i] = v;
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < 4; i++) {
-            int c = tid + 256 * i, row = c >> 3, kc = (c & 7) * 8;
-            int gn = bn + row;
-            U4 v = {0, 0, 0, 0};
-            if (gn < g.N) v = *(const U4*)(g.Bt + (long)gn * g.ldb + k + kc);
-            rb[i] = v;
-        }
-    };
-
-    auto store_tile = [&]() {
-        if (AM == A_F32T) {
-            const float sc = g.in_scale;
-#pragma unroll
-            for (int i = 0; i < 2; i++) {
-                int id = tid + 256 * i, mg = id & 31, kg = id >> 5;
-                const float4 v0 = raT[i * 4 + 0], v1 = raT[i * 4 + 1], v2 = raT[i * 4 + 2], v3 = raT[i * 4 + 3];
-                uint2 w;
-                half_t* base = As + (mg * 4) * LDSP + kg * 4;
-                w.x = pack2(v0.x * sc, v1.x * sc); w.y = pack2(v2.x * sc, v3.x * sc); *(uint2*)(base) = w;
-                w.x = pack2(v0.y * sc, v1.y * sc); w.y = pack2(v2.y * sc, v3.y * sc); *(uint2*)(base + LDSP) = w;
-                w.x = pack2(v0.z * sc, v1.z * sc); w.y = pack2(v2.z * sc, v3.z * sc); *(uint2*)(base + 2 * LDSP) = w;
-                w.x = pack2(v0.w * sc, v1.w * sc); w.y = pack2(v2.w * sc, v3.w * sc); *(uint2*)(base + 3 * LDSP) = w;
-            }
-        } else {
-#pragma unroll
-            for (int i = 0; i < 4; i++) {
-                int c = tid + 256 * i, row = c >> 3, kc = (c & 7) * 8;
-                *(U4*)(As + row * LDSP + kc) = ra16[i];
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < 4; i++) {
-            int c = tid + 256 * i, row = c >> 3, kc = (c & 7) * 8;
-            *(U4*)(Bs + row * LDSP + kc) = rb[i];
-        }
-    };
-
-    floatx16 acc[2][2];
-#pragma unroll
-    for (int i = 0; i < 2; i++)
-#pragma unroll
-        for (int j = 0; j < 2; j++)
-#pragma unroll
-            for (int e = 0; e < 16; e++) acc[i][j][e] = 0.f;
-
-    const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
-
-    if (kt0 < kt1) {
-        load_tile(kt0);
-        store_tile();
-        __syncthreads();
-        for (int kt = kt0; kt < kt1; kt++) {
-            const bool more = (kt + 1 < kt1);
-            if (more) load_tile(kt + 1);
-#pragma unroll
-            for (int ks = 0; ks < BK / 16; ks++) {
-                half8 a[2], b[2];
-#pragma unroll
-                for (int i = 0; i < 2; i++) a[i] = *(const half8*)(As + (wm + i * 32 + r) * LDSP + ks * 16 + h * 8);
-#pragma unroll
-                for (int j = 0; j < 2; j++) b[j] = *(const half8*)(Bs + (wn + j * 32 + r) * LDSP + ks * 16 + h * 8);
-#pragma unroll
-                for (int i = 0; i < 2; i++)
-#pragma unroll
-                    for (int j = 0; j < 2; j++)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i], b[j], acc[i][j], 0, 0, 0);
-            }
-            __syncthreads();
-            if (more) {
-                store_tile();
-                __syncthreads();
-            }
-        }
-    }
-
-    // ---- epilogue.  D layout of 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
-    const float alpha = g.alpha;
-    if (EM == E_SUB_F32) {
-        epilogue_sub_f32<2, 2>(acc, (float*)g.C, g.ldc, g.M, g.N, g.col_lo, alpha, bm + wm, bn + wn, r, h, g.Ct, g.ldct, g.ct_scale);
-        return;
-    }
-#pragma unroll
-    for (int i = 0; i < 2; i++)
-#pragma unroll
-        for (int j = 0; j < 2; j++) {
-            const int n = bn + wn + j * 32 + r;
-#pragma unroll
-            for (int e = 0; e < 16; e++) {
-                const int m = bm + wm + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-                if (m < g.M && n < g.N) {
-                    const float v = alpha * acc[i][j][e];
-                    if (EM == E_STORE_F32) ((float*)g.C)[(long)z * g.slab_out_stride + (long)m * g.ldc + n] = v;
-                    else ((half_t*)g.C)[(long)m * g.ldc + n] = (half_t)(g.cscale ? v * g.cscale[(long)n * g.cscale_ld] : v);
-                }
-            }
-        }
+    gemm_f16_body<AM, EM>(g, lds, blockIdx.x, blockIdx.y, blockIdx.z);
 }
 
 template <int AM, int EM>

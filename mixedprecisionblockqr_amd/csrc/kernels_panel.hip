@@ -16,6 +16,7 @@
 // -> per-workgroup partial in HBM, summed by every workgroup of the next launch.
 #include "mpqr_internal.h"
 #include "panel_dev.h"
+#include "gemm_body.h"
 
 namespace mpqr {
 
@@ -836,37 +837,42 @@ void launch_leaf_xt(const float* X, int nslab, long slab_stride, int M1, const h
 // (T_ii = 2/S_ii, T[:i,i] = -T_ii T[:i,:i] S[:i,i]; row a depends on row a only, so lane a runs it in registers),
 // then two levels of  T_LR = -T_L (S_LR T_R) on the exact-f32 MFMA.  Indices >= w are padded with T = I, which decouples.
 // Replaces the reference's dev_wy_transform loop (Cuda/qr.cu:535-600: r rounds of three kernels, dense (m-l)^2).
-__global__ __launch_bounds__(1024) void t_panel_kernel(const float* __restrict__ S, int nslab, long slab_stride, int lds_,
-                                                       int a0, int c0, int c1, float* __restrict__ T,
-                                                       half_t* __restrict__ Th, half_t* __restrict__ Tth, int ldt, int ld) {
-    float* Ss = (float*)gh_smem;             // [TP][TPS]
+// NT threads (>= 256: tri_inverse_128 needs four waves).  SC1: S was written by OTHER workgroups of the same launch (leaf_mid_kernel): every
+// load of it is an agent-scope relaxed atomic load (global_load_dword sc1: served past this CU's L1 and this XCD's L2 hit path as the
+// hand-off table of MI355X_MICROARCH.md requires when the producer stored sc1).
+template <int NT, bool SC1>
+__device__ __forceinline__ void t_panel_body(const float* __restrict__ S, int nslab, long slab_stride, int lds_, int a0, int c0, int c1,
+                                             float* __restrict__ T, half_t* __restrict__ Th, half_t* __restrict__ Tth, int ldt, int ld,
+                                             float* Ss, float* tdiag) {
     float* Ts = Ss + TP * TPS;               // [TP][TPS]
-    __shared__ float tdiag[TP];
     const int tid = threadIdx.x;
     const int w = c1 - c0, off = c0 - a0;
     const int nblk = (w + 31) / 32;          // active 32-blocks
     KT_DECL; KT();
-    // the 16 loads of a thread first (unconditional: clamped addresses, masked afterwards), THEN the LDS stores: with the loads inside the
+    // the loads of a thread first (unconditional: clamped addresses, masked afterwards), THEN the LDS stores: with the loads inside the
     // branches the compiler kept load -> use in program order and the kernel's load phase took 16.8 k cycles for 64 KB (one miss
     // latency per load: S was just written by gh_reduce_f32 on other CUs) -- in-kernel stamps, tools/ktrace_solve.sh
-    float sv[TP * TP / 1024];
+    constexpr int NQ = TP * TP / NT;
+    float sv[NQ];
 #pragma unroll
-    for (int q = 0; q < TP * TP / 1024; q++) {
-        const int e = tid + 1024 * q;
+    for (int q = 0; q < NQ; q++) {
+        const int e = tid + NT * q;
         const int i = min(e >> 7, w - 1), j = min(e & 127, w - 1);
-        sv[q] = S[(long)(off + i) * lds_ + off + j];
+        const float* p = &S[(long)(off + i) * lds_ + off + j];
+        if (SC1) sv[q] = __builtin_bit_cast(float, __hip_atomic_load((const unsigned*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        else sv[q] = *p;
     }
     if (nslab > 1) {
 #pragma unroll
-        for (int q = 0; q < TP * TP / 1024; q++) {
-            const int e = tid + 1024 * q;
+        for (int q = 0; q < NQ; q++) {
+            const int e = tid + NT * q;
             const int i = min(e >> 7, w - 1), j = min(e & 127, w - 1);
             for (int sl = 1; sl < nslab; sl++) sv[q] += S[(long)sl * slab_stride + (long)(off + i) * lds_ + off + j];
         }
     }
 #pragma unroll
-    for (int q = 0; q < TP * TP / 1024; q++) {
-        const int e = tid + 1024 * q;
+    for (int q = 0; q < NQ; q++) {
+        const int e = tid + NT * q;
         const int i = e >> 7, j = e & 127;
         float v = (i < w && j < w && j >= i) ? sv[q] : 0.f;
         if (i == j) { tdiag[i] = (i < w) ? (v > 0.f ? 2.0f / v : 0.f) : 1.f; v = 0.f; }
@@ -883,8 +889,8 @@ __global__ __launch_bounds__(1024) void t_panel_kernel(const float* __restrict__
         // the usual case (a full 128-column leaf): four consecutive entries per thread, 16- and 8-byte stores
         typedef half_t half4t __attribute__((ext_vector_type(4)));
 #pragma unroll
-        for (int q = 0; q < TP * TP / 4 / 1024; q++) {
-            const int e4 = tid + 1024 * q, i = e4 >> 5, j = (e4 & 31) * 4;
+        for (int q = 0; q < TP * TP / 4 / NT; q++) {
+            const int e4 = tid + NT * q, i = e4 >> 5, j = (e4 & 31) * 4;
             float4 v; half4t hv, ht;
             float t[4], u[4];
             const float tii = i < w ? Ts[i * TPS + i] : 0.f;
@@ -901,7 +907,7 @@ __global__ __launch_bounds__(1024) void t_panel_kernel(const float* __restrict__
             *(half4t*)&Tth[(long)i * ld + j] = ht;
         }
     } else {
-    for (int e = tid; e < ldt * ldt; e += 1024) {
+    for (int e = tid; e < ldt * ldt; e += NT) {
         const int i = e / ldt, j = e % ldt;
         const int li = i - off, lj = j - off;
         float v = 0.f;
@@ -910,7 +916,7 @@ __global__ __launch_bounds__(1024) void t_panel_kernel(const float* __restrict__
         const float tii = (li >= 0 && li < w) ? Ts[li * TPS + li] : 0.f;
         Th[(long)i * ld + j] = (half_t)(tii != 0.f ? v / tii : 0.f);       // fp16 copies carry T[n][k] / tau_n (unit diagonal)
     }
-    for (int e = tid; e < ldt * ldt; e += 1024) {          // T^T: consecutive lanes walk a column of T (odd LDS stride)
+    for (int e = tid; e < ldt * ldt; e += NT) {          // T^T: consecutive lanes walk a column of T (odd LDS stride)
         const int j = e / ldt, i = e % ldt;
         const int li = i - off, lj = j - off;
         float v = 0.f;
@@ -920,6 +926,12 @@ __global__ __launch_bounds__(1024) void t_panel_kernel(const float* __restrict__
     }
     }
     KT(); KT_DUMP(1, "t_panel load|inverse|store");
+}
+__global__ __launch_bounds__(1024) void t_panel_kernel(const float* __restrict__ S, int nslab, long slab_stride, int lds_,
+                                                       int a0, int c0, int c1, float* __restrict__ T,
+                                                       half_t* __restrict__ Th, half_t* __restrict__ Tth, int ldt, int ld) {
+    __shared__ float tdiag[TP];
+    t_panel_body<1024, false>(S, nslab, slab_stride, lds_, a0, c0, c1, T, Th, Tth, ldt, ld, (float*)gh_smem, tdiag);
 }
 
 // T_LR = -T_L (S T_R) for two children of at most 128 reflectors each, one workgroup, products on the exact-f32 MFMA
@@ -1015,6 +1027,91 @@ void launch_t_leaf(const float* S, int nslab, long slab_stride, int lds_, int a0
     MPQR_ONCE_PER_DEVICE((void)hipFuncSetAttribute((const void*)t_panel_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * TP * TPS * 4));
     hipLaunchKernelGGL(t_panel_kernel, dim3(1), dim3(1024), 2 * TP * TPS * 4, s, S, nslab, slab_stride, lds_, a0, c0, c1, T, Th,
                        Tth, ldt, ld);
+}
+
+// ------------------------------------------------------------------ the middle of a Gram-Householder leaf in ONE launch
+// Between gh_apply and leaf_xt a leaf needs two independent things: X = C2^T V_j (a split-K GEMM over all rows, ~16 us) and T_j (sum of
+// gh_apply's partial Gram matrices, ~6 us, then the triangular inverse, ~16 us in one workgroup).  As launches on two streams they cost
+// two cross-stream hand-offs on the critical path (chain -> side stream ~7 us, side stream -> chain ~10-14 us: kernel trace, and
+// tools/probe_graph_handoff.hip); as launches on one stream they serialise.  Here they are ONE grid: the first MID_RB workgroups sum the
+// partials, the others compute GEMM tiles (gemm_body.h); the reduce workgroups sum (four consecutive entries per lane, the same four interleaved chains per
+// entry as gh_reduce_f32_kernel, so S is bit-identical to it) and the one whose arrival is last runs the T kernel's body on 256 threads.
+// Hand-off inside the launch (MI355X_MICROARCH.md, inter-workgroup visibility, first row of the hand-off table): S is stored sc1, every
+// storing wave waits vmcnt(0), one lane per workgroup adds to an agent-scope counter behind a workgroup barrier, the workgroup whose add
+// returned MID_RB - 1 loads S with sc1 loads behind another barrier.  Nothing spins: no residency requirement.  One workgroup per CU (LDS).
+constexpr int MID_RB = 64;
+struct LeafMidArgs {
+    GemmArgs g; int gx, nX;                                  // X tiles along M; GEMM workgroups = gx * nsplit
+    const float* Sp; int nslab; float* S; int sh;            // partials -> S (128 x 128 window); T reads it from (sh, sh)
+    int* counter;                                            // zero between launches (the last arriver resets it)
+    int a0, c0, c1; float* T; half_t* Th; half_t* Tth; int ldt, ld;
+};
+__global__ __launch_bounds__(256) void leaf_mid_kernel(LeafMidArgs m) {
+    if ((int)blockIdx.x >= MID_RB) {                         // (the reduce workgroups come first in the grid: theirs is the longer path)
+        const int b = (int)blockIdx.x - MID_RB;
+        gemm_f16_body<A_F32T, E_STORE_F32>(m.g, (half_t*)gh_smem, b % m.gx, 0, b / m.gx);
+        return;
+    }
+    __shared__ float4 part[4][64];
+    __shared__ float tdiag[TP];
+    __shared__ int is_last;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int e = ((int)blockIdx.x * 64 + lane) * 4;          // four consecutive entries of one row of the window
+    const bool act = ((e >> 7) >> 5) <= ((e & 127) >> 5);     // the partials hold the 10 upper 32 x 32 tiles only; T reads j >= i
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (act) {
+        float4 s0 = s, s1 = s, s2 = s, s3 = s;
+        auto add = [](float4& a, const float4& b) { a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w; };
+        int q = wave;
+        for (; q + 60 < m.nslab; q += 64) {
+            float4 v[16];
+#pragma unroll
+            for (int u = 0; u < 16; u++) v[u] = *(const float4*)&m.Sp[(long)(q + 4 * u) * (GW * GW) + e];
+#pragma unroll
+            for (int u = 0; u < 16; u += 4) { add(s0, v[u]); add(s1, v[u + 1]); add(s2, v[u + 2]); add(s3, v[u + 3]); }
+        }
+        {
+            float4 v[16];
+#pragma unroll
+            for (int u = 0; u < 16; u++) v[u] = *(const float4*)&m.Sp[(long)min(q + 4 * u, m.nslab - 1) * (GW * GW) + e];
+#pragma unroll
+            for (int u = 0; u < 16; u++) if (q + 4 * u >= m.nslab) v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int u = 0; u < 16; u += 4) { add(s0, v[u]); add(s1, v[u + 1]); add(s2, v[u + 2]); add(s3, v[u + 3]); }
+        }
+        s.x = (s0.x + s1.x) + (s2.x + s3.x); s.y = (s0.y + s1.y) + (s2.y + s3.y);
+        s.z = (s0.z + s1.z) + (s2.z + s3.z); s.w = (s0.w + s1.w) + (s2.w + s3.w);
+    }
+    part[wave][lane] = s;
+    __syncthreads();
+    if (wave == 0) {
+        const float4 p0 = part[0][lane], p1 = part[1][lane], p2 = part[2][lane], p3 = part[3][lane];
+        const float r4[4] = {(p0.x + p1.x) + (p2.x + p3.x), (p0.y + p1.y) + (p2.y + p3.y), (p0.z + p1.z) + (p2.z + p3.z), (p0.w + p1.w) + (p2.w + p3.w)};
+#pragma unroll
+        for (int c = 0; c < 4; c++)
+            __hip_atomic_store((unsigned*)&m.S[e + c], __builtin_bit_cast(unsigned, r4[c]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the stores have left before this workgroup signals
+    }
+    __syncthreads();
+    if (tid == 0) is_last = __hip_atomic_fetch_add(m.counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == MID_RB - 1;
+    __syncthreads();
+    if (!is_last) return;
+    if (tid == 0) __hip_atomic_store(m.counter, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    t_panel_body<256, true>(m.S + (long)m.sh * 128 + m.sh, 1, 0, 128, m.a0, m.c0, m.c1, m.T, m.Th, m.Tth, m.ldt, m.ld, (float*)gh_smem, tdiag);
+}
+void launch_leaf_mid(const GemmArgs& g1, const float* Sp, int nslab, float* S, int sh, int* counter, int a0, int c0, int c1,
+                     float* T, half_t* Th, half_t* Tth, int ldt, int ld, hipStream_t s) {
+    constexpr int LDS = 2 * TP * TPS * 4;
+    static_assert(LDS >= (gemm128::BM + gemm128::BN) * gemm128::LDSP * 2, "the GEMM tile's LDS image fits in the T body's");
+    MPQR_ONCE_PER_DEVICE((void)hipFuncSetAttribute((const void*)leaf_mid_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+    LeafMidArgs m{};
+    m.g = g1;
+    if (m.g.nsplit < 1) m.g.nsplit = 1;
+    if (m.g.nslab_in < 1) m.g.nslab_in = 1;
+    m.gx = (g1.M + gemm128::BM - 1) / gemm128::BM; m.nX = m.gx * m.g.nsplit;
+    m.Sp = Sp; m.nslab = nslab; m.S = S; m.sh = sh; m.counter = counter;
+    m.a0 = a0; m.c0 = c0; m.c1 = c1; m.T = T; m.Th = Th; m.Tth = Tth; m.ldt = ldt; m.ld = ld <= 0 ? ldt : ld;
+    hipLaunchKernelGGL(leaf_mid_kernel, dim3(m.nX + MID_RB), dim3(256), LDS, s, m);
 }
 
 // fp16 copies of one column block of a block-level T: Th[0:rows, c:c+w] = T[0:rows, c:c+w], Tth[c:c+w, 0:rows] = its transpose

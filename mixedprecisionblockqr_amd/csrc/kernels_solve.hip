@@ -51,38 +51,6 @@ __device__ int g_s3_trace_left = 1;
 typedef double double4s __attribute__((ext_vector_type(4)));
 typedef float float4s __attribute__((ext_vector_type(4)));
 
-// ---- in-wave broadcasts: DPP row_newbcast:n = lane n of the own 16-lane row (gfx90a+).  On gfx950 (tools/ubench_valu.hip)
-// v_fmac_f32_dpp costs what a plain v_fmac_f32 does (4.6 cycles per wave-instruction: the broadcast is free) and
-// v_mov_b64_dpp 4.6; v_readlane_b32 + s_nop + use costs 10-20 per value.  So every 16-lane row of a chain wave keeps its OWN
-// copy of the block's 16 x 16 diagonal block (lane li = column or row k0 + li) and never leaves its row.
-// Software hazard (not interlocked on gfx9): a DPP read of a VGPR needs 2 wait states after the VALU write -> NOP = 1 puts an
-// s_nop 1 in front where the source may just have been written.
-template <int I, int NOP>
-__device__ __forceinline__ double dpp_bcast64(double x) {
-    double r;
-    if (NOP) asm volatile("s_nop 1\n\tv_mov_b64_dpp %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(x), "n"(I));
-    else asm volatile("v_mov_b64_dpp %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(x), "n"(I));
-    return r;
-}
-template <int I, int NOP>
-__device__ __forceinline__ float dpp_bcast32(float x) {
-    float r;
-    if (NOP) asm volatile("s_nop 1\n\tv_mov_b32_dpp %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(x), "n"(I));
-    else asm volatile("v_mov_b32_dpp %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(x), "n"(I));
-    return r;
-}
-// acc += (lane I of a's row) * b
-template <int I, int NOP>
-__device__ __forceinline__ void fmac_dpp(float& acc, float a, float b) {
-    if (NOP) asm volatile("s_nop 1\n\tv_fmac_f32_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(a), "v"(b), "n"(I));
-    else asm volatile("v_fmac_f32_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(a), "v"(b), "n"(I));
-}
-// compile-time loop I = LO .. 15
-template <int LO, typename F>
-__device__ __forceinline__ void static_for16(F&& f) {
-    if constexpr (LO < 16) { f(std::integral_constant<int, LO>{}); static_for16<LO + 1>(f); }
-}
-
 // The chain blocks are straight-line code: no divergent branch inside the 16 steps (a branch splits the block and LLVM then
 // sinks every deferred update next to its use).  Per-step scalars are collected in lane kk of a register and written after
 // the block; masked LDS stores go to a dummy slot instead.
@@ -132,10 +100,6 @@ __device__ __forceinline__ void s3_piv_link(S3Piv& q) {
         const bool ok = q.p > 1e-30 && q.p < 1e30;           // false: zero / cancelled column or out of range -> flagged
         q.y = ok ? q.y0 * q.t : 0.0; s3_pin(q.y);
     } else if constexpr (J == 9) { q.y2 = q.y * q.y; s3_pin(q.y2); }
-}
-template <int LO, int HI, typename F>
-__device__ __forceinline__ void static_range(F&& f) {
-    if constexpr (LO < HI) { f(std::integral_constant<int, LO>{}); static_range<LO + 1, HI>(f); }
 }
 template <int NS>
 __device__ __forceinline__ void s3_chol_block(double (&dg)[16], double (&n)[16][2], int li, double& piv) {
@@ -432,6 +396,62 @@ __global__ __launch_bounds__(S3_THREADS) void gh_solve3_kernel(LeafArgs a, const
     if (tid == 0) lflag = 0;
     KT();
 
+    // ---- output helpers of the update waves (also used after the triangular inverse, below)
+    float rc_tail[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
+    // R[k][j] = -sgn(u0_k) c_kj (j >= k): wave u sends out rows 2u, 2u + 1 of every block.  The Cholesky rows are read (fp32)
+    // in the round the Householder waves work on the block; the signs exist one barrier later, so the stores wait in
+    // registers until the next round
+    auto store_r = [&](int kb, const float (&rc)[2][2]) {
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+            const int k = kb + j;
+            if (k < w) {
+                const float ns = -sgn[k];
+                float* rowp = a.A + (long)(a.c0 + k) * a.lda + a.c0;
+#pragma unroll
+                for (int s2 = 0; s2 < 2; s2++) {
+                    const int col = lane + 64 * s2;
+                    if (col >= k && col < w) rowp[col] = ns * rc[j][s2];
+                }
+            }
+        }
+    };
+    // V_top of block b (Ws[i][k], i > k; diagonal in vdl): A below the diagonal, the fp16 copies V and V^T -- one round after
+    // the Householder waves finished the block, 16-byte stores where the leaf is 8-aligned (else: after the loop, all threads)
+    const bool vec_out = (w & 7) == 0 && (a.c0 & 7) == 0;
+    auto store_v = [&](int b, int u) {
+        typedef half_t half4v __attribute__((ext_vector_type(4)));
+        typedef half_t half8v __attribute__((ext_vector_type(8)));
+        if (!vec_out) return;
+        {
+            const int id = u * 64 + lane, i = 16 * b + (id >> 2), k = 16 * b + 4 * (id & 3);   // 4 consecutive k: a row segment of A and Vh
+            if (i < w && k < w && i >= k) {
+                float t4[4]; half4v hv;
+#pragma unroll
+                for (int q = 0; q < 4; q++) t4[q] = Ws[i * TPS + k + q];
+                float* dst = &a.A[(long)(a.c0 + i) * a.lda + a.c0 + k];
+                if (i > k + 3) *(float4*)dst = make_float4(t4[0], t4[1], t4[2], t4[3]);
+                else {
+#pragma unroll
+                    for (int q = 0; q < 4; q++) if (i > k + q) dst[q] = t4[q];
+                }
+                const float vd = vdl[i];
+#pragma unroll
+                for (int q = 0; q < 4; q++) hv[q] = i > k + q ? (half_t)t4[q] : (i == k + q ? (half_t)vd : (half_t)0.f);
+                *(half4v*)&a.Vh[(long)(a.c0 + i) * a.ldvh + a.c0 + k] = hv;
+            }
+        }
+        if (u < 4) {
+            const int id = u * 64 + lane, k = 16 * b + (id >> 4), i = 8 * (id & 15);            // 8 consecutive i: a row segment of V^T
+            if (k < w && i < w && i + 7 >= k) {
+                half8v hv;
+                const float vd = vdl[k];
+#pragma unroll
+                for (int q = 0; q < 8; q++) hv[q] = (i + q > k) ? (half_t)Ws[(i + q) * TPS + k] : (i + q == k ? (half_t)vd : (half_t)0.f);
+                *(half8v*)&a.Vt[(long)(a.c0 + k) * a.ldvt + a.c0 + i] = hv;
+            }
+        }
+    };
     // Every role runs the same sequence of workgroup barriers (one after the set-up, two per round); the roles' code paths are
     // separate so that each gets its own register allocation.
     if (wave < 3) __builtin_amdgcn_s_setprio(3);           // the chains first: their panel loads compete with the update waves' operand reads
@@ -553,64 +573,10 @@ __global__ __launch_bounds__(S3_THREADS) void gh_solve3_kernel(LeafArgs a, const
         for (int I = 0; I < 8; I++)
 #pragma unroll
             for (int e = 0; e < 4; e++) Bacc[I][e] = BV[I][e] ? Bacc[I][e] : 0.f;
-        // R[k][j] = -sgn(u0_k) c_kj (j >= k): wave u sends out rows 2u, 2u + 1 of every block.  The Cholesky rows are read (fp32)
-        // in the round the Householder waves work on the block; the signs exist one barrier later, so the stores wait in
-        // registers until the next round
         float rc[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
-        auto store_r = [&](int kb) {
-#pragma unroll
-            for (int j = 0; j < 2; j++) {
-                const int k = kb + j;
-                if (k < w) {
-                    const float ns = -sgn[k];
-                    float* rowp = a.A + (long)(a.c0 + k) * a.lda + a.c0;
-#pragma unroll
-                    for (int s2 = 0; s2 < 2; s2++) {
-                        const int col = lane + 64 * s2;
-                        if (col >= k && col < w) rowp[col] = ns * rc[j][s2];
-                    }
-                }
-            }
-        };
-        // V_top of block b (Ws[i][k], i > k; diagonal in vdl): A below the diagonal, the fp16 copies V and V^T -- one round after
-        // the Householder waves finished the block, 16-byte stores where the leaf is 8-aligned (else: after the loop, all threads)
-        const bool vec_out = (w & 7) == 0 && (a.c0 & 7) == 0;
-        auto store_v = [&](int b) {
-            typedef half_t half4v __attribute__((ext_vector_type(4)));
-            typedef half_t half8v __attribute__((ext_vector_type(8)));
-            if (!vec_out) return;
-            {
-                const int id = u * 64 + lane, i = 16 * b + (id >> 2), k = 16 * b + 4 * (id & 3);   // 4 consecutive k: a row segment of A and Vh
-                if (i < w && k < w && i >= k) {
-                    float t4[4]; half4v hv;
-#pragma unroll
-                    for (int q = 0; q < 4; q++) t4[q] = Ws[i * TPS + k + q];
-                    float* dst = &a.A[(long)(a.c0 + i) * a.lda + a.c0 + k];
-                    if (i > k + 3) *(float4*)dst = make_float4(t4[0], t4[1], t4[2], t4[3]);
-                    else {
-#pragma unroll
-                        for (int q = 0; q < 4; q++) if (i > k + q) dst[q] = t4[q];
-                    }
-                    const float vd = vdl[i];
-#pragma unroll
-                    for (int q = 0; q < 4; q++) hv[q] = i > k + q ? (half_t)t4[q] : (i == k + q ? (half_t)vd : (half_t)0.f);
-                    *(half4v*)&a.Vh[(long)(a.c0 + i) * a.ldvh + a.c0 + k] = hv;
-                }
-            }
-            if (u < 4) {
-                const int id = u * 64 + lane, k = 16 * b + (id >> 4), i = 8 * (id & 15);            // 8 consecutive i: a row segment of V^T
-                if (k < w && i < w && i + 7 >= k) {
-                    half8v hv;
-                    const float vd = vdl[k];
-#pragma unroll
-                    for (int q = 0; q < 8; q++) hv[q] = (i + q > k) ? (half_t)Ws[(i + q) * TPS + k] : (i + q == k ? (half_t)vd : (half_t)0.f);
-                    *(half8v*)&a.Vt[(long)(a.c0 + k) * a.ldvt + a.c0 + i] = hv;
-                }
-            }
-        };
         for (int r = 0; r <= nb; r++) {
             if (u == 7) S3T(3, 4 * r);
-            if (r >= 2) { store_r(16 * (r - 2) + 2 * u); store_v(r - 2); }
+            if (r >= 2) { store_r(16 * (r - 2) + 2 * u, rc); store_v(r - 2, u); }
             // ---- segment 1: the updates nobody is waiting for
 #ifndef S3_DBG_NOUPD
             if (r >= 1 && r + 1 < nb) {                    // Cholesky block r-1 onto the tiles below the next panel
@@ -671,11 +637,23 @@ __global__ __launch_bounds__(S3_THREADS) void gh_solve3_kernel(LeafArgs a, const
             if (u == 7) S3T(3, 4 * r + 3);
             s3_barrier();
         }
-        store_r(16 * (nb - 1) + 2 * u);
-        store_v(nb - 1);
+        // the last block's R rows and V_top go out AFTER the triangular inverse: a wave with global stores in flight stalls there (the
+        // compiler waits for them before it reuses their registers: 4 - 6 k cycles inside the inverse's first stage, in-kernel stamps)
+#pragma unroll
+        for (int j = 0; j < 2; j++)
+#pragma unroll
+            for (int s2 = 0; s2 < 2; s2++) rc_tail[j][s2] = rc[j][s2];
     }
     __builtin_amdgcn_s_setprio(0);
     KT();
+    __syncthreads();                                       // the panels are dead: their LDS becomes Ts
+    for (int e = tid; e < TP * TPS; e += S3_THREADS) Ts[e] = 0.f;
+    __syncthreads();
+    // C = (D^-1 + W)^-1, columns of flagged reflectors zeroed (tri_inverse_128 reads only the strictly upper part of Ws)
+    KT();
+    tri_inverse_128(Ws, tdiag, Ts, (w + 31) / 32, tid);
+    KT();
+    if (wave >= 3) { store_r(16 * (nb - 1) + 2 * (wave - 3), rc_tail); store_v(nb - 1, wave - 3); }
     // ------------------------------------------------ outputs.  R went out row by row (Householder wave); V_top sits in the
     // lower triangle of Ws (Ws[i][k] = v_top^(k)[i], i > k), the diagonal entries in vdl.
     if ((w & 7) == 0 && (a.c0 & 7) == 0) {                 // usual case: the update waves sent V_top out block by block
@@ -703,13 +681,7 @@ __global__ __launch_bounds__(S3_THREADS) void gh_solve3_kernel(LeafArgs a, const
         atomicOr(flag, 1);
         if (a.hostflag) __hip_atomic_store(a.hostflag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // the enqueuing host thread polls this word
     }
-    __syncthreads();                                       // the panels are dead: their LDS becomes Ts
-    for (int e = tid; e < TP * TPS; e += S3_THREADS) Ts[e] = 0.f;
-    __syncthreads();
-    // C = (D^-1 + W)^-1, columns of flagged reflectors zeroed (tri_inverse_128 reads only the strictly upper part of Ws)
-    KT();
-    tri_inverse_128(Ws, tdiag, Ts, (w + 31) / 32, tid);
-    KT();
+
     for (int e = tid; e < GW * GW; e += S3_THREADS) {      // window coordinates (leaf index + off), zero elsewhere
         const int i = (e >> 7) - off, k = (e & 127) - off;
         Cv[e] = (i >= 0 && i <= k && k < w && cmask[k]) ? Ts[i * TPS + k] : 0.f;

@@ -144,6 +144,11 @@ void launch_gh_reduce_f32(const float* Sp, int nslab, float* S, hipStream_t s);
 
 // T of a leaf (<= 128 reflectors) from its Gram slabs S (row stride lds_, aligned range starting at a0)
 // ld: leading dimension of T / Th / Tth (0: ldt, the node's own contiguous T)
+// One launch for the middle of a Gram-Householder leaf (kernels_panel.hip, leaf_mid_kernel): the split-K GEMM g1 (A_F32T, E_STORE_F32,
+// N <= 128) beside the sum of the nslab partial Gram matrices Sp -> S and the leaf's T from it (arguments as launch_t_leaf, S read at
+// (sh, sh) of its 128 x 128 window).  counter: one device int, zero between launches.
+void launch_leaf_mid(const GemmArgs& g1, const float* Sp, int nslab, float* S, int sh, int* counter, int a0, int c0, int c1,
+                     float* T, half_t* Th, half_t* Tth, int ldt, int ld, hipStream_t s);
 void launch_t_leaf(const float* S, int nslab, long slab_stride, int lds_, int a0, int c0, int c1,
                    float* T, half_t* Th, half_t* Tth, int ldt, hipStream_t s, int ld = 0);
 // fp16 copies (plain and transposed) of column block [c, c+w) x rows [0, rows) of a T with leading dimension ld

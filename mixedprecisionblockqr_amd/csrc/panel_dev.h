@@ -1,6 +1,7 @@
 // panel_dev.h -- device helpers shared by the panel translation units (kernels_panel.hip, kernels_solve.hip)
 #pragma once
 #include "mpqr_internal.h"
+#include <type_traits>
 
 namespace mpqr {
 
@@ -9,7 +10,7 @@ extern __shared__ __attribute__((aligned(16))) char gh_smem[];   // dynamic LDS 
 // optional in-kernel phase timing (make EXTRA=-DMPQR_KTRACE): thread 0 of block 0 stamps s_memtime at phase
 // boundaries and prints the deltas for the first few launches of each kernel
 #ifdef MPQR_KTRACE
-static __device__ int g_ktrace_left[8] = {3, 3, 3, 3, 3, 3, 3, 3};
+static __device__ int g_ktrace_left[8] = {3, 3, 3, 3, 6, 3, 3, 3};
 #define KT_DECL long kt_[16]; int kn_ = 0; const bool kon_ = (threadIdx.x == 0 && blockIdx.x == 0)
 #define KT() do { if (kon_ && kn_ < 16) kt_[kn_++] = clock64(); } while (0)
 #define KT_DUMP(id, name) do { if (kon_ && atomicSub(&g_ktrace_left[id], 1) > 0) { printf("ktrace %s:", name); \
@@ -44,6 +45,42 @@ __device__ __forceinline__ double fast_rsqrt(double x) {
     return refine_rsqrt(x, (double)rsqrtf((float)x));
 }
 
+// ---- in-wave broadcasts: DPP row_newbcast:n = lane n of the own 16-lane row (gfx90a+).  On gfx950 (tools/ubench_valu.hip)
+// v_fmac_f32_dpp costs what a plain v_fmac_f32 does (4.6 cycles per wave-instruction: the broadcast is free) and
+// v_mov_b64_dpp 4.6; v_readlane_b32 + s_nop + use costs 10-20 per value.  So every 16-lane row of a chain wave keeps its OWN
+// copy of the block's 16 x 16 diagonal block (lane li = column or row k0 + li) and never leaves its row.
+// Software hazard (not interlocked on gfx9): a DPP read of a VGPR needs 2 wait states after the VALU write -> NOP = 1 puts an
+// s_nop 1 in front where the source may just have been written.
+template <int I, int NOP>
+__device__ __forceinline__ double dpp_bcast64(double x) {
+    double r;
+    if (NOP) asm volatile("s_nop 1\n\tv_mov_b64_dpp %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(x), "n"(I));
+    else asm volatile("v_mov_b64_dpp %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(x), "n"(I));
+    return r;
+}
+template <int I, int NOP>
+__device__ __forceinline__ float dpp_bcast32(float x) {
+    float r;
+    if (NOP) asm volatile("s_nop 1\n\tv_mov_b32_dpp %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(x), "n"(I));
+    else asm volatile("v_mov_b32_dpp %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(x), "n"(I));
+    return r;
+}
+// acc += (lane I of a's row) * b
+template <int I, int NOP>
+__device__ __forceinline__ void fmac_dpp(float& acc, float a, float b) {
+    if (NOP) asm volatile("s_nop 1\n\tv_fmac_f32_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(a), "v"(b), "n"(I));
+    else asm volatile("v_fmac_f32_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(a), "v"(b), "n"(I));
+}
+// compile-time loop I = LO .. 15
+template <int LO, typename F>
+__device__ __forceinline__ void static_for16(F&& f) {
+    if constexpr (LO < 16) { f(std::integral_constant<int, LO>{}); static_for16<LO + 1>(f); }
+}
+
+template <int LO, int HI, typename F>
+__device__ __forceinline__ void static_range(F&& f) {
+    if constexpr (LO < HI) { f(std::integral_constant<int, LO>{}); static_range<LO + 1, HI>(f); }
+}
 typedef float floatx16p __attribute__((ext_vector_type(16)));
 constexpr int TP = 128, TPS = 129;
 
@@ -80,24 +117,44 @@ __device__ __forceinline__ void tri_inverse_128(float* Ss, const float* tdiag, f
     if (tid == 0 && blockIdx.x == 0) ti_[tn_++] = clock64();
 #endif
     // diagonal 16 x 16 blocks: row a of the inverse depends on row a only -- lane a runs the column recurrence in registers
-    // (eight blocks: two per wave, one per half of the first 32 lanes ... of waves 0-3)
-    if (wave < nblk && lane < 32) {
+    // (eight blocks: two per wave, one per 16-lane row of the first 32 lanes of waves 0-3)
+    if (wave < nblk && lane < 32) {                         // (four blocks per wave on all 64 lanes of waves 0 and 1 measured 6.4 k cycles against 2.0 k)
         const int base = 32 * wave + 16 * (lane >> 4), a = lane & 15;
+        // lane l of the block's 16-lane row holds ROW l of the block (sc[i] = S[l][i]) and the diagonal entry of row l: 17 loads, all in
+        // flight together.  Column i of the recurrence then takes S[q][i] from lane q through the DPP operand of the FMA (row_newbcast,
+        // free on gfx950: tools/ubench_valu.hip) -- straight-line code.  (Written with S[q][i] read from LDS where it is used, the
+        // compiler put each column's loads inside a divergent branch behind their own s_waitcnt: 74 LDS round trips, 5 - 8.5 k cycles of
+        // the inverse's 20 - 23 k; in-kernel stamps, tools/ktrace_solve.sh.)
+        float sc[16];
+#pragma unroll
+        for (int i = 0; i < 16; i++) sc[i] = Ss[(base + a) * TPS + base + i];
+        const float tda = tdiag[base + a];
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         float tr[16];
-#pragma unroll
-        for (int i = 0; i < 16; i++) {
-            const float tii = tdiag[base + i];
+        static_for16<0>([&](auto II) {
+            constexpr int i = decltype(II)::value;
+            const float tii = dpp_bcast32<i, 0>(tda);
             float ps[4] = {0.f, 0.f, 0.f, 0.f};            // four partial sums: a quarter of the dependent chain
-#pragma unroll
-            for (int q = 0; q < i; q++) ps[q & 3] += tr[q] * Ss[(base + q) * TPS + base + i];      // broadcast reads; preloading the block into registers
-                                                                                                      // measured the same in gh_solve3 and spills in t_panel
+            static_range<0, i>([&](auto QQ) {
+                constexpr int q = decltype(QQ)::value;
+                fmac_dpp<q, 0>(ps[q & 3], sc[i], tr[q]);   // += S[q][i] (lane q's sc[i]) * tr[q]
+            });
             const float sum = (ps[0] + ps[1]) + (ps[2] + ps[3]);
             tr[i] = (a < i) ? -tii * sum : (a == i ? tii : 0.f);
-        }
+        });
+#ifdef MPQR_KTRACE
+        if (tid == 0 && blockIdx.x == 0) ti_[tn_++] = clock64();
+#endif
 #pragma unroll
         for (int i = 0; i < 16; i++) Ts[(base + a) * TPS + base + i] = tr[i];
     }
+#ifdef MPQR_KTRACE
+    if (tid == 0 && blockIdx.x == 0) ti_[tn_++] = clock64();
+#endif
     __syncthreads();
+#ifdef MPQR_KTRACE
+    if (tid == 0 && blockIdx.x == 0) ti_[tn_++] = clock64();
+#endif
     // 16 -> 32 inside every 32-block (one wave each): with L / R the two halves, T_LR = -T_L (S_LR T_R).  On 32 x 32 tiles:
     // rows < 16 of  S_blk[:, 16:32] T_blk[16:32, :]  (k range 16..32) are S_LR T_R in the columns >= 16; it replaces S_LR,
     // then rows < 16 of  T_blk[:, 0:16] (that)[0:16, :]  (k range 0..16) are T_L (S_LR T_R).
@@ -151,7 +208,7 @@ __device__ __forceinline__ void tri_inverse_128(float* Ss, const float* tdiag, f
     }
 #ifdef MPQR_KTRACE
     if (tid == 0 && blockIdx.x == 0 && atomicSub(&g_ktrace_left[4], 1) > 0) {
-        printf("ktrace tri_inverse diag|merge32|merge64:");
+        printf("ktrace tri_inverse rec|store|barrier|merge16|merge32|merge64:");
         for (int q = 1; q < tn_; q++) printf(" %ld", ti_[q] - ti_[q - 1]);
         printf("\n");
     }
