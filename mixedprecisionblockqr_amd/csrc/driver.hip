@@ -112,6 +112,9 @@ struct mpqr_handle_s {
     struct MidT { const float* Sp; int nslab; int sh, a0, c0, c1; float* T; half_t* Th; half_t* Tth; int ldt, ld; };
     const MidT* mid = nullptr;    // set by the flat schedule around one apply_node call: its X GEMM and the leaf's T go out as ONE launch
     bool leaf_mid = true;         // MPQR_LEAF_MID=0: X on the side stream, Gram sum and T as two launches on the chain (before round 4)
+    int* tflag = nullptr;         // device word the chain publishes its progress in (leaf_xt_kernel), polled by the T stream (wait_flag_kernel)
+    int tseq = 0, xt_pub = 0;     // last published value; value the next leaf_xt launch of apply_node is to publish (0: none)
+    bool tpoll = true;            // MPQR_TPOLL=0: the T stream follows the chain through an event (costs the chain ~4 us per leaf)
     float* P = nullptr;    int maxwg = 0;
     double* Gp = nullptr; double* Gs = nullptr; float* Cv = nullptr; int* dflag = nullptr;   // Gram-Householder leaf workspace
     float* Sp = nullptr;          // per-workgroup partial Grams of the fp16 reflectors (fused into gh_apply)
@@ -232,7 +235,7 @@ int dalloc(mpqr_handle_t h, T** p, size_t elems) {
 void free_plan(mpqr_handle_t h) {
     void* ptrs[] = {h->dA, h->dA0, h->dQ, h->Vh, h->Vt, h->vdiag, h->Xt, h->Yt, h->S, h->P, h->tmp1, h->tmp2,
                     h->Tf, h->Th, h->Tth, h->dstage, h->Gp, h->Gs, h->Cv, h->dflag, h->Vf, h->Yf, h->Xt1, h->Yt1, h->Sp,
-                    h->rbTf, h->rbTh, h->rbTth, h->Sleaf, h->mid_counter, h->V8n, h->V8t, h->A8t, h->Y8, h->Xt2, h->Yt2,
+                    h->rbTf, h->rbTh, h->rbTth, h->Sleaf, h->mid_counter, h->tflag, h->V8n, h->V8t, h->A8t, h->Y8, h->Xt2, h->Yt2,
                     h->S2, h->tmp1b, h->tmp2b, h->Qt, h->At, h->Xh, h->Wh, h->Xl, h->Xh1, h->Xl1};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (h->hflag_host) (void)hipHostFree(h->hflag_host);
@@ -243,7 +246,7 @@ void free_plan(mpqr_handle_t h) {
     h->dstage = nullptr; h->stage_elems = 0;
     h->Gp = nullptr; h->Gs = nullptr; h->Cv = nullptr; h->dflag = nullptr; h->Vf = nullptr; h->Yf = nullptr;
     h->Xt1 = nullptr; h->Yt1 = nullptr; h->Sp = nullptr; h->Xt2 = nullptr; h->Yt2 = nullptr; h->xt2_elems = 0;
-    h->rbTf = nullptr; h->rbTh = h->rbTth = nullptr; h->rb_elems = 0; h->nflag = 0; h->leaf_robust.clear(); h->Sleaf = nullptr; h->mid_counter = nullptr;
+    h->rbTf = nullptr; h->rbTh = h->rbTth = nullptr; h->rb_elems = 0; h->nflag = 0; h->leaf_robust.clear(); h->Sleaf = nullptr; h->mid_counter = nullptr; h->tflag = nullptr;
     h->V8n = h->V8t = h->A8t = h->Y8 = nullptr; h->v8_node = -1;
     for (hipEvent_t e : h->chain_ev) (void)hipEventDestroy(e);
     h->chain_ev.clear(); h->chain_used = 0; h->far_used = 0;
@@ -513,7 +516,10 @@ void apply_node(mpqr_handle_t h, const Node& nd, float* C, long ldc, int clo, in
     g2.in_scale = 1.f; g2.alpha = 1.f; g2.nsplit = 1;
     g2.tri = trans_t ? 2 : 1;                              // T is upper triangular: T^T rows end at the diagonal, T rows start there
     g2.cscale = h->Tf + nd.toff; g2.cscale_ld = (long)nd.tld + 1;   // tau_n: the fp16 T's have a unit diagonal
-    if (fuse_xt) launch_leaf_xt(Xt, g1.nsplit, slab, M1, g2.Bt, g2.ldb, g2.tri, Yt, Kr, g2.cscale, g2.cscale_ld, st);
+    if (fuse_xt) {
+        launch_leaf_xt(Xt, g1.nsplit, slab, M1, g2.Bt, g2.ldb, g2.tri, Yt, Kr, g2.cscale, g2.cscale_ld, st, h->xt_pub ? h->tflag : nullptr, h->xt_pub);
+        h->xt_pub = 0;
+    }
     else if (x16) { g2.A = Xhi; g2.A2 = Xlo; gemm_dispatch(A_H16, E_STORE_H16, g2, st); }
     else
     gemm_dispatch(A_F32S, E_STORE_H16, g2, st);
@@ -871,10 +877,15 @@ int factor_block_flat(mpqr_handle_t h, int top, const std::vector<int>& leaves) 
             Range rg("mpqr:in_block_update");
             h->op1_stream = (tq && !mid_leaf) ? h->sT : nullptr;
             h->mid = mid_leaf ? &mid_desc : nullptr;
+            const bool poll = mid_leaf && h->tpoll && h->tflag && h->hflag_dev && h->flag_words > 0;
+            h->xt_pub = poll ? ++h->tseq : 0;                  // leaf_xt (behind the leaf's T in the chain stream) publishes this value
             apply_node(h, lf, h->Aeff, h->lda, lf.c1, own_end, true, h->a_scale, false);
             h->op1_stream = nullptr;
-            if (h->mid) { h->mid = nullptr; h->dispatch_error = true; }      // (apply_node took another path than predicted: T_j was never built)
-            if (mid_leaf && tq) t_stream_follows_chain(h);
+            if (h->mid || h->xt_pub) { h->mid = nullptr; h->xt_pub = 0; h->dispatch_error = true; }   // (apply_node took another path than predicted)
+            // the T stream may go on (with the previous leaf's column block of T) once the chain is past this leaf's T: it polls the
+            // published word instead of waiting for an event the chain stream would have to record
+            if (poll) launch_wait_flag(h->tflag, h->tseq, h->hflag_dev + h->flag_words - 1, h->sT);
+            else if (mid_leaf && tq) t_stream_follows_chain(h);
         }
         if (have_rest) {                                   // the rest, on the T stream
             Range rg("mpqr:in_block_update_deferred");
@@ -1105,7 +1116,26 @@ int form_q(mpqr_handle_t h) {
 
 // the far-update stream: low priority, unmasked (restricting it to 1/2 .. 7/8 of the CUs made the step slower in rounds 2 and 3; only
 // masks that keep CUs on every XCC are honoured by the runtime at all: tools/probe_cumask.hip)
-hipError_t create_update_stream(hipStream_t* st, int prio) { return hipStreamCreateWithPriority(st, hipStreamNonBlocking, prio); }
+hipError_t create_update_stream(hipStream_t* st, int prio) {
+    // MPQR_UPDATE_CU_MASK=0x........ (32-bit pattern, repeated over the 8 XCCs): experiment hook, re-measured in round 4
+    const char* e = getenv("MPQR_UPDATE_CU_MASK");
+    if (e && strlen(e) > 2 && e[0] == '0' && (e[1] == 'x' || e[1] == 'X')) {
+        uint32_t mask[8];
+        const uint32_t pat = (uint32_t)strtoul(e, nullptr, 16);
+        for (int i = 0; i < 8; i++) mask[i] = pat;
+        if (hipExtStreamCreateWithCUMask(st, 8, mask) == hipSuccess) return hipSuccess;
+    }
+    // MPQR_UPDATE_CU_ROWS=N: the far stream may use CUs 0 .. N-1 of the 8 in EVERY shader engine (mask word i = CU i of all 32 engines)
+    if (const char* r = getenv("MPQR_UPDATE_CU_ROWS")) {
+        const int n = atoi(r);
+        if (n >= 1 && n < 8) {
+            uint32_t mask[8];
+            for (int i = 0; i < 8; i++) mask[i] = i < n ? 0xffffffffu : 0u;
+            if (hipExtStreamCreateWithCUMask(st, 8, mask) == hipSuccess) return hipSuccess;
+        }
+    }
+    return hipStreamCreateWithPriority(st, hipStreamNonBlocking, prio);
+}
 
 int check_shape(mpqr_handle_t h, int m, int n, int r) {
     if (!h) return MPQR_ERR_INVALID;
@@ -1232,6 +1262,7 @@ static int plan_common(mpqr_handle_t h, int m, int n, int r, const mpqr_opts* op
     if (const char* e = getenv("MPQR_GH_MIN_ROWS")) h->gh_min_rows = atoi(e);      // tuning hook
     if (const char* e = getenv("MPQR_TAIL_LEAF")) h->tail_leaf = atoi(e) != 0;       // A/B hook
     if (const char* e = getenv("MPQR_LEAF_MID")) h->leaf_mid = atoi(e) != 0;         // A/B hook
+    if (const char* e = getenv("MPQR_TPOLL")) h->tpoll = atoi(e) != 0;               // A/B hook
     h->m_pad = rup(m, 256); h->n_pad = rup(n, 256);
     int Ko = o.outer_block > 0 ? o.outer_block : 1024;
     Ko = std::max(Ko, 32);
@@ -1369,6 +1400,9 @@ static int plan_common(mpqr_handle_t h, int m, int n, int r, const mpqr_opts* op
     if ((rc = dalloc(h, &h->Sleaf, (size_t)128 * 128))) return rc;
     if ((rc = dalloc(h, &h->mid_counter, (size_t)1))) return rc;
     HIPCHK(h, hipMemsetAsync(h->mid_counter, 0, sizeof(int), h->s0));
+    if ((rc = dalloc(h, &h->tflag, (size_t)1))) return rc;
+    HIPCHK(h, hipMemsetAsync(h->tflag, 0, sizeof(int), h->s0));
+    h->tseq = 0;
     if ((rc = dalloc(h, &h->P, (size_t)2 * h->maxwg * 32))) return rc;
     if ((rc = dalloc(h, &h->Gp, (size_t)(h->m_pad / 128 + 2) * 16384))) return rc;
     if ((rc = dalloc(h, &h->Gs, (size_t)16384))) return rc;
@@ -1706,6 +1740,8 @@ int mpqr_factor(mpqr_handle_t h) {
         HIPCHK(h, hipEventRecord(h->ev[2], h->s0));
         HIPCHK(h, hipEventSynchronize(h->ev[1]));           // the block loop (not Q formation) is done: the flag word is final
         HIPCHK(h, hipGetLastError());
+        if (h->hflag_host && h->flag_words > 0 && __atomic_load_n(h->hflag_host + h->flag_words - 1, __ATOMIC_RELAXED) != 0)
+            return fail(h, MPQR_ERR_HIP, "the T stream's wait for the chain stream timed out (wait_flag_kernel)");
         if (!flag_words_set(h, h->flag_words) && !h->pass_aborted) break;
         h->factored = false; h->q_formed = false;
         flags.assign(h->nodes.size(), 0);

@@ -771,7 +771,12 @@ typedef half_t half4x __attribute__((ext_vector_type(4)));
 typedef float float4x __attribute__((ext_vector_type(4)));
 __global__ __launch_bounds__(256) void leaf_xt_kernel(const float* __restrict__ X, int nslab, long slab_stride, int M1,
                                                       const half_t* __restrict__ Bt, long ldb, int tri,
-                                                      half_t* __restrict__ Y, long ldy, const float* __restrict__ cscale, long cs_ld) {
+                                                      half_t* __restrict__ Y, long ldy, const float* __restrict__ cscale, long cs_ld,
+                                                      int* pub_flag, int pub_value) {
+    // pub_flag: tell the T stream that everything BEFORE this kernel in the chain stream (the leaf's reflectors, its T) is complete and
+    // visible -- it is, or this kernel would not have started.  wait_flag_kernel polls the word: an event record here would cost the
+    // chain stream 3 - 4.5 us per leaf (tools/probe_graph_handoff.hip), this store costs it nothing.
+    if (pub_flag && blockIdx.x == 0 && threadIdx.x == 0) __hip_atomic_store(pub_flag, pub_value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __shared__ __attribute__((aligned(16))) half_t Xs[16][136];       // fp16(X)
     __shared__ __attribute__((aligned(16))) half_t Xl[16][136];       // X - fp16(X): the product keeps X to ~22 bits
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -825,9 +830,30 @@ __global__ __launch_bounds__(256) void leaf_xt_kernel(const float* __restrict__ 
     }
 }
 void launch_leaf_xt(const float* X, int nslab, long slab_stride, int M1, const half_t* Bt, long ldb, int tri, half_t* Y, long ldy,
-                    const float* cscale, long cscale_ld, hipStream_t s) {
+                    const float* cscale, long cscale_ld, hipStream_t s, int* pub_flag, int pub_value) {
     hipLaunchKernelGGL(leaf_xt_kernel, dim3((M1 + 15) / 16), dim3(256), 0, s, X, nslab, slab_stride, M1, Bt, ldb, tri, Y, ldy,
-                       cscale, cscale_ld);
+                       cscale, cscale_ld, pub_flag, pub_value);
+}
+
+// One wave waits until *flag >= value (published by a kernel of ANOTHER stream: leaf_xt_kernel), then the stream goes on: a cross-stream
+// dependency that costs the publishing stream nothing.  The kernels behind this one start after it has ended, i.e. with the usual
+// start-of-kernel acquire, so they see what the publisher's predecessors wrote.  The values of a handle only grow (a restarted pass
+// publishes larger ones), so a stale word can only end the wait early for work whose inputs are older still.  Exit condition every
+// wave reaches: the publisher is always enqueued BEFORE the waiter (host order); should it never run, the wait gives up after 0.2 s and
+// raises *timeout_word (mapped host memory), which mpqr_factor reports as an error.
+__global__ __launch_bounds__(64) void wait_flag_kernel(const int* __restrict__ flag, int value, int* __restrict__ timeout_word) {
+    if (threadIdx.x != 0) return;
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();       // 100 MHz
+    while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < value) {
+        __builtin_amdgcn_s_sleep(8);
+        if (__builtin_amdgcn_s_memrealtime() - t0 > 20000000ull) {
+            __hip_atomic_store(timeout_word, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            break;
+        }
+    }
+}
+void launch_wait_flag(const int* flag, int value, int* timeout_word, hipStream_t s) {
+    hipLaunchKernelGGL(wait_flag_kernel, dim3(1), dim3(64), 0, s, flag, value, timeout_word);
 }
 
 // ------------------------------------------------------------------ T of a leaf (up to 128 reflectors)

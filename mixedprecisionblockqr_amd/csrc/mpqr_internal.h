@@ -139,7 +139,9 @@ void launch_gh_apply(const LeafArgs& a, const float* Cv, float* Sp, hipStream_t 
 void launch_gh_solve3(const LeafArgs& a, const double* G, float* Cv, int* flag, hipStream_t s);
 // Y[M1 x 128] (fp16, ld ldy) = fp16(sum of nslab X slabs, M1 x 128 fp32) * T', Bt[n][k] = T'[k][n] (fp16, ld ldb), tri as GemmArgs::tri
 void launch_leaf_xt(const float* X, int nslab, long slab_stride, int M1, const half_t* Bt, long ldb, int tri, half_t* Y, long ldy,
-                    const float* cscale, long cscale_ld, hipStream_t s);
+                    const float* cscale, long cscale_ld, hipStream_t s, int* pub_flag = nullptr, int pub_value = 0);
+// cross-stream dependency without an event: stream s goes on once *flag >= value (published by leaf_xt_kernel: pub_flag / pub_value)
+void launch_wait_flag(const int* flag, int value, int* timeout_word, hipStream_t s);
 void launch_gh_reduce_f32(const float* Sp, int nslab, float* S, hipStream_t s);
 
 // T of a leaf (<= 128 reflectors) from its Gram slabs S (row stride lds_, aligned range starting at a0)

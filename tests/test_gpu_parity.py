@@ -863,6 +863,7 @@ OPT_IN = [
     {"MPQR_ASHADOW": "0"},                         # far X = A2^T V from the fp32 matrix (converted + transposed while staged: round 3 default)
     {"MPQR_EXT_LEAVES": "1"},                      # block boundary: the in-block updates reach ONE leaf of the next block (round 2)
     {"MPQR_DEFER_FAR": "0"},                       # far update enqueued at the block's end instead of behind the next block's first gh_gram
+    {"MPQR_TPOLL": "0"},                           # the T stream follows the chain through an event instead of polling the word leaf_xt publishes
     {"MPQR_LEAF_MID": "0"},                        # a leaf's X on the side stream, Gram sum and T as two launches on the chain (before round 4's leaf_mid_kernel)
     {"MPQR_TAIL_LEAF": "0"},                       # the last <= 128 rows as 32-column leaves + merges (before round 4's leaf_tail_kernel)
     {"MPQR_LEAF_LA": "1"},                         # leaf-level look-ahead: every leaf's update of the rest of its block on the T stream

@@ -21,5 +21,6 @@ ts.sort(key=lambda t: t["ms_total"])
 b, md = ts[0], ts[len(ts) // 2]
 mt = h.metrics()
 print(f"{label:10s} {m}x{n} r={r}: best {b['ms_total']:.3f} median {md['ms_total']:.3f} ms  (factor {b['ms_factor']:.3f} panel {b['ms_panel']:.3f} q {b['ms_form_q']:.3f})"
+      f" far tn {b['ms_far_tn']:.2f} nn {b['ms_far_nn']:.2f} wait {b['ms_chain_wait']:.2f}"
       f"  backward {mt['backward_error']:.2e} orth {mt['q_error_fro']:.2e} gh_leaves {b['n_gh_leaves']}", flush=True)
 h.close()

@@ -19,11 +19,13 @@ int main() {
     uint32_t* d; CK(hipMalloc(&d, nwg * 8));
     std::vector<uint32_t> h(2 * nwg);
     const uint32_t pats[] = {0xffffffffu, 0x7f7f7f7fu, 0x55555555u, 0x0000ffffu, 0x000000ffu, 0x1u};
-    for (int p = -1; p < 6; p++) {
+    for (int p = -1; p < 6 + 3; p++) {
         hipStream_t st;
         if (p < 0) { CK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking)); }
         else {
-            uint32_t mask[8]; for (int i = 0; i < 8; i++) mask[i] = pats[p];
+            uint32_t mask[8]; for (int i = 0; i < 8; i++) mask[i] = pats[p < 6 ? p : 0];
+            // word i = CU i of every shader engine?  rows 0..6 / 0..5 / 0..3 of the 8 CUs of each engine
+            if (p >= 6) { const int n = p == 6 ? 7 : p == 7 ? 6 : 4; for (int i = 0; i < 8; i++) mask[i] = i < n ? 0xffffffffu : 0u; }
             hipError_t e = hipExtStreamCreateWithCUMask(&st, 8, mask);
             if (e != hipSuccess) { printf("mask %08x: create failed: %s\n", pats[p], hipGetErrorString(e)); continue; }
         }
@@ -41,7 +43,8 @@ int main() {
             cus.insert((xcc << 16) | (se << 8) | (sh << 4) | cu); xccs.insert(xcc);
         }
         if (p < 0) printf("no mask      : %3zu distinct CUs on %zu XCCs, %.3f ms\n", cus.size(), xccs.size(), ms);
-        else printf("mask %08x: %3zu distinct CUs on %zu XCCs, %.3f ms\n", pats[p], cus.size(), xccs.size(), ms);
+        else if (p < 6) printf("mask %08x: %3zu distinct CUs on %zu XCCs, %.3f ms\n", pats[p], cus.size(), xccs.size(), ms);
+        else printf("CU rows 0..%d of every engine: %3zu distinct CUs on %zu XCCs, %.3f ms\n", (p == 6 ? 7 : p == 7 ? 6 : 4) - 1, cus.size(), xccs.size(), ms);
         CK(hipStreamDestroy(st));
     }
     return 0;
