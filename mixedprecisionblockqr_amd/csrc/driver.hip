@@ -1114,25 +1114,20 @@ int form_q(mpqr_handle_t h) {
     return MPQR_OK;
 }
 
-// the far-update stream: low priority, unmasked (restricting it to 1/2 .. 7/8 of the CUs made the step slower in rounds 2 and 3; only
-// masks that keep CUs on every XCC are honoured by the runtime at all: tools/probe_cumask.hip)
 hipError_t create_update_stream(hipStream_t* st, int prio) {
-    // MPQR_UPDATE_CU_MASK=0x........ (32-bit pattern, repeated over the 8 XCCs): experiment hook, re-measured in round 4
-    const char* e = getenv("MPQR_UPDATE_CU_MASK");
-    if (e && strlen(e) > 2 && e[0] == '0' && (e[1] == 'x' || e[1] == 'X')) {
+    // The far-update stream keeps off ONE of the 8 CUs of every shader engine (round 4): its GEMM workgroups hold a CU for ~85 us each, and
+    // with the last CU of every engine free the chain's small kernels start at once wherever the dispatcher sends them
+    // (16384^2: 35.9-36.1 -> 35.6 ms, two A/B pairs on one box; 6 / 5 / 4 of 8: 35.9 / 36.1 / 37.7; configs 3 and 5: no change).
+    // Mask layout (tools/probe_cumask.hip): word i of the 8 x 32-bit mask = CU i of all 32 shader engines (8 XCCs x 4), bit s = engine s.
+    // Rounds 2 and 3 repeated one 32-bit pattern over the 8 words, which selects ENGINES, not CUs -- the runtime ignores such masks
+    // unless every XCC keeps an engine, and leaving whole engines to the chain does not help it (0x0000ffff: 40.1 ms): that, not the idea,
+    // is what "CU masks do not help" measured.  MPQR_UPDATE_CU_ROWS=n (1..7) keeps n CUs per engine, 8: no mask (low-priority stream).
+    int n = 7;
+    if (const char* r = getenv("MPQR_UPDATE_CU_ROWS")) n = atoi(r);
+    if (n >= 1 && n < 8) {
         uint32_t mask[8];
-        const uint32_t pat = (uint32_t)strtoul(e, nullptr, 16);
-        for (int i = 0; i < 8; i++) mask[i] = pat;
+        for (int i = 0; i < 8; i++) mask[i] = i < n ? 0xffffffffu : 0u;
         if (hipExtStreamCreateWithCUMask(st, 8, mask) == hipSuccess) return hipSuccess;
-    }
-    // MPQR_UPDATE_CU_ROWS=N: the far stream may use CUs 0 .. N-1 of the 8 in EVERY shader engine (mask word i = CU i of all 32 engines)
-    if (const char* r = getenv("MPQR_UPDATE_CU_ROWS")) {
-        const int n = atoi(r);
-        if (n >= 1 && n < 8) {
-            uint32_t mask[8];
-            for (int i = 0; i < 8; i++) mask[i] = i < n ? 0xffffffffu : 0u;
-            if (hipExtStreamCreateWithCUMask(st, 8, mask) == hipSuccess) return hipSuccess;
-        }
     }
     return hipStreamCreateWithPriority(st, hipStreamNonBlocking, prio);
 }
