@@ -7,9 +7,16 @@ for r in rows:
     r['s'] = int(r['Start_Timestamp']); r['e'] = int(r['End_Timestamp'])
 rows.sort(key=lambda r: r['s'])
 ab = [i for i, r in enumerate(rows) if 'absmax' in r['Kernel_Name']]          # compute_scale opens every mpqr_factor
-lo = ab[-1]
-hi = next((i for i in range(lo, len(rows)) if 'lower_norm' in rows[i]['Kernel_Name'] or 'strip_r' in rows[i]['Kernel_Name'] or 'pack_factor' in rows[i]['Kernel_Name']), len(rows))
-run = rows[lo:hi]
+# the last run that is a whole factorisation (bench.py's stand-alone timings behind the steps also start with an absmax pass)
+bounds = ab + [len(rows)]
+run = None
+for a, b in reversed(list(zip(bounds, bounds[1:]))):
+    if sum(1 for r in rows[a:b] if 'gh_apply' in r['Kernel_Name']) >= 8:
+        hi = next((i for i in range(a, b) if 'lower_norm' in rows[i]['Kernel_Name'] or 'strip_r' in rows[i]['Kernel_Name']), b)
+        run = rows[a:hi]
+        break
+if run is None:
+    sys.exit("no factorisation found in the trace")
 # Q formation = everything behind the last gh_apply of the run (round 4: Q = I is set up at the START of the factorisation, the identity
 # kernels no longer mark the phase)
 last_apply = max(i for i, r in enumerate(run) if 'gh_apply' in r['Kernel_Name'])
