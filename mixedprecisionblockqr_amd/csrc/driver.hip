@@ -531,6 +531,14 @@ void apply_node(mpqr_handle_t h, const Node& nd, float* C, long ldc, int clo, in
     g3.M = Kw; g3.N = M1; g3.K = Kr;
     g3.col_lo = clo - clo_al; g3.alpha = 1.0f / in_scale; g3.in_scale = 1.f; g3.nsplit = 1;
     if (a_shadow) { g3.Ct = h->At + (long)clo_al * h->ldat + rlo; g3.ldct = h->ldat; g3.ct_scale = in_scale; }
+    {   // Far updates and Q formation stream their C tiles (and the fp16 shadow) once per launch, ~2 GB each: read and written with the
+        // non-temporal cache policy they leave the chain's working set (panel columns, V, X, T) in the caches.  16384^2: far nn
+        // 4.75 -> 4.57 ms, chain -0.2 ms, Q formation 8.0 -> 7.85 ms; 65536 x 8192: factorisation -0.7 ms (A/B pairs on one box).
+        // MPQR_NT_C: bit 0 far updates, bit 1 Q formation (A/B hook).
+        static const int nt_env = []() { const char* e = getenv("MPQR_NT_C"); return e ? atoi(e) : 3; }();
+        if ((nt_env & 1) && far) g3.nt_c = 1;
+        if ((nt_env & 2) && q_apply) g3.nt_c = 1;
+    }
     if (h->shadow && h->shadow_write && lane == 0 && !far) { g3.Ct = h->shadow + (long)clo_al * h->ldshadow + rlo; g3.ldct = h->ldshadow; g3.ct_scale = in_scale; }
     if (record) HIPQ(h, hipEventRecord(e2, st));
     if (f8) {

@@ -334,7 +334,7 @@ static void launch2(const GemmArgs& g, hipStream_t s) {
 // every wave transposes its 128 x 64 sub-tile through its own 16 KiB of the (now free) LDS ring -- 8-byte writes at
 // [column][row], XOR-swizzled 16-byte chunks -- and stores whole 256-byte column segments (16 lanes x 16 bytes; the
 // direct 8-byte stores of a first version cost the kernel 55 %).
-template <bool SH, typename ACC>
+template <bool SH, int NT, typename ACC>
 __device__ __forceinline__ void epilogue_sub_f32_dma(ACC (&acc)[4][2], char* smem, float* __restrict__ C, long ldc,
                                                      float alpha, int bm, int bn, int wave, int lane,
                                                      half_t* __restrict__ Ct = nullptr, long ldct = 0, float cts = 1.f) {
@@ -348,7 +348,7 @@ __device__ __forceinline__ void epilogue_sub_f32_dma(ACC (&acc)[4][2], char* sme
 #pragma unroll
         for (int q = 0; q < 4; q++)
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (long)q * ldc),
-                                             (__attribute__((address_space(3))) void*)(base + q * 1024), 16, 0, 0);
+                                             (__attribute__((address_space(3))) void*)(base + q * 1024), 16, 0, NT ? 2 : 0);
     };
     issue(0); issue(1); issue(2); issue(3);
     float* pbase = C + (long)(bm + wr * 128 + 4 * h) * ldc + bn + wn + r;
@@ -381,7 +381,7 @@ __device__ __forceinline__ void epilogue_sub_f32_dma(ACC (&acc)[4][2], char* sme
 #pragma unroll
                 for (int e = 0; e < 4; e++) {
                     const float v = oldv[j][q * 4 + e] - alpha * acc[i][j][8 * hf + q * 4 + e];
-                    p[(long)e * ldc] = v;
+                    if (NT) __builtin_nontemporal_store(v, &p[(long)e * ldc]); else p[(long)e * ldc] = v;
                     if (SH) acc[i][j][8 * hf + q * 4 + e] = v;
                 }
                 p += 8 * ldc;
@@ -410,7 +410,11 @@ __device__ __forceinline__ void epilogue_sub_f32_dma(ACC (&acc)[4][2], char* sme
         for (int it = 0; it < 16; it++) {
             const int col = it * 4 + (lane >> 4), ch = lane & 15;
             const uint4 v = *(const uint4*)(tb + col * 256 + ((ch ^ (col & 15)) << 4));
-            *(uint4*)(ct + (long)col * ldct + 8 * ch) = v;
+            if (NT) {
+                typedef unsigned u4v __attribute__((ext_vector_type(4)));
+                u4v vv; vv[0] = v.x; vv[1] = v.y; vv[2] = v.z; vv[3] = v.w;
+                __builtin_nontemporal_store(vv, (u4v*)(ct + (long)col * ldct + 8 * ch));
+            } else *(uint4*)(ct + (long)col * ldct + 8 * ch) = v;
         }
     }
 }
@@ -694,8 +698,13 @@ __global__ __launch_bounds__(512) void gemm6_f16_kernel(GemmArgs g, int tilesM, 
     if (EM == E_SUB_F32) {
         const bool full = DMA_EPI && bm + BM <= g.M && bn + BN <= g.N && bn >= g.col_lo;      // uniform over the workgroup
         if (full) {
-            if (g.Ct) epilogue_sub_f32_dma<true>(acc, g2_smem, (float*)g.C, g.ldc, alpha, bm, bn, wave, lane, g.Ct, g.ldct, g.ct_scale);
-            else epilogue_sub_f32_dma<false>(acc, g2_smem, (float*)g.C, g.ldc, alpha, bm, bn, wave, lane);
+            if (g.nt_c) {
+                if (g.Ct) epilogue_sub_f32_dma<true, 1>(acc, g2_smem, (float*)g.C, g.ldc, alpha, bm, bn, wave, lane, g.Ct, g.ldct, g.ct_scale);
+                else epilogue_sub_f32_dma<false, 1>(acc, g2_smem, (float*)g.C, g.ldc, alpha, bm, bn, wave, lane);
+            } else {
+                if (g.Ct) epilogue_sub_f32_dma<true, 0>(acc, g2_smem, (float*)g.C, g.ldc, alpha, bm, bn, wave, lane, g.Ct, g.ldct, g.ct_scale);
+                else epilogue_sub_f32_dma<false, 0>(acc, g2_smem, (float*)g.C, g.ldc, alpha, bm, bn, wave, lane);
+            }
         }
         else epilogue_sub_f32<4, 2>(acc, (float*)g.C, g.ldc, g.M, g.N, g.col_lo, alpha, bm + wm, bn + wn, r, h, g.Ct, g.ldct, g.ct_scale);
 #ifdef MPQR_KTRACE
