@@ -380,6 +380,8 @@ __global__ __launch_bounds__(S3_THREADS) void gh_solve3_kernel(LeafArgs a, const
     __shared__ double thr[GW];                            // rho thresholds GH_RHO_MIN ||a_j||^2
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // (round 4: swapping the roles of physical waves 1 and 3 -- wave 3 has one SIMD partner where waves 0-2 have two, if waves i, i + 4,
+    //  i + 8 share a SIMD -- changed nothing: 61.5 us alone either way)
     const int li = lane & 15, lk = lane >> 4;
     const int w = a.c1 - a.c0, off = a.c0 - a.cb;
     const int nb = (w + 15) / 16, ncol = 16 * nb;
