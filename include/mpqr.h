@@ -72,8 +72,10 @@ typedef struct mpqr_metrics {
 
 typedef struct mpqr_timings {
     float ms_total;       /* factor (+ form_q) on the device, HIP events                            */
-    float ms_factor;      /* panels + trailing updates                                              */
-    float ms_form_q;      /* backward accumulation of Q                                             */
+    float ms_factor;      /* copy-in + max|a| pass (and its host round trip), panels + trailing updates; on a matrix that needed
+                             the robust fallback: every pass, the stopped ones included (n_passes, restart_block)             */
+    float ms_form_q;      /* backward accumulation of Q behind the last pass (a speculative Q formation behind a pass that was
+                             then repaired is inside ms_factor's interval)                                                   */
     float ms_trailing;    /* sum over the far trailing updates (3 GEMM launches each)               */
     float ms_panel;       /* the panel chain timed on its own stream: leaves, in-block updates, T merges
                              (with look-ahead the far updates overlap it on the second stream)       */
