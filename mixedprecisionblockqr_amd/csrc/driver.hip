@@ -496,7 +496,8 @@ void apply_node(mpqr_handle_t h, const Node& nd, float* C, long ldc, int clo, in
     } else if (h->mid && lane == 0 && fuse_xt && st1 == st) {
         // flat schedule: X beside the leaf's Gram sum and T, one launch (kernels_panel.hip: leaf_mid_kernel); one workgroup per CU there
         const int gx = (M1 + 127) / 128;
-        while (g1.nsplit > 1 && gx * g1.nsplit > 176) g1.nsplit--;
+        static const int mid_wgs = []() { const char* e = getenv("MPQR_MID_WGS"); return e ? std::max(8, atoi(e)) : 128; }();   // tuning hook (48 / 64 / 96 / 128 / 176: 35.7 / 35.4 / 35.0 / 35.0 / 35.1-35.2 ms)
+        while (g1.nsplit > 1 && gx * g1.nsplit > mid_wgs) g1.nsplit--;
         const mpqr_handle_s::MidT& mt = *h->mid;
         launch_leaf_mid(g1, mt.Sp, mt.nslab, h->Sleaf, mt.sh, h->mid_counter, mt.a0, mt.c0, mt.c1, mt.T, mt.Th, mt.Tth, mt.ldt, mt.ld, st);
         h->mid = nullptr;                                   // consumed
@@ -1074,6 +1075,7 @@ static int form_q_one_shot(mpqr_handle_t h) {
     q.Bt = h->Vh + (long)rlo * h->ldvh + rt.a0; q.ldb = h->ldvh;
     q.C = h->dQ + (long)rlo * h->ldq + rlo; q.ldc = h->ldq;
     q.M = h->m - rlo; q.N = h->m - rlo; q.K = Kr; q.alpha = 1.f; q.in_scale = 1.f; q.nsplit = 1; q.tri = 2; q.eye_minus = 1;
+    { static const int nt_env = []() { const char* e = getenv("MPQR_NT_C"); return e ? atoi(e) : 3; }(); q.nt_c = (nt_env & 2) ? 1 : 0; }   // Q is written once: streamed
     gemm_dispatch(A_H16, E_STORE_F32, q, h->s0);
     if (rec) HIPQ(h, hipEventRecord(e3, h->s0));
     h->q_formed = true;

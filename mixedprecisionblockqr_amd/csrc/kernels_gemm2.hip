@@ -683,7 +683,8 @@ __global__ __launch_bounds__(512) void gemm6_f16_kernel(GemmArgs g, int tilesM, 
                             if (n0 + e < g.N) { ((half_t*)g.C)[o + e] = hv[e]; if (g.C2) g.C2[o + e] = lv[e]; }
                     }
                 } else if (EM == E_STORE_F32) {
-                    if (inner) *(F4*)((float*)g.C + o) = v;
+                    if (inner && g.nt_c) __builtin_nontemporal_store(v, (F4*)((float*)g.C + o));      // (a result nobody on the GPU reads again soon)
+                    else if (inner) *(F4*)((float*)g.C + o) = v;
                     else if (m < g.M) {
 #pragma unroll
                         for (int e = 0; e < 4; e++) if (n0 + e < g.N) ((float*)g.C)[o + e] = v[e];
