@@ -490,7 +490,7 @@ __global__ __launch_bounds__(512) void gemm6_f16_kernel(GemmArgs g, int tilesM, 
             else row0 = 64 * (gidx >> 2) + 32 * sub + 8 * (gidx & 3);
             const int rr = row0 + (lane >> 3);
             const int c = (lane & 7) ^ ((rr >> 1) & 7);
-            if (isA)
+            if (isA)        // (non-temporal loads for the shadow operand of the far X = A2^T V: no effect, round 4)
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(Ab + (long)(bm + rr) * g.lda + k + c * 8),
                                                  (__attribute__((address_space(3))) void*)(buf + row0 * ROWB), 16, 0, 0);
             else

@@ -76,7 +76,7 @@ struct GemmArgs {
     half_t* C2;          // E_STORE_H16 (256-wide kernels): also store the remainder  fp16(v - fp16(v))  here (same layout as C)
     const half_t* A2;    // ping-pong kernel: a second A operand (the lo parts) accumulated over the same Bt: C = (A + A2) Bt^T
     int eye_minus;       // E_STORE_F32 (256-wide kernel): store (m == n ? 1 : 0) - alpha*acc  (Q = I - W V^T in one product)
-    int nt_c;            // E_SUB_F32 (ping-pong kernel, LDS-DMA epilogue): C (and Ct) are streamed with the non-temporal cache policy
+    int nt_c;            // ping-pong kernel: C (and Ct) are streamed with the non-temporal cache policy (read-modify-write ring, fp32 stores)
 };
 // false: no 128-tile kernel for this (staging, epilogue) pair, or hi + lo operands requested (256-wide kernels only)
 bool launch_gemm_f16(AMode am, EMode em, const GemmArgs& g, hipStream_t s);
