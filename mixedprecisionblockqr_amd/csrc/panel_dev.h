@@ -10,7 +10,7 @@ extern __shared__ __attribute__((aligned(16))) char gh_smem[];   // dynamic LDS 
 // optional in-kernel phase timing (make EXTRA=-DMPQR_KTRACE): thread 0 of block 0 stamps s_memtime at phase
 // boundaries and prints the deltas for the first few launches of each kernel
 #ifdef MPQR_KTRACE
-static __device__ int g_ktrace_left[8] = {3, 3, 3, 3, 6, 3, 3, 3};
+static __device__ int g_ktrace_left[8] = {3, 3, 3, 3, 3, 3, 3, 3};
 #define KT_DECL long kt_[16]; int kn_ = 0; const bool kon_ = (threadIdx.x == 0 && blockIdx.x == 0)
 #define KT() do { if (kon_ && kn_ < 16) kt_[kn_++] = clock64(); } while (0)
 #define KT_DUMP(id, name) do { if (kon_ && atomicSub(&g_ktrace_left[id], 1) > 0) { printf("ktrace %s:", name); \

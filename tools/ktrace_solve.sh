@@ -3,7 +3,7 @@
 # builds a tracing copy of the library under /tmp and runs one 16384 x 2048 factorisation with it.  usage: bash tools/ktrace_solve.sh
 root=${GRAFT_REPO_ROOT:-/root/repo}
 rm -rf /tmp/kt && mkdir -p /tmp/kt && cp -r $root/mixedprecisionblockqr_amd $root/include /tmp/kt/ && rm -rf /tmp/kt/mixedprecisionblockqr_amd/csrc/build /tmp/kt/mixedprecisionblockqr_amd/libmpqr.so
-make -C /tmp/kt/mixedprecisionblockqr_amd/csrc -j16 EXTRA="-DMPQR_KTRACE $KT_EXTRA" > /tmp/kt/build.log 2>&1 || { tail -20 /tmp/kt/build.log; exit 1; }
+make -C /tmp/kt/mixedprecisionblockqr_amd/csrc -j16 EXTRA=-DMPQR_KTRACE > /tmp/kt/build.log 2>&1 || { tail -20 /tmp/kt/build.log; exit 1; }
 cd /tmp/kt && python3 - <<'PY'
 import mixedprecisionblockqr_amd as mp
 h = mp.Handle(0)
