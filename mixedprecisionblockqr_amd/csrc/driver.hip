@@ -888,6 +888,9 @@ int factor_block_flat(mpqr_handle_t h, int top, const std::vector<int>& leaves) 
             h->mid = mid_leaf ? &mid_desc : nullptr;
             const bool poll = mid_leaf && h->tpoll && h->tflag && h->hflag_dev && h->flag_words > 0;
             h->xt_pub = poll ? ++h->tseq : 0;                  // leaf_xt (behind the leaf's T in the chain stream) publishes this value
+            static const int dbg_nopub = []() { const char* e = getenv("MPQR_DBG_NOPUB"); return e ? atoi(e) : 0; }();   // test hook: the word is never
+            const bool swallow = poll && dbg_nopub;                                                                      // published -> the waiter must time out
+            if (swallow) h->xt_pub = -1;                       // (leaf_xt then stores -1: never >= a sequence number)
             apply_node(h, lf, h->Aeff, h->lda, lf.c1, own_end, true, h->a_scale, false);
             h->op1_stream = nullptr;
             if (h->mid || h->xt_pub) { h->mid = nullptr; h->xt_pub = 0; h->dispatch_error = true; }   // (apply_node took another path than predicted)

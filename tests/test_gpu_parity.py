@@ -895,6 +895,21 @@ def test_tall_matrix_one_shot_q_formation():
 
 
 @pytest.mark.gpu
+def test_t_stream_wait_gives_up_instead_of_hanging():
+    """The T stream follows the chain by polling a word that leaf_xt publishes (wait_flag_kernel).  Exit condition: should the word
+    never arrive (MPQR_DBG_NOPUB=1 makes leaf_xt publish -1), every waiter gives up after 0.2 s and raises a mapped host word;
+    mpqr_factor then returns an error instead of results built on a T stream that ran ahead of the chain -- and nothing hangs."""
+    import os, subprocess, sys, time
+    child = os.path.join(os.path.dirname(os.path.abspath(__file__)), "optin_child.py")
+    env = dict(os.environ); env["MPQR_DBG_NOPUB"] = "1"
+    t0 = time.time()
+    p = subprocess.run([sys.executable, child, "1024", "1024", "128"], env=env, capture_output=True, text=True, timeout=120)
+    assert p.returncode != 0, p.stdout[-500:]
+    assert "timed out" in (p.stderr + p.stdout), p.stderr[-1500:]
+    assert time.time() - t0 < 60
+
+
+@pytest.mark.gpu
 def test_opt_in_schedules_and_kernels():
     import json, os, subprocess, sys
     child = os.path.join(os.path.dirname(os.path.abspath(__file__)), "optin_child.py")
