@@ -9,8 +9,9 @@ import mixedprecisionblockqr_amd as mp
 
 label, m, n, r = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4])
 reps = int(sys.argv[5]) if len(sys.argv) > 5 else 7
+ob = int(os.environ.get("AB_OUTER_BLOCK", "0"))             # outer block (0: the library's choice)
 h = mp.Handle(0)
-h.plan(m, n, r)
+h.plan(m, n, r, outer_block=ob) if ob else h.plan(m, n, r)
 h.generate(1234)
 ts = []
 for i in range(reps + 2):
