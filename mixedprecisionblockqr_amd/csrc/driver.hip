@@ -112,6 +112,9 @@ struct mpqr_handle_s {
     struct MidT { const float* Sp; int nslab; int sh, a0, c0, c1; float* T; half_t* Th; half_t* Tth; int ldt, ld; };
     const MidT* mid = nullptr;    // set by the flat schedule around one apply_node call: its X GEMM and the leaf's T go out as ONE launch
     bool leaf_mid = true;         // MPQR_LEAF_MID=0: X on the side stream, Gram sum and T as two launches on the chain (before round 4)
+    bool v_clean = false;         // the reflector stores (Vh, Vt, vdiag) need no clearing before the next factorisation of this plan: they are
+                                  // zero (fresh plan) or hold the reflectors of a clean single-pass factorisation of the same plan, every one of
+                                  // which the next factorisation rewrites before it reads it
     int* tflag = nullptr;         // device word the chain publishes its progress in (leaf_xt_kernel), polled by the T stream (wait_flag_kernel)
     int tseq = 0, xt_pub = 0;     // last published value; value the next leaf_xt launch of apply_node is to publish (0: none)
     bool tpoll = true;            // MPQR_TPOLL=0: the T stream follows the chain through an event (costs the chain ~4 us per leaf)
@@ -1482,6 +1485,7 @@ static int plan_common(mpqr_handle_t h, int m, int n, int r, const mpqr_opts* op
     HIPCHK(h, hipMemsetAsync(h->dA, 0, (size_t)h->m_pad * h->lda * sizeof(float), h->s0));
     HIPCHK(h, hipMemsetAsync(h->dQ, 0, (size_t)h->m_pad * h->ldq * sizeof(float), h->s0));
     if ((rc = clear_reflectors(h))) return rc;
+    h->v_clean = true;
     HIPCHK(h, hipStreamSynchronize(h->s0));
     h->Aeff = h->dA;
     h->planned = true;
@@ -1560,7 +1564,13 @@ static int run_block_loop(mpqr_handle_t h, int start = 0) {
         if (!h->copied_in)                                  // (a later pass from block 0; the first one found the copy made by mpqr_factor)
             HIPCHK(h, hipMemcpyAsync(h->dA, h->dA0, (size_t)h->m_pad * h->lda * sizeof(float), hipMemcpyDeviceToDevice, h->s0));
         h->copied_in = false;
-        if ((rc = clear_reflectors(h))) return rc;
+        // 1.1 GB of memsets (0.25-0.3 ms at 16384^2) only when the stores may hold something a kernel could read before this pass has
+        // rewritten it: after a flagged / restarted / robust pass, a stage call or a distributed factorisation.  A clean factorisation
+        // leaves finite reflectors exactly where this one writes its own before any kernel reads them; what no kernel ever writes (the
+        // entries above the diagonal, the pads) is still zero from the plan.  The only stale values a kernel can meet are the next
+        // leaf's reflectors inside a 64-aligned widened range of a SHORT leaf, where T is zero-padded (finite x 0).
+        if (!h->v_clean) { if ((rc = clear_reflectors(h))) return rc; }
+        h->v_clean = false;                                 // (mpqr_factor declares the stores clean again after a clean single pass)
     } else {
         Range rg("mpqr:restart_replay");
         const int cs = h->nodes[h->tops[start]].c0;
@@ -1780,6 +1790,7 @@ int mpqr_factor(mpqr_handle_t h) {
     h->n_gh_leaves = gh_total;
     h->n_robust_leaves = 0;
     for (char c : h->leaf_robust) h->n_robust_leaves += c ? 1 : 0;
+    h->v_clean = h->n_passes == 1 && !h->robust && h->n_robust_leaves == 0 && h->world == 1;
     if (dispatch_failed(h)) return fail(h, MPQR_ERR_STATE, "a GEMM of the factorisation found no kernel for its operand staging / epilogue, or an enqueue call failed (stderr)");
     return MPQR_OK;
 }
@@ -2225,7 +2236,7 @@ static int stage_load(mpqr_handle_t h, const float* A, int m, int n, int r, int 
     launch_unpack_factor(h->dstage, m, n, c0, c1, h->dA, h->lda, h->vdiag, h->Vh, h->ldvh, h->Vt, h->ldvt, h->s0);
     if (h->Vf && c1 > c0) launch_extract_vf(h->dA, h->lda, h->vdiag, h->Vf, h->n_pad, h->m, c0, c1, h->s0);
     HIPCHK(h, hipStreamSynchronize(h->s0));
-    h->Aeff = h->dA; h->v8_node = -1; h->q_inited = false;
+    h->Aeff = h->dA; h->v8_node = -1; h->q_inited = false; h->v_clean = false;       // (the stores now hold the caller's reflectors c0..c1)
     h->factored = false; h->q_formed = false; h->have_input = false;
     return MPQR_OK;
 }
@@ -2560,6 +2571,7 @@ int mpqr_dist_begin(mpqr_handle_t h, float absmax) {
     for (int b = 0; b < h->flag_words; b++) __atomic_store_n(h->hflag_host + b, 0, __ATOMIC_RELAXED);   // (the previous factorisation was synchronised: mpqr_dist_flags)
     h->cur_block = 0; h->watch_flags = false;
     if ((rc = clear_reflectors(h))) return rc;
+    h->v_clean = false;                                     // (this rank's stores will hold received panels)
     h->factored = false; h->q_formed = false;
     return MPQR_OK;
 }
