@@ -105,6 +105,8 @@ struct mpqr_handle_s {
     float* Xt2 = nullptr;  half_t* Yt2 = nullptr; size_t xt2_elems = 0;   // scratch of the deferred in-block updates (apply_node lane 2, T stream)
     int pre_leaves = 0;                 // flat block: its first pre_leaves leaves were brought up to date by the previous block (run_block_loop)
     hipEvent_t ev_def = nullptr;        // chain -> T stream: a pre-updated leaf's reflectors and T are complete (deferred update may start)
+    hipEvent_t ev_rest = nullptr;       // T stream -> chain: a leaf's deferred update of the rest of its block is complete (leaf-level look-ahead)
+    bool rest_pending = false;          // ... and the chain stream has not waited for the last one yet
     std::vector<hipEvent_t> ev_node, ev_cols;          // per top-level node: reflectors ready / columns up to date
     float* S = nullptr;    size_t s_elems = 0;
     float* Sleaf = nullptr;       // 128 x 128 Gram of a leaf's fp16 reflectors (chain stream; S itself is used by the T stream)
@@ -843,11 +845,16 @@ int factor_block_flat(mpqr_handle_t h, int top, const std::vector<int>& leaves) 
         // order (its X GEMM runs there), so the chain first meets the far update's columns one leaf later than the block boundary.
         const int P = std::min<int>(h->pre_leaves, (int)leaves.size());
         const int cpre = P > 0 ? h->nodes[leaves[P - 1]].c1 : lf.c1;
-        // Leaf-level look-ahead (opt-in, MPQR_LEAF_LA=1; measured slower): on the chain a leaf updates only the NEXT
+        // Leaf-level look-ahead (MPQR_LEAF_LA; round 3 measured it slower with its two events per leaf): on the chain a leaf updates only the NEXT
         // leaf's columns (what the next gh_gram reads); its update of everything else (`rest`) runs on the T stream (lane 2) as soon
         // as T_j exists, i.e. beside the next leaf's gh_solve.  Order: the T stream runs X_urgent(j), rest(j), X_urgent(j+1), ...
         // so rest(j) has written the columns X_urgent(j+1) reads, and the chain's own update of them waits for that X (ev_x).
-        static const int leaf_la = []() { const char* e = getenv("MPQR_LEAF_LA"); return e ? atoi(e) : 0; }();
+        // Round 4: with the one-launch middle and the polling T stream no event is left on the chain for it but one wait for the previous
+        // leaf's rest (long finished): on for leaves with >= 20480 rows, where the update it moves off the chain is large enough --
+        // 24576 x 8192: 29.4 -> 28.7 ms, 32768 x 4096: 18.8 -> 18.3, 49152 x 4096: 32.2 -> 30.8, 65536 x 8192: factorisation 44.2 -> 41.8;
+        // 16384^2: 34.8 either way, 2048^2: 2.95 -> 3.01 (MPQR_LEAF_LA=0 / 1 forces it off / on for every leaf; same bits either way).
+        static const int leaf_la_env = []() { const char* e = getenv("MPQR_LEAF_LA"); return e ? atoi(e) : -1; }();
+        const int leaf_la = leaf_la_env >= 0 ? leaf_la_env : (h->m - lf.c0 >= 20480 ? 1 : 0);
         const int next_c1 = j + 1 < leaves.size() ? h->nodes[leaves[j + 1]].c1 : lf.c1 + 128;
         const bool lane2_ok = h->Xt2 != nullptr && h->Yt2 != nullptr;      // (allocated with opts.lookahead only: ADVICE round 3)
         const bool la_split = tq && lane2_ok && leaf_la && lf.c1 < upd_end && std::min(next_c1, upd_end) < upd_end;
@@ -869,7 +876,7 @@ int factor_block_flat(mpqr_handle_t h, int top, const std::vector<int>& leaves) 
             // side stream for X, no hand-offs around it; the T stream then follows the chain AFTER the update (it only builds the previous
             // leaf's column block of T).  Not for a leaf whose X still waits for the previous block's far update: there the chain goes on
             // with T_j while the side stream waits.
-            mid_leaf = h->leaf_mid && tq && !la_split && !far_wait_pending && lf.ldt == 128 && lf.c1 < own_end &&
+            mid_leaf = h->leaf_mid && tq && (!la_split || h->tpoll) && !far_wait_pending && lf.ldt == 128 && lf.c1 < own_end &&
                        own_end - rdown(lf.c1, 32) <= 4096 && !h->shadow && !h->Vf && h->opts.precision != MPQR_PREC_FP32;
             if (mid_leaf) {
                 mid_desc = mpqr_handle_s::MidT{h->Sp, gh_partials, gh_sh, lf.a0, lf.c0, lf.c1, h->Tf + lf.toff, h->Th + lf.toff, h->Tth + lf.toff, lf.ldt, ld};
@@ -884,7 +891,16 @@ int factor_block_flat(mpqr_handle_t h, int top, const std::vector<int>& leaves) 
                               h->Tth + lf.toff, lf.ldt, h->s0, ld);
             }
         }
-        if (have_rest && la_split) HIPQ(h, hipEventRecord(h->ev_def, h->s0));   // T_j and V_j are complete here: the rest may start beside the urgent part
+        // leaf-level look-ahead with the one-launch middle: T_j comes out of the urgent apply below, and the rest (T stream) starts behind
+        // the word its leaf_xt publishes -- no event on the chain stream for it
+        const bool la_mid = la_split && mid_leaf;
+        if (have_rest && la_split && !la_mid) HIPQ(h, hipEventRecord(h->ev_def, h->s0));   // T_j and V_j are complete here: the rest may start beside the urgent part
+        if (h->rest_pending) {
+            // the previous leaf's deferred update (T stream) wrote columns this leaf's X reads and the next gh_gram needs: it finished
+            // ~100 us ago (it ran beside this leaf's gh_solve), the wait only orders the streams
+            HIPQ(h, hipStreamWaitEvent(h->s0, h->ev_rest, 0));
+            h->rest_pending = false;
+        }
         if (lf.c1 < own_end) {
             Range rg("mpqr:in_block_update");
             h->op1_stream = (tq && !mid_leaf) ? h->sT : nullptr;
@@ -904,8 +920,10 @@ int factor_block_flat(mpqr_handle_t h, int top, const std::vector<int>& leaves) 
         }
         if (have_rest) {                                   // the rest, on the T stream
             Range rg("mpqr:in_block_update_deferred");
-            if (!la_split) HIPQ(h, hipEventRecord(h->ev_def, h->s0));
-            HIPQ(h, hipStreamWaitEvent(h->sT, h->ev_def, 0));
+            if (!la_mid) {
+                if (!la_split) HIPQ(h, hipEventRecord(h->ev_def, h->s0));
+                HIPQ(h, hipStreamWaitEvent(h->sT, h->ev_def, 0));
+            }                                               // (la_mid: the T stream is already behind wait_flag_kernel for this leaf)
             int lo = own_end;
             if (pre_split && lo < cpre) {                   // columns the previous block already brought up to date: no far update to wait for
                 apply_node(h, lf, h->Aeff, h->lda, lo, cpre, true, h->a_scale, false, 2);
@@ -913,12 +931,14 @@ int factor_block_flat(mpqr_handle_t h, int top, const std::vector<int>& leaves) 
             }
             if (pre_split && h->wait_after_first_leaf) HIPQ(h, hipStreamWaitEvent(h->sT, h->wait_after_first_leaf, 0));   // (kept: the last pre-updated leaf waits too)
             apply_node(h, lf, h->Aeff, h->lda, lo, upd_end, true, h->a_scale, false, 2);
+            if (la_mid) { HIPQ(h, hipEventRecord(h->ev_rest, h->sT)); h->rest_pending = true; }
         }
         // background, behind this leaf's X GEMM in the side stream's queue: the PREVIOUS leaf's column block of T
         if (prev_o >= 0) t_column_block(prev, prev_o);
         prev = lf; prev_o = o;
         if (!tq) { t_column_block(prev, prev_o); prev_o = -1; }          // single stream: nothing to defer
     }
+    if (h->rest_pending) { HIPQ(h, hipStreamWaitEvent(h->s0, h->ev_rest, 0)); h->rest_pending = false; }
     if (prev_o >= 0) {                                     // the last leaf's column block needs its T (chain stream)
         if (tq) t_stream_follows_chain(h);
         t_column_block(prev, prev_o);
@@ -1204,6 +1224,7 @@ int mpqr_create(mpqr_handle_t* out, int device) {
         hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&h->ev_x, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&h->ev_def, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&h->ev_rest, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&h->ev_dist_chain, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&h->ev_dist_far, hipEventDisableTiming) != hipSuccess) {
         g_create_err = "hipSetDevice/hipStreamCreate failed";
@@ -1237,6 +1258,7 @@ int mpqr_destroy(mpqr_handle_t h) {
     if (h->sD) (void)hipStreamDestroy(h->sD);
     if (h->ev_x) (void)hipEventDestroy(h->ev_x);
     if (h->ev_def) (void)hipEventDestroy(h->ev_def);
+    if (h->ev_rest) (void)hipEventDestroy(h->ev_rest);
     if (h->ev_dist_chain) (void)hipEventDestroy(h->ev_dist_chain);
     if (h->ev_dist_far) (void)hipEventDestroy(h->ev_dist_far);
     (void)hipStreamDestroy(h->s0);
