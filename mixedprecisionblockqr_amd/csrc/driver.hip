@@ -1430,7 +1430,7 @@ static int plan_common(mpqr_handle_t h, int m, int n, int r, const mpqr_opts* op
         }
     }
     if ((rc = dalloc(h, &h->S, h->s_elems))) return rc;
-    if ((rc = dalloc(h, &h->Sleaf, (size_t)128 * 128))) return rc;
+    if ((rc = dalloc(h, &h->Sleaf, (size_t)128 * 128 * LEAF_MID_MAX_GROUPS))) return rc;
     if ((rc = dalloc(h, &h->mid_counter, (size_t)1))) return rc;
     HIPCHK(h, hipMemsetAsync(h->mid_counter, 0, sizeof(int), h->s0));
     if ((rc = dalloc(h, &h->tflag, (size_t)1))) return rc;

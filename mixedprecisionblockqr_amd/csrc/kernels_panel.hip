@@ -893,7 +893,10 @@ __device__ __forceinline__ void t_panel_body(const float* __restrict__ S, int ns
         for (int q = 0; q < NQ; q++) {
             const int e = tid + NT * q;
             const int i = min(e >> 7, w - 1), j = min(e & 127, w - 1);
-            for (int sl = 1; sl < nslab; sl++) sv[q] += S[(long)sl * slab_stride + (long)(off + i) * lds_ + off + j];
+            for (int sl = 1; sl < nslab; sl++) {
+                const float* p = &S[(long)sl * slab_stride + (long)(off + i) * lds_ + off + j];
+                sv[q] += SC1 ? __builtin_bit_cast(float, __hip_atomic_load((const unsigned*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) : *p;
+            }
         }
     }
 #pragma unroll
@@ -1061,7 +1064,7 @@ void launch_t_leaf(const float* S, int nslab, long slab_stride, int lds_, int a0
 // two cross-stream hand-offs on the critical path (chain -> side stream ~7 us, side stream -> chain ~10-14 us: kernel trace, and
 // tools/probe_graph_handoff.hip); as launches on one stream they serialise.  Here they are ONE grid: the first MID_RB workgroups sum the
 // partials, the others compute GEMM tiles (gemm_body.h); the reduce workgroups sum (four consecutive entries per lane, the same four interleaved chains per
-// entry as gh_reduce_f32_kernel, so S is bit-identical to it) and the one whose arrival is last runs the T kernel's body on 256 threads.
+// entry as gh_reduce_f32_kernel, so S is bit-identical to it for leaves of < 32768 rows; taller ones cut the partials into up to four ranges) and the one whose arrival is last runs the T kernel's body on 256 threads.
 // Hand-off inside the launch (MI355X_MICROARCH.md, inter-workgroup visibility, first row of the hand-off table): S is stored sc1, every
 // storing wave waits vmcnt(0), one lane per workgroup adds to an agent-scope counter behind a workgroup barrier, the workgroup whose add
 // returned MID_RB - 1 loads S with sc1 loads behind another barrier.  Nothing spins: no residency requirement.  One workgroup per CU (LDS).
@@ -1069,12 +1072,14 @@ constexpr int MID_RB = 64;
 struct LeafMidArgs {
     GemmArgs g; int gx, nX;                                  // X tiles along M; GEMM workgroups = gx * nsplit
     const float* Sp; int nslab; float* S; int sh;            // partials -> S (128 x 128 window); T reads it from (sh, sh)
+    int ngrp;                                                // the partials are cut into ngrp ranges (64 workgroups each -> S + grp * 16384), summed by the T body
     int* counter;                                            // zero between launches (the last arriver resets it)
     int a0, c0, c1; float* T; half_t* Th; half_t* Tth; int ldt, ld;
 };
 __global__ __launch_bounds__(256) void leaf_mid_kernel(LeafMidArgs m) {
-    if ((int)blockIdx.x >= MID_RB) {                         // (the reduce workgroups come first in the grid: theirs is the longer path)
-        const int b = (int)blockIdx.x - MID_RB;
+    const int nrb = MID_RB * m.ngrp;
+    if ((int)blockIdx.x >= nrb) {                            // (the reduce workgroups come first in the grid: theirs is the longer path)
+        const int b = (int)blockIdx.x - nrb;
         gemm_f16_body<A_F32T, E_STORE_F32>(m.g, (half_t*)gh_smem, b % m.gx, 0, b / m.gx);
         return;
     }
@@ -1082,14 +1087,16 @@ __global__ __launch_bounds__(256) void leaf_mid_kernel(LeafMidArgs m) {
     __shared__ float tdiag[TP];
     __shared__ int is_last;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int e = ((int)blockIdx.x * 64 + lane) * 4;          // four consecutive entries of one row of the window
+    const int grp = (int)blockIdx.x / MID_RB;                // tall leaves: gh_apply leaves rows / 64 partials (1026 at 65536 rows, 67 MB) -- cut into
+    const int q_lo = (int)((long)m.nslab * grp / m.ngrp), q_hi = (int)((long)m.nslab * (grp + 1) / m.ngrp);   // ranges of <= ~256
+    const int e = (((int)blockIdx.x % MID_RB) * 64 + lane) * 4;   // four consecutive entries of one row of the window
     const bool act = ((e >> 7) >> 5) <= ((e & 127) >> 5);     // the partials hold the 10 upper 32 x 32 tiles only; T reads j >= i
     float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
     if (act) {
         float4 s0 = s, s1 = s, s2 = s, s3 = s;
         auto add = [](float4& a, const float4& b) { a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w; };
-        int q = wave;
-        for (; q + 60 < m.nslab; q += 64) {
+        int q = q_lo + wave;
+        for (; q + 60 < q_hi; q += 64) {
             float4 v[16];
 #pragma unroll
             for (int u = 0; u < 16; u++) v[u] = *(const float4*)&m.Sp[(long)(q + 4 * u) * (GW * GW) + e];
@@ -1099,9 +1106,9 @@ __global__ __launch_bounds__(256) void leaf_mid_kernel(LeafMidArgs m) {
         {
             float4 v[16];
 #pragma unroll
-            for (int u = 0; u < 16; u++) v[u] = *(const float4*)&m.Sp[(long)min(q + 4 * u, m.nslab - 1) * (GW * GW) + e];
+            for (int u = 0; u < 16; u++) v[u] = *(const float4*)&m.Sp[(long)min(q + 4 * u, q_hi - 1) * (GW * GW) + e];
 #pragma unroll
-            for (int u = 0; u < 16; u++) if (q + 4 * u >= m.nslab) v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int u = 0; u < 16; u++) if (q + 4 * u >= q_hi) v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
             for (int u = 0; u < 16; u += 4) { add(s0, v[u]); add(s1, v[u + 1]); add(s2, v[u + 2]); add(s3, v[u + 3]); }
         }
@@ -1115,15 +1122,15 @@ __global__ __launch_bounds__(256) void leaf_mid_kernel(LeafMidArgs m) {
         const float r4[4] = {(p0.x + p1.x) + (p2.x + p3.x), (p0.y + p1.y) + (p2.y + p3.y), (p0.z + p1.z) + (p2.z + p3.z), (p0.w + p1.w) + (p2.w + p3.w)};
 #pragma unroll
         for (int c = 0; c < 4; c++)
-            __hip_atomic_store((unsigned*)&m.S[e + c], __builtin_bit_cast(unsigned, r4[c]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store((unsigned*)&m.S[(long)grp * (GW * GW) + e + c], __builtin_bit_cast(unsigned, r4[c]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the stores have left before this workgroup signals
     }
     __syncthreads();
-    if (tid == 0) is_last = __hip_atomic_fetch_add(m.counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == MID_RB - 1;
+    if (tid == 0) is_last = __hip_atomic_fetch_add(m.counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == nrb - 1;
     __syncthreads();
     if (!is_last) return;
     if (tid == 0) __hip_atomic_store(m.counter, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    t_panel_body<256, true>(m.S + (long)m.sh * 128 + m.sh, 1, 0, 128, m.a0, m.c0, m.c1, m.T, m.Th, m.Tth, m.ldt, m.ld, (float*)gh_smem, tdiag);
+    t_panel_body<256, true>(m.S + (long)m.sh * 128 + m.sh, m.ngrp, GW * GW, 128, m.a0, m.c0, m.c1, m.T, m.Th, m.Tth, m.ldt, m.ld, (float*)gh_smem, tdiag);
 }
 void launch_leaf_mid(const GemmArgs& g1, const float* Sp, int nslab, float* S, int sh, int* counter, int a0, int c0, int c1,
                      float* T, half_t* Th, half_t* Tth, int ldt, int ld, hipStream_t s) {
@@ -1136,8 +1143,9 @@ void launch_leaf_mid(const GemmArgs& g1, const float* Sp, int nslab, float* S, i
     if (m.g.nslab_in < 1) m.g.nslab_in = 1;
     m.gx = (g1.M + gemm128::BM - 1) / gemm128::BM; m.nX = m.gx * m.g.nsplit;
     m.Sp = Sp; m.nslab = nslab; m.S = S; m.sh = sh; m.counter = counter;
+    m.ngrp = std::max(1, std::min(LEAF_MID_MAX_GROUPS, nslab / 256));        // (S holds LEAF_MID_MAX_GROUPS windows)
     m.a0 = a0; m.c0 = c0; m.c1 = c1; m.T = T; m.Th = Th; m.Tth = Tth; m.ldt = ldt; m.ld = ld <= 0 ? ldt : ld;
-    hipLaunchKernelGGL(leaf_mid_kernel, dim3(m.nX + MID_RB), dim3(256), LDS, s, m);
+    hipLaunchKernelGGL(leaf_mid_kernel, dim3(m.nX + MID_RB * m.ngrp), dim3(256), LDS, s, m);
 }
 
 // fp16 copies of one column block of a block-level T: Th[0:rows, c:c+w] = T[0:rows, c:c+w], Tth[c:c+w, 0:rows] = its transpose

@@ -150,6 +150,7 @@ void launch_gh_reduce_f32(const float* Sp, int nslab, float* S, hipStream_t s);
 // One launch for the middle of a Gram-Householder leaf (kernels_panel.hip, leaf_mid_kernel): the split-K GEMM g1 (A_F32T, E_STORE_F32,
 // N <= 128) beside the sum of the nslab partial Gram matrices Sp -> S and the leaf's T from it (arguments as launch_t_leaf, S read at
 // (sh, sh) of its 128 x 128 window).  counter: one device int, zero between launches.
+constexpr int LEAF_MID_MAX_GROUPS = 4;      // S must hold this many 128 x 128 windows
 void launch_leaf_mid(const GemmArgs& g1, const float* Sp, int nslab, float* S, int sh, int* counter, int a0, int c0, int c1,
                      float* T, half_t* Th, half_t* Tth, int ldt, int ld, hipStream_t s);
 void launch_t_leaf(const float* S, int nslab, long slab_stride, int lds_, int a0, int c0, int c1,
