@@ -406,32 +406,45 @@ __global__ __launch_bounds__(256) void gh_reduce_kernel(const double* __restrict
 typedef half_t half8p __attribute__((ext_vector_type(8)));
 // partial Gram of the fp16 reflectors held in Ts ([128 columns][72]: the 64 rows of this workgroup, k contiguous):
 // upper 32 x 32 tiles of Ts Ts^T on v_mfma_f32_32x32x16_f16, written to Sp (fp32, 128 x 128, window coordinates)
-__device__ __forceinline__ void gh_partial_gram(const half_t* Ts, float* __restrict__ Sp, int lane, int wave) {
+// ga[0..2]: this wave's (up to three) 32 x 32 upper tiles of the partial Gram matrix; add = accumulate over 64 more rows in Ts
+__device__ __forceinline__ void gh_partial_gram_add(const half_t* Ts, floatx16p (&ga)[3], int lane, int wave) {
     const int r = lane & 31, h = lane >> 5;
     int t = 0;
 #pragma unroll
     for (int ti = 0; ti < 4; ti++)
 #pragma unroll
         for (int tj = ti; tj < 4; tj++, t++) {
-            if ((t & 3) != wave) continue;               // 10 upper tiles dealt to the 4 waves
-            floatx16p acc;
-#pragma unroll
-            for (int e = 0; e < 16; e++) acc[e] = 0.f;
+            if ((t & 3) != wave) continue;               // 10 upper tiles dealt to the 4 waves: tile t is this wave's number t / 4
 #pragma unroll
             for (int ks = 0; ks < 4; ks++) {
                 const half8p av = *(const half8p*)&Ts[(ti * 32 + r) * 72 + ks * 16 + 8 * h];
                 const half8p bv = *(const half8p*)&Ts[(tj * 32 + r) * 72 + ks * 16 + 8 * h];
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, bv, acc, 0, 0, 0);
+                ga[t >> 2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, bv, ga[t >> 2], 0, 0, 0);
             }
-#pragma unroll
-            for (int e = 0; e < 16; e++)
-                Sp[(ti * 32 + (e & 3) + 8 * (e >> 2) + 4 * h) * GW + tj * 32 + r] = acc[e];
         }
 }
-
-// blockIdx < nlow: rows c1 + 64 b .. of A_low (apply, and the partial Gram when Sp is given);  blockIdx >= nlow:
-// 64 rows of the TOP block (final already, written by gh_solve): partial Gram only.
-__global__ __launch_bounds__(256) void gh_apply_kernel(LeafArgs a, const float* __restrict__ Cv, float* __restrict__ Sp, int nlow) {
+__device__ __forceinline__ void gh_partial_gram_store(const floatx16p (&ga)[3], float* __restrict__ Sp, int lane, int wave) {
+    const int r = lane & 31, h = lane >> 5;
+    int t = 0;
+#pragma unroll
+    for (int ti = 0; ti < 4; ti++)
+#pragma unroll
+        for (int tj = ti; tj < 4; tj++, t++) {
+            if ((t & 3) != wave) continue;
+#pragma unroll
+            for (int e = 0; e < 16; e++) Sp[(ti * 32 + (e & 3) + 8 * (e >> 2) + 4 * h) * GW + tj * 32 + r] = ga[t >> 2][e];
+        }
+}
+__device__ __forceinline__ void gh_partial_gram(const half_t* Ts, float* __restrict__ Sp, int lane, int wave) {
+    floatx16p ga[3];
+#pragma unroll
+    for (int q = 0; q < 3; q++)
+#pragma unroll
+        for (int e = 0; e < 16; e++) ga[q][e] = 0.f;
+    gh_partial_gram_add(Ts, ga, lane, wave);
+    gh_partial_gram_store(ga, Sp, lane, wave);
+}
+__global__ __launch_bounds__(256) void gh_apply_kernel(LeafArgs a, const float* __restrict__ Cv, float* __restrict__ Sp, int nlow, int iters) {
     float* As = (float*)gh_smem;                         // [64][129] = 8256 floats
     float* Cs = (float*)gh_smem + 8256;                  // [128][GH_TS], 16-B aligned
     half_t* Ts = (half_t*)gh_smem;                       // [128][72] halves, reuses the As region after the MFMAs
@@ -449,13 +462,23 @@ __global__ __launch_bounds__(256) void gh_apply_kernel(LeafArgs a, const float* 
         gh_partial_gram(Ts, Sp + (long)blockIdx.x * (GW * GW), lane, wave);
         return;
     }
-    const int row0 = a.c1 + blockIdx.x * 64;
     // C arrives in window coordinates, zero outside the leaf and below the diagonal
 #pragma unroll
     for (int q = 0; q < GW * GW / 4 / 256; q++) {
         const int e4 = tid + 256 * q, wi = e4 >> 5, wk = (e4 & 31) * 4;
         *(float4*)&Cs[wi * GH_TS + wk] = *(const float4*)&Cv[wi * GW + wk];
     }
+    // `iters` blocks of 64 rows per workgroup (tall leaves: gh_apply_iters): C is staged once, and the partial Gram matrix of the rounded
+    // reflectors accumulates over the blocks -- a quarter of the 67 MB of partials a 65536-row leaf would write (and leaf_mid would read)
+    floatx16p ga[3];
+#pragma unroll
+    for (int q = 0; q < 3; q++)
+#pragma unroll
+        for (int e = 0; e < 16; e++) ga[q][e] = 0.f;
+    for (int it = 0; it < iters; it++) {
+    const int row0 = a.c1 + ((int)blockIdx.x * iters + it) * 64;
+    if (row0 >= a.mrows) break;
+    if (it) __syncthreads();                               // the previous block's V^T rows have been read from Ts (= As)
     float4 av[8];                                          // (loads first, as in gh_gram: eight serialised latencies otherwise)
 #pragma unroll
     for (int i = 0; i < 8; i++) {
@@ -509,7 +532,7 @@ __global__ __launch_bounds__(256) void gh_apply_kernel(LeafArgs a, const float* 
     }
     __syncthreads();
     KT();
-    if (Sp) gh_partial_gram(Ts, Sp + (long)blockIdx.x * (GW * GW), lane, wave);
+    if (Sp) gh_partial_gram_add(Ts, ga, lane, wave);
     KT();
     // V^T rows: 128 columns x 64 rows of this workgroup, 16-B chunks along the row index
     for (int e = tid; e < GW * 8; e += 256) {
@@ -525,6 +548,8 @@ __global__ __launch_bounds__(256) void gh_apply_kernel(LeafArgs a, const float* 
             }
         }
     }
+    }                                                      // row blocks
+    if (Sp) gh_partial_gram_store(ga, Sp + (long)blockIdx.x * (GW * GW), lane, wave);
     KT(); KT_DUMP(6, "gh_apply load|mfma|store+next|gram|vt");
 }
 
@@ -561,8 +586,14 @@ __global__ __launch_bounds__(256) void gh_reduce_f32_kernel(const float* __restr
     if (wave == 0) S[e] = (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
 }
 
+// blocks of 64 rows per gh_apply workgroup: tall leaves take 2 / 4, which still leaves >= 256 workgroups
+static int gh_apply_iters(const LeafArgs& a) {
+    const int rows = a.mrows - a.c1;
+    return rows >= 49152 ? 4 : rows >= 24576 ? 2 : 1;
+}
 int gh_num_partials(const LeafArgs& a) {
-    return (a.mrows - a.c1 + 63) / 64 + (a.c1 - a.c0 + 63) / 64;
+    const int it = gh_apply_iters(a);
+    return ((a.mrows - a.c1 + 63) / 64 + it - 1) / it + (a.c1 - a.c0 + 63) / 64;
 }
 void launch_gh_reduce_f32(const float* Sp, int nslab, float* S, hipStream_t s) {
     hipLaunchKernelGGL(gh_reduce_f32_kernel, dim3(256), dim3(256), 0, s, Sp, nslab, S);
@@ -588,10 +619,11 @@ void launch_gh_solve(const LeafArgs& a, const double* G, float* Cv, int* flag, h
 }
 void launch_gh_apply(const LeafArgs& a, const float* Cv, float* Sp, hipStream_t s) {
     gh_set_attrs();
-    const int nlow = (a.mrows - a.c1 + 63) / 64;
+    const int it = gh_apply_iters(a);
+    const int nlow = ((a.mrows - a.c1 + 63) / 64 + it - 1) / it;
     const int ntop = Sp ? (a.c1 - a.c0 + 63) / 64 : 0;      // extra workgroups: Gram contribution of the top block
     if (nlow + ntop == 0) return;
-    hipLaunchKernelGGL(gh_apply_kernel, dim3(nlow + ntop), dim3(256), (8256 + GW * GH_TS) * 4, s, a, Cv, Sp, nlow);
+    hipLaunchKernelGGL(gh_apply_kernel, dim3(nlow + ntop), dim3(256), (8256 + GW * GH_TS) * 4, s, a, Cv, Sp, nlow, it);
 }
 void launch_leaf_gram_householder(const LeafArgs& a, double* Gp, double* G, float* Cv, int* flag, float* Sp, float* S,
                                   hipStream_t s) {
