@@ -931,7 +931,11 @@ int factor_block_flat(mpqr_handle_t h, int top, const std::vector<int>& leaves) 
             }
             if (pre_split && h->wait_after_first_leaf) HIPQ(h, hipStreamWaitEvent(h->sT, h->wait_after_first_leaf, 0));   // (kept: the last pre-updated leaf waits too)
             apply_node(h, lf, h->Aeff, h->lda, lo, upd_end, true, h->a_scale, false, 2);
-            if (la_mid) { HIPQ(h, hipEventRecord(h->ev_rest, h->sT)); h->rest_pending = true; }
+            // EVERY deferred update is announced to the chain stream: the next leaf may take the one-launch middle, whose X runs on the
+            // chain stream and reads the columns this update writes (a leaf on the two-stream form is ordered behind it by the T stream
+            // itself; the extra wait is harmless there).  Without it the first one-launch leaf behind a block's two-stream leaves raced
+            // with the second leaf's rest: R differed from run to run from that leaf's successor on (tools/determinism_check.py).
+            HIPQ(h, hipEventRecord(h->ev_rest, h->sT)); h->rest_pending = true;
         }
         // background, behind this leaf's X GEMM in the side stream's queue: the PREVIOUS leaf's column block of T
         if (prev_o >= 0) t_column_block(prev, prev_o);

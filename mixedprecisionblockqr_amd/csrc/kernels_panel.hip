@@ -296,12 +296,38 @@ constexpr int GH_TS = 132;       // LDS row stride (floats) of a staged 128-colu
 constexpr int GH_ROWS = 128;     // rows per workgroup in gh_gram
 
 constexpr int GH_TD = 144;       // LDS row stride (doubles) of the staged tile: rows k, k+1 of one MFMA operand read land on disjoint bank halves
-__global__ __launch_bounds__(256) void gh_gram_kernel(LeafArgs a, double* __restrict__ Gp) {
+__global__ __launch_bounds__(256) void gh_gram_kernel(LeafArgs a, double* __restrict__ Gp, int iters) {
     double* tile = (double*)gh_smem;                      // [GH_ROWS][GH_TD] doubles: converted once while staging
     const int tid = threadIdx.x;
     KT_DECL; KT();
-    const int row0 = a.c0 + (blockIdx.x >> 1) * GH_ROWS;   // ALL leaf rows, top block included: G = Gram of the remaining rows at k = c0
     const int hb = blockIdx.x & 1;                        // which half of G's rows this workgroup produces
+    // G = T^T T on v_mfma_f64_16x16x4_f64 (A[i][k] from lane i + 16k, B[k][j] from lane j + 16k, D[i][j] in lane j + 16 (i%4),
+    // element i/4 -- probed, tools/probe_mfma_f64.hip).  G is symmetric: only the 36 upper 16 x 16 tiles are computed,
+    // tile t = hb + 2 wave + 8 s  (s < 5) by this wave; gh_reduce mirrors the sum.
+    const int lane = tid & 63, wave = tid >> 6, li = lane & 15, lk = lane >> 4;
+    int tti[5], ttj[5];
+    typedef double double4g __attribute__((ext_vector_type(4)));
+    double4g acc[5];
+#pragma unroll
+    for (int s = 0; s < 5; s++) {
+        int t = hb + 2 * wave + 8 * s;                       // row-major index among the upper tiles of an 8 x 8 tile grid
+        int ti = 0;
+        if (t >= 36) { tti[s] = -1; ttj[s] = 0; }
+        else {
+            while (t >= 8 - ti) { t -= 8 - ti; ti++; }
+            tti[s] = ti; ttj[s] = ti + t;
+        }
+        acc[s] = double4g{0, 0, 0, 0};
+    }
+    int ca[5], cb[5];
+#pragma unroll
+    for (int s = 0; s < 5; s++) { ca[s] = tti[s] >= 0 ? 16 * tti[s] : 0; cb[s] = tti[s] >= 0 ? 16 * ttj[s] : 0; }
+    // `iters` blocks of GH_ROWS rows per workgroup pair (tall leaves: gh_gram_iters): the accumulators carry over, a 65536-row leaf
+    // writes 128 partials (9 MB) instead of 512 (37 MB, more than the rows it reads)
+    for (int it = 0; it < iters; it++) {
+    const int row0 = a.c0 + ((int)(blockIdx.x >> 1) * iters + it) * GH_ROWS;   // ALL leaf rows, top block included: G = Gram of the remaining rows at k = c0
+    if (row0 >= a.mrows) break;
+    if (it) __syncthreads();                               // every wave is done with the previous tile
     // all 16 loads of a thread first (clamped row, masked afterwards), then the conversions and LDS stores: with the load inside the bounds
     // branch the compiler emitted load -> s_waitcnt vmcnt(0) -> store sixteen times, one memory latency each -- 14-24 k cycles of this
     // kernel's ~30 k (in-kernel stamps tools/ktrace_solve.sh; ISA: hipcc -S)
@@ -321,29 +347,8 @@ __global__ __launch_bounds__(256) void gh_gram_kernel(LeafArgs a, double* __rest
     }
     __syncthreads();
     KT();
-    // G = T^T T on v_mfma_f64_16x16x4_f64 (A[i][k] from lane i + 16k, B[k][j] from lane j + 16k, D[i][j] in lane j + 16 (i%4),
-    // element i/4 -- probed, tools/probe_mfma_f64.hip).  G is symmetric: only the 36 upper 16 x 16 tiles are computed,
-    // tile t = hb + 2 wave + 8 s  (s < 5) by this wave; gh_reduce mirrors the sum.
-    const int lane = tid & 63, wave = tid >> 6, li = lane & 15, lk = lane >> 4;
-    int tti[5], ttj[5];
-    typedef double double4g __attribute__((ext_vector_type(4)));
-    double4g acc[5];
-#pragma unroll
-    for (int s = 0; s < 5; s++) {
-        int t = hb + 2 * wave + 8 * s;                       // row-major index among the upper tiles of an 8 x 8 tile grid
-        int ti = 0;
-        if (t >= 36) { tti[s] = -1; ttj[s] = 0; }
-        else {
-            while (t >= 8 - ti) { t -= 8 - ti; ti++; }
-            tti[s] = ti; ttj[s] = ti + t;
-        }
-        acc[s] = double4g{0, 0, 0, 0};
-    }
     // two K steps per iteration, all 20 operand reads in flight before the 10 MFMAs (the loop was LDS-latency bound: 10 of
     // the kernel's 16 us); slots without a tile recompute tile 0 (never stored) so that the loop has no branches
-    int ca[5], cb[5];
-#pragma unroll
-    for (int s = 0; s < 5; s++) { ca[s] = tti[s] >= 0 ? 16 * tti[s] : 0; cb[s] = tti[s] >= 0 ? 16 * ttj[s] : 0; }
     for (int k0 = 0; k0 < GH_ROWS; k0 += 8) {
         const double* tr0 = &tile[(k0 + lk) * GH_TD + li];
         const double* tr1 = tr0 + 4 * GH_TD;
@@ -356,6 +361,7 @@ __global__ __launch_bounds__(256) void gh_gram_kernel(LeafArgs a, double* __rest
         for (int s = 0; s < 5; s++) acc[s] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[s], b1[s], acc[s], 0, 0, 0);
     }
     KT();
+    }                                                      // row blocks
     double* out = Gp + (long)(blockIdx.x >> 1) * (GW * GW);
 #pragma unroll
     for (int s = 0; s < 5; s++)
@@ -368,9 +374,6 @@ __global__ __launch_bounds__(256) void gh_gram_kernel(LeafArgs a, double* __rest
         }
     KT(); KT_DUMP(3, "gh_gram load|mfma|store");
 }
-
-// G = sum of the partials in slab order.  256 workgroups: workgroup b owns 64 consecutive entries, its 4 waves
-// take interleaved quarters of the partials, combined through LDS in a fixed order (deterministic).
 __global__ __launch_bounds__(256) void gh_reduce_kernel(const double* __restrict__ Gp, int nwg, double* __restrict__ G) {
     __shared__ double part[4][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -605,8 +608,10 @@ static void gh_set_attrs() {
 // the four steps of a Gram-Householder leaf, separately launchable (the look-ahead schedule puts them on different streams)
 void launch_gh_gram(const LeafArgs& a, double* Gp, double* G, hipStream_t s) {
     gh_set_attrs();
-    const int nwg = (a.mrows - a.c0 + GH_ROWS - 1) / GH_ROWS;
-    hipLaunchKernelGGL(gh_gram_kernel, dim3(2 * nwg), dim3(256), GH_ROWS * GH_TD * 8, s, a, Gp);
+    const int rows = a.mrows - a.c0;
+    const int it = rows >= 49152 ? 4 : rows >= 24576 ? 2 : 1;          // row blocks per workgroup pair: tall leaves still get >= 192 workgroups
+    const int nwg = ((rows + GH_ROWS - 1) / GH_ROWS + it - 1) / it;
+    hipLaunchKernelGGL(gh_gram_kernel, dim3(2 * nwg), dim3(256), GH_ROWS * GH_TD * 8, s, a, Gp, it);
     hipLaunchKernelGGL(gh_reduce_kernel, dim3(256), dim3(256), 0, s, Gp, nwg, G);
 }
 void launch_gh_solve(const LeafArgs& a, const double* G, float* Cv, int* flag, hipStream_t s) {
