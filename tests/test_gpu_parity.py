@@ -490,6 +490,31 @@ def test_full_size_configs_properties(mp, m, n, r):
         hh.close()
 
 
+def test_tall_leaves_with_leaf_lookahead_are_bit_repeatable(mp):
+    """Leaves with >= 20480 rows take the leaf-level look-ahead: a leaf's update of the rest of its block runs on the T stream
+    beside the next leaf's solve, ordered against the chain stream by one event per leaf.  No atomics on the path: five
+    factorisations of the same matrix must give the same R bit for bit (a missing ordering shows up here as run-to-run
+    differences from some leaf on), and the usual properties hold."""
+    hh = mp.Handle(0)
+    try:
+        m, n = 24576, 3072                                   # three 1024-column blocks of 8 leaves, every leaf >= 21504 rows
+        hh.plan(m, n, 128)
+        hh.generate(4242)
+        ref = None
+        for it in range(5):
+            hh.factor(); hh.sync()
+            R = hh.r_matrix()
+            if ref is None:
+                ref = R.copy()
+            else:
+                cols = np.flatnonzero((R != ref).any(axis=0))
+                assert len(cols) == 0, (it, int(cols[0]), len(cols))
+        mt = hh.metrics()
+        assert mt["backward_error"] <= 1e-3 and mt["q_error_fro"] <= 2e-3 * np.sqrt(m) and mt["lower_trapezoid"] == 0.0, mt
+    finally:
+        hh.close()
+
+
 @pytest.mark.baseline(3)
 def test_config3_synthetic_jacobian_through_the_file_format(mp, h, po, tmp_path):
     """BASELINE config 3 (EuRoC bundle-adjustment Jacobian, r = 64): the real files are an absent LFS blob, so a
