@@ -502,6 +502,10 @@ void apply_node(mpqr_handle_t h, const Node& nd, float* C, long ldc, int clo, in
         // flat schedule: X beside the leaf's Gram sum and T, one launch (kernels_panel.hip: leaf_mid_kernel); one workgroup per CU there
         const int gx = (M1 + 127) / 128;
         static const int mid_wgs = []() { const char* e = getenv("MPQR_MID_WGS"); return e ? std::max(8, atoi(e)) : 128; }();   // tuning hook (48 / 64 / 96 / 128 / 176: 35.7 / 35.4 / 35.0 / 35.0 / 35.1-35.2 ms)
+        // tall leaves with few column tiles (leaf-level look-ahead: ONE tile): the general split cap (32) leaves every workgroup ~30 K tiles of
+        // 64 at 65536 rows, 45 us of load -> LDS -> MFMA round trips beside a 26 us T path; ~12 K tiles per workgroup instead
+        g1.nsplit = std::max(g1.nsplit, std::min(Kw / 64 / 12, mid_wgs / gx));
+        while (g1.nsplit > 1 && (size_t)g1.nsplit * (size_t)slab > h->xt_elems) g1.nsplit--;
         while (g1.nsplit > 1 && gx * g1.nsplit > mid_wgs) g1.nsplit--;
         const mpqr_handle_s::MidT& mt = *h->mid;
         launch_leaf_mid(g1, mt.Sp, mt.nslab, h->Sleaf, mt.sh, h->mid_counter, mt.a0, mt.c0, mt.c1, mt.T, mt.Th, mt.Tth, mt.ldt, mt.ld, st);
