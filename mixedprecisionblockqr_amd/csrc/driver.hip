@@ -117,7 +117,14 @@ struct mpqr_handle_s {
     bool v_clean = false;         // the reflector stores (Vh, Vt, vdiag) need no clearing before the next factorisation of this plan: they are
                                   // zero (fresh plan) or hold the reflectors of a clean single-pass factorisation of the same plan, every one of
                                   // which the next factorisation rewrites before it reads it
-    int* tflag = nullptr;         // device word the chain publishes its progress in (leaf_xt_kernel), polled by the T stream (wait_flag_kernel)
+    // fused leaf (round 5): the chain touches only the next leaf's columns, in three launches (leaf_a / leaf_m / leaf_b, kernels_panel.hip)
+    bool fused_leaf = true;       // MPQR_FUSED_LEAF=0: the seven-launch leaf of round 4
+    float* Xp = nullptr;          // per-workgroup partials of X = (s P)^T V for the next panel (leaf_a), like Sp
+    float* Xs = nullptr;          // their sum (LEAF_MID_MAX_GROUPS windows)
+    half_t* Yfl = nullptr;        // Y = fp16(X T') for the next panel, 128 x 128
+    int gram_ready_c0 = -1, gram_ready_rows = 0, gram_ready_n = 0;   // leaf_b left the partial Gram matrices (n of them) of the leaf that starts at this column, over this many rows
+    int n_fused_leaves = 0;       // of the last mpqr_factor
+    int* tflag = nullptr;         // device word the chain publishes its progress in (leaf_xt_kernel / leaf_b_kernel), polled by the T stream (wait_flag_kernel)
     int tseq = 0, xt_pub = 0;     // last published value; value the next leaf_xt launch of apply_node is to publish (0: none)
     bool tpoll = true;            // MPQR_TPOLL=0: the T stream follows the chain through an event (costs the chain ~4 us per leaf)
     float* P = nullptr;    int maxwg = 0;
@@ -240,7 +247,7 @@ int dalloc(mpqr_handle_t h, T** p, size_t elems) {
 void free_plan(mpqr_handle_t h) {
     void* ptrs[] = {h->dA, h->dA0, h->dQ, h->Vh, h->Vt, h->vdiag, h->Xt, h->Yt, h->S, h->P, h->tmp1, h->tmp2,
                     h->Tf, h->Th, h->Tth, h->dstage, h->Gp, h->Gs, h->Cv, h->dflag, h->Vf, h->Yf, h->Xt1, h->Yt1, h->Sp,
-                    h->rbTf, h->rbTh, h->rbTth, h->Sleaf, h->mid_counter, h->tflag, h->V8n, h->V8t, h->A8t, h->Y8, h->Xt2, h->Yt2,
+                    h->rbTf, h->rbTh, h->rbTth, h->Sleaf, h->mid_counter, h->tflag, h->V8n, h->V8t, h->A8t, h->Y8, h->Xt2, h->Yt2, h->Xp, h->Xs, h->Yfl,
                     h->S2, h->tmp1b, h->tmp2b, h->Qt, h->At, h->Xh, h->Wh, h->Xl, h->Xh1, h->Xl1};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (h->hflag_host) (void)hipHostFree(h->hflag_host);
@@ -251,7 +258,7 @@ void free_plan(mpqr_handle_t h) {
     h->dstage = nullptr; h->stage_elems = 0;
     h->Gp = nullptr; h->Gs = nullptr; h->Cv = nullptr; h->dflag = nullptr; h->Vf = nullptr; h->Yf = nullptr;
     h->Xt1 = nullptr; h->Yt1 = nullptr; h->Sp = nullptr; h->Xt2 = nullptr; h->Yt2 = nullptr; h->xt2_elems = 0;
-    h->rbTf = nullptr; h->rbTh = h->rbTth = nullptr; h->rb_elems = 0; h->nflag = 0; h->leaf_robust.clear(); h->Sleaf = nullptr; h->mid_counter = nullptr; h->tflag = nullptr;
+    h->rbTf = nullptr; h->rbTh = h->rbTth = nullptr; h->rb_elems = 0; h->nflag = 0; h->leaf_robust.clear(); h->Sleaf = nullptr; h->mid_counter = nullptr; h->tflag = nullptr; h->Xp = nullptr; h->Xs = nullptr; h->Yfl = nullptr; h->gram_ready_c0 = -1;
     h->V8n = h->V8t = h->A8t = h->Y8 = nullptr; h->v8_node = -1;
     for (hipEvent_t e : h->chain_ev) (void)hipEventDestroy(e);
     h->chain_ev.clear(); h->chain_used = 0; h->far_used = 0;
@@ -622,6 +629,16 @@ static void t_stream_follows_chain(mpqr_handle_t h) {
     HIPQ(h, hipStreamWaitEvent(h->sT, h->ev_v, 0));
 }
 
+// the Gram matrix of a Gram-Householder leaf: gh_gram + gh_reduce, or the reduction alone when the previous leaf's leaf_b has already left
+// the partials (fused leaf)
+static void leaf_gram(mpqr_handle_t h, const LeafArgs& a) {
+    if (h->gram_ready_c0 == a.c0 && h->gram_ready_rows == a.mrows - a.c0 && h->gram_ready_n > 0)
+        launch_gh_gram_reduce(h->Gp, h->gram_ready_n, h->Gs, h->s0);
+    else
+        launch_gh_gram(a, h->Gp, h->Gs, h->s0);
+    h->gram_ready_c0 = -1;
+}
+
 int factor_rec(mpqr_handle_t h, int id, bool do_panel) {
     const Node nd = h->nodes[id];
     int rc;
@@ -649,7 +666,12 @@ int factor_rec(mpqr_handle_t h, int id, bool do_panel) {
             a.P = h->P; a.maxwg = h->maxwg; a.hostflag = h->hflag_dev + h->cur_block;
             const bool fused = tall && !h->Vf;    // fp16 mode: the Gram of the rounded reflectors comes out of gh_apply
             int* flag = h->dflag + (id < h->nflag ? id : 0);
-            if (tall) { launch_leaf_gram_householder(a, h->Gp, h->Gs, h->Cv, flag, fused ? h->Sp : nullptr, nullptr, h->s0); h->n_gh_leaves++; }
+            if (tall) {
+                leaf_gram(h, a);
+                launch_gh_solve(a, h->Gs, h->Cv, flag, h->s0);
+                launch_gh_apply(a, h->Cv, fused ? h->Sp : nullptr, h->s0);
+                h->n_gh_leaves++;
+            }
             else if (tail) launch_leaf_tail(a, h->Sleaf, h->s0);
             else launch_leaf_factor(a, h->s0);
             if (h->Vf) launch_extract_vf(h->Aeff, h->lda, h->vdiag, h->Vf, h->n_pad, h->m, nd.c0, nd.c1, h->s0);
@@ -789,6 +811,7 @@ int factor_block_flat(mpqr_handle_t h, int top, const std::vector<int>& leaves) 
         const bool robust_leaf = !tail && (h->robust || (id < (int)h->leaf_robust.size() && h->leaf_robust[id]));
         bool mid_leaf = false, gh_leaf = false, far_wait_pending = false;
         int gh_partials = 0, gh_sh = 0;
+        LeafArgs gh_args{};
         mpqr_handle_s::MidT mid_desc{};
         if (tail) {
             // the matrix's last <= 128 rows: plain Householder in one workgroup, S for its T from the same kernel
@@ -823,12 +846,12 @@ int factor_block_flat(mpqr_handle_t h, int top, const std::vector<int>& leaves) 
             a.A = h->Aeff; a.lda = h->lda; a.mrows = h->m; a.cb = rdown(lf.c0, 128); a.c0 = lf.c0; a.c1 = lf.c1;
             a.Vh = h->Vh; a.ldvh = h->ldvh; a.Vt = h->Vt; a.ldvt = h->ldvt; a.vdiag = h->vdiag;
             a.P = h->P; a.maxwg = h->maxwg; a.hostflag = h->hflag_dev + h->cur_block;
-            launch_gh_gram(a, h->Gp, h->Gs, h->s0);
+            leaf_gram(h, a);
             // the previous block's far update is enqueued HERE (run_block_loop): its stream starts when this leaf's gh_solve does,
             // so its first GEMMs fill the other 255 CUs during the solve instead of holding them while gh_gram wants them
             if (h->far_hook) { auto fh = std::move(h->far_hook); h->far_hook = nullptr; if ((rc = fh())) return rc; }
             launch_gh_solve(a, h->Gs, h->Cv, h->dflag + (id < h->nflag ? id : 0), h->s0);
-            launch_gh_apply(a, h->Cv, h->Sp, h->s0);
+            gh_args = a;                                     // (gh_apply, or the fused leaf's leaf_a, is launched below once the leaf's form is known)
             h->n_gh_leaves++;
             if (h->wait_after_first_leaf && !tq) {       // look-ahead: the block's other columns arrive with this event
                 HIPQ(h, hipStreamWaitEvent(h->s0, h->wait_after_first_leaf, 0));
@@ -861,18 +884,25 @@ int factor_block_flat(mpqr_handle_t h, int top, const std::vector<int>& leaves) 
         const int leaf_la = leaf_la_env >= 0 ? leaf_la_env : (h->m - lf.c0 >= 20480 ? 1 : 0);
         const int next_c1 = j + 1 < leaves.size() ? h->nodes[leaves[j + 1]].c1 : lf.c1 + 128;
         const bool lane2_ok = h->Xt2 != nullptr && h->Yt2 != nullptr;      // (allocated with opts.lookahead only: ADVICE round 3)
-        const bool la_split = tq && lane2_ok && leaf_la && lf.c1 < upd_end && std::min(next_c1, upd_end) < upd_end;
+        // Fused leaf (round 5): the chain works on the NEXT 128 columns only, in three launches (leaf_a: gh_apply + partial X; leaf_m: T and Y;
+        // leaf_b: the update + the next leaf's partial Gram matrices), the rest of the block follows on the T stream as under leaf-level look-ahead.
+        // Needs a full 128-column leaf, 128 further columns inside the update range, and the polling T stream (leaf_b publishes the word).
+        const bool fl = h->fused_leaf && gh_leaf && tq && lane2_ok && h->Xp && h->tpoll && h->tflag && h->hflag_dev && h->flag_words > 0 &&
+                        lf.ldt == 128 && lf.a0 == lf.c0 && lf.c1 - lf.c0 == 128 && (lf.c0 % 128) == 0 && lf.c1 + 128 <= upd_end && lf.c1 + 128 <= h->n &&
+                        !h->shadow && !h->Vf && h->opts.precision != MPQR_PREC_FP32;
+        const bool la_split = fl || (tq && lane2_ok && leaf_la && lf.c1 < upd_end && std::min(next_c1, upd_end) < upd_end);
         const bool pre_split = tq && lane2_ok && P >= 2 && (int)j < P - 1 && cpre < upd_end;      // a pre-updated leaf before the last one
         if ((int)j == P - 1 || P == 0 || (int)j >= P || !tq) {
             if (h->wait_after_first_leaf) {
                 // Only X = C2^T V_j reads those columns first, and it runs on the side stream: that stream waits, the chain stream goes
                 // on with T_j and meets the dependency through the X event (the robust leaf path, which works on the chain stream, waits there)
                 HIPQ(h, hipStreamWaitEvent(tq && !robust_leaf ? h->sT : h->s0, h->wait_after_first_leaf, 0));
-                if (tq && robust_leaf) HIPQ(h, hipStreamWaitEvent(h->sT, h->wait_after_first_leaf, 0));
+                if (tq && (robust_leaf || fl)) HIPQ(h, hipStreamWaitEvent(robust_leaf ? h->sT : h->s0, h->wait_after_first_leaf, 0));   // (fused leaf: leaf_a reads those columns on the chain stream)
                 h->wait_after_first_leaf = nullptr;
             }
         }
-        const int own_end = la_split ? std::min(next_c1, upd_end) : (pre_split ? cpre : upd_end);
+        const int own_end = fl ? lf.c1 + 128 : la_split ? std::min(next_c1, upd_end) : (pre_split ? cpre : upd_end);
+        if (gh_leaf && !fl) launch_gh_apply(gh_args, h->Cv, h->Sp, h->s0);
         const bool have_rest = (la_split || pre_split) && own_end < upd_end;
         if (gh_leaf) {
             // T_j = (Gram of the fp16 reflectors: gh_apply's partials, summed)^-1.  Round 4: when this leaf has an in-block update of the plain
@@ -880,9 +910,11 @@ int factor_block_flat(mpqr_handle_t h, int top, const std::vector<int>& leaves) 
             // side stream for X, no hand-offs around it; the T stream then follows the chain AFTER the update (it only builds the previous
             // leaf's column block of T).  Not for a leaf whose X still waits for the previous block's far update: there the chain goes on
             // with T_j while the side stream waits.
-            mid_leaf = h->leaf_mid && tq && (!la_split || h->tpoll) && !far_wait_pending && lf.ldt == 128 && lf.c1 < own_end &&
+            mid_leaf = !fl && h->leaf_mid && tq && (!la_split || h->tpoll) && !far_wait_pending && lf.ldt == 128 && lf.c1 < own_end &&
                        own_end - rdown(lf.c1, 32) <= 4096 && !h->shadow && !h->Vf && h->opts.precision != MPQR_PREC_FP32;
-            if (mid_leaf) {
+            if (fl) {
+                // (T_j comes out of leaf_m below)
+            } else if (mid_leaf) {
                 mid_desc = mpqr_handle_s::MidT{h->Sp, gh_partials, gh_sh, lf.a0, lf.c0, lf.c1, h->Tf + lf.toff, h->Th + lf.toff, h->Tth + lf.toff, lf.ldt, ld};
             } else {
                 Range rt("mpqr:wy_T");
@@ -897,7 +929,7 @@ int factor_block_flat(mpqr_handle_t h, int top, const std::vector<int>& leaves) 
         }
         // leaf-level look-ahead with the one-launch middle: T_j comes out of the urgent apply below, and the rest (T stream) starts behind
         // the word its leaf_xt publishes -- no event on the chain stream for it
-        const bool la_mid = la_split && mid_leaf;
+        const bool la_mid = la_split && (mid_leaf || fl);
         if (have_rest && la_split && !la_mid) HIPQ(h, hipEventRecord(h->ev_def, h->s0));   // T_j and V_j are complete here: the rest may start beside the urgent part
         if (h->rest_pending) {
             // the previous leaf's deferred update (T stream) wrote columns this leaf's X reads and the next gh_gram needs: it finished
@@ -905,6 +937,20 @@ int factor_block_flat(mpqr_handle_t h, int top, const std::vector<int>& leaves) 
             HIPQ(h, hipStreamWaitEvent(h->s0, h->ev_rest, 0));
             h->rest_pending = false;
         }
+        if (fl) {
+            Range rg("mpqr:fused_leaf");
+            // next leaf: does it take the partial Gram matrices leaf_b can leave?  (a Gram-Householder leaf: not the tail, not on the robust path)
+            bool next_gh = !is_tail(h, lf.c1) && !h->robust;
+            if (next_gh && j + 1 < leaves.size()) { const int nid = leaves[j + 1]; next_gh = !(nid < (int)h->leaf_robust.size() && h->leaf_robust[nid]); }
+            launch_leaf_a(gh_args, h->Cv, h->Sp, h->Xp, lf.c1, h->a_scale, h->s0);
+            launch_leaf_m(h->Sp, h->Xp, gh_partials, h->Sleaf, h->Xs, h->mid_counter, gh_sh, lf.a0, lf.c0, lf.c1, h->Tf + lf.toff, h->Th + lf.toff,
+                          h->Tth + lf.toff, lf.ldt, ld, h->Yfl, h->s0);
+            launch_leaf_b(gh_args, lf.c1, h->Yfl, 1.0f / h->a_scale, h->Gp, next_gh, h->tflag, ++h->tseq, h->s0);
+            if (next_gh) { h->gram_ready_c0 = lf.c1; h->gram_ready_rows = h->m - lf.c1; h->gram_ready_n = fl_gram_partials(gh_args); }
+            h->n_fused_leaves++;
+            // the T stream goes on (the previous leaf's column block of T, this leaf's update of the rest of the block) once the chain is past T_j
+            launch_wait_flag(h->tflag, h->tseq, h->hflag_dev + h->flag_words - 1, h->sT);
+        } else
         if (lf.c1 < own_end) {
             Range rg("mpqr:in_block_update");
             h->op1_stream = (tq && !mid_leaf) ? h->sT : nullptr;
@@ -1445,10 +1491,16 @@ static int plan_common(mpqr_handle_t h, int m, int n, int r, const mpqr_opts* op
     HIPCHK(h, hipMemsetAsync(h->tflag, 0, sizeof(int), h->s0));
     h->tseq = 0;
     if ((rc = dalloc(h, &h->P, (size_t)2 * h->maxwg * 32))) return rc;
-    if ((rc = dalloc(h, &h->Gp, (size_t)(h->m_pad / 128 + 2) * 16384))) return rc;
+    if ((rc = dalloc(h, &h->Gp, (size_t)(h->m_pad / 64 + 2) * 16384))) return rc;      // (leaf_b: one partial per 64 rows)
     if ((rc = dalloc(h, &h->Gs, (size_t)16384))) return rc;
     if ((rc = dalloc(h, &h->Sp, (size_t)(h->m_pad / 64 + 4) * 16384))) return rc;
     if ((rc = dalloc(h, &h->Cv, (size_t)16384))) return rc;
+    if (const char* e = getenv("MPQR_FUSED_LEAF")) h->fused_leaf = atoi(e) != 0;     // A/B hook
+    if (h->fused_leaf && o.precision != MPQR_PREC_FP32) {
+        if ((rc = dalloc(h, &h->Xp, (size_t)(h->m_pad / 64 + 4) * 16384))) return rc;
+        if ((rc = dalloc(h, &h->Xs, (size_t)16384 * LEAF_MID_MAX_GROUPS))) return rc;
+        if ((rc = dalloc(h, &h->Yfl, (size_t)16384))) return rc;
+    }
     h->nflag = (int)h->nodes.size() + 1024;               // one flag per tree node (+ room for the stage calls' private trees)
     if ((rc = dalloc(h, &h->dflag, (size_t)h->nflag))) return rc;
     {   // the flag word the enqueuing thread polls: mapped, coherent host memory (a flagged leaf stores 1 into it, system scope)
@@ -1580,6 +1632,8 @@ int mpqr_generate_matrix(mpqr_handle_t h, uint64_t seed) {
 static int run_block_loop(mpqr_handle_t h, int start = 0) {
     int rc;
     h->v8_node = -1;
+    h->gram_ready_c0 = -1;
+    if (start <= 0) h->n_fused_leaves = 0;
     h->pairs_ready = false; h->q_first = (size_t)-1;
     const auto host_t0 = std::chrono::steady_clock::now();  // host time to enqueue the block loop (ms_host_enqueue)
     if (start > 0 && (size_t)start < h->far_mark.size()) {

@@ -903,10 +903,10 @@ void launch_wait_flag(const int* flag, int value, int* timeout_word, hipStream_t
 // NT threads (>= 256: tri_inverse_128 needs four waves).  SC1: S was written by OTHER workgroups of the same launch (leaf_mid_kernel): every
 // load of it is an agent-scope relaxed atomic load (global_load_dword sc1: served past this CU's L1 and this XCD's L2 hit path as the
 // hand-off table of MI355X_MICROARCH.md requires when the producer stored sc1).
+// (two halves since round 5: the fused leaf computes Y = X T' out of LDS between the inverse and the stores of T)
 template <int NT, bool SC1>
-__device__ __forceinline__ void t_panel_body(const float* __restrict__ S, int nslab, long slab_stride, int lds_, int a0, int c0, int c1,
-                                             float* __restrict__ T, half_t* __restrict__ Th, half_t* __restrict__ Tth, int ldt, int ld,
-                                             float* Ss, float* tdiag) {
+__device__ __forceinline__ void t_panel_load_invert(const float* __restrict__ S, int nslab, long slab_stride, int lds_, int a0, int c0, int c1,
+                                                    float* Ss, float* tdiag) {
     float* Ts = Ss + TP * TPS;               // [TP][TPS]
     const int tid = threadIdx.x;
     const int w = c1 - c0, off = c0 - a0;
@@ -948,7 +948,13 @@ __device__ __forceinline__ void t_panel_body(const float* __restrict__ S, int ns
     __syncthreads();
     KT();
     tri_inverse_128(Ss, tdiag, Ts, nblk, tid);
-    KT();
+    KT(); KT_DUMP(1, "t_panel load|inverse");
+}
+template <int NT>
+__device__ __forceinline__ void t_panel_store(const float* Ts, int a0, int c0, int c1, float* __restrict__ T, half_t* __restrict__ Th,
+                                              half_t* __restrict__ Tth, int ldt, int ld) {
+    const int tid = threadIdx.x;
+    const int w = c1 - c0, off = c0 - a0;
     // the ldt x ldt aligned range is written (zeros outside the leaf) into a matrix of leading dimension ld (>= ldt:
     // the node's own T, or its diagonal block inside the T of the enclosing top-level block)
     if (ldt == TP && off == 0 && (ld & 3) == 0) {
@@ -991,7 +997,13 @@ __device__ __forceinline__ void t_panel_body(const float* __restrict__ S, int ns
         Tth[(long)j * ld + i] = (half_t)(tjj != 0.f ? v / tjj : 0.f);
     }
     }
-    KT(); KT_DUMP(1, "t_panel load|inverse|store");
+}
+template <int NT, bool SC1>
+__device__ __forceinline__ void t_panel_body(const float* __restrict__ S, int nslab, long slab_stride, int lds_, int a0, int c0, int c1,
+                                             float* __restrict__ T, half_t* __restrict__ Th, half_t* __restrict__ Tth, int ldt, int ld,
+                                             float* Ss, float* tdiag) {
+    t_panel_load_invert<NT, SC1>(S, nslab, slab_stride, lds_, a0, c0, c1, Ss, tdiag);
+    t_panel_store<NT>(Ss + TP * TPS, a0, c0, c1, T, Th, Tth, ldt, ld);
 }
 __global__ __launch_bounds__(1024) void t_panel_kernel(const float* __restrict__ S, int nslab, long slab_stride, int lds_,
                                                        int a0, int c0, int c1, float* __restrict__ T,
@@ -1183,6 +1195,515 @@ void launch_leaf_mid(const GemmArgs& g1, const float* Sp, int nslab, float* S, i
     m.ngrp = std::max(1, std::min(LEAF_MID_MAX_GROUPS, nslab / 256));        // (S holds LEAF_MID_MAX_GROUPS windows)
     m.a0 = a0; m.c0 = c0; m.c1 = c1; m.T = T; m.Th = Th; m.Tth = Tth; m.ldt = ldt; m.ld = ld <= 0 ? ldt : ld;
     hipLaunchKernelGGL(leaf_mid_kernel, dim3(m.nX + MID_RB * m.ngrp), dim3(256), LDS, s, m);
+}
+
+// ------------------------------------------------------------------ fused leaf (round 5): three launches between two solves
+// A steady leaf of the flat schedule used to cost the chain stream seven launches: gh_solve, gh_apply, leaf_mid (X for the rest of the block +
+// Gram sum + T), leaf_xt (Y), the K = 128 update of the rest of the block, gh_gram, gh_reduce -- 150 us, 60 of them the solve (kernel trace,
+// profiles/r04_c4_leaf_timeline.txt).  Every one of them re-reads what its predecessor held in LDS, and five of them work on the WHOLE rest of
+// the block although the next solve needs only the next leaf's 128 columns.  Now the chain stream touches only those 128 columns (the rest of
+// the block follows on the T stream, as the leaf-level look-ahead of round 4 did for tall leaves), in three launches that share row blocks:
+//   leaf_a : gh_apply (V_low = A_low C, fp16 copies, partial Gram of the rounded reflectors) + the partial X = (s P)^T V of the NEXT panel P
+//            over the same 64 rows (fp16 MFMA out of LDS: V is already there, P is staged like the GEMMs' A_F32T operand)
+//   leaf_m : sums the partials of S and X (fixed order), and the last arriver (agent-scope counter, as leaf_mid_kernel) inverts T AND forms
+//            Y = fp16(tau (X_hi + X_lo) T'^T) for the next panel out of LDS -- leaf_xt's arithmetic -- before it stores T
+//   leaf_b : P -= (1/s) V Y^T on 64-row blocks (fp16 MFMA, operands straight from L2 in fragment layout) and, from the updated values still
+//            in registers, the partial Gram matrix of the next leaf (fp64 MFMA, all 36 upper tiles: a block's rows are updated by ONE
+//            workgroup) -- gh_gram's loop, so gh_reduce + gh_solve follow unchanged.  Its first thread publishes the chain's progress word
+//            for the T stream (every earlier launch of the chain stream -- the leaf's reflectors and T -- is complete and visible).
+typedef half_t half8f __attribute__((ext_vector_type(8)));
+constexpr int FL_PT_OFF = (8256 + GW * GH_TS) * 4;                // byte offset of the staged next-panel tile in leaf_a's LDS
+constexpr int FL_VS_OFF = FL_PT_OFF + GW * 72 * 2;              // ... of V (fp32, row-major [64][132]) on its way to 16-byte global stores
+constexpr int FL_A_LDS = FL_VS_OFF + 64 * 132 * 4;
+// X partial: this wave's 32 columns of the next panel (c = 32 wave + ...) against all 128 reflectors, over the 64 rows in Pt / Ts
+__device__ __forceinline__ void fl_x_add(const half_t* Pt, const half_t* Ts, floatx16p (&xa)[4], int lane, int wave) {
+    const int r = lane & 31, h = lane >> 5;
+#pragma unroll
+    for (int ks = 0; ks < 4; ks++) {
+        const half8f av = *(const half8f*)&Pt[(32 * wave + r) * 72 + ks * 16 + 8 * h];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const half8f bv = *(const half8f*)&Ts[(32 * j + r) * 72 + ks * 16 + 8 * h];
+            xa[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, bv, xa[j], 0, 0, 0);
+        }
+    }
+}
+// stage 64 rows x 128 columns of the next panel (fp32, already in registers as 2 x 4 float4: thread block (mg, kg) = columns 4 mg .. +3 of
+// rows 4 kg .. +3) as Pt[column][row] = fp16(scale * value): four consecutive rows = one 8-byte LDS store (the GEMMs' A_F32T staging)
+__device__ __forceinline__ void fl_stage_pt(half_t* Pt, const float4 (&pv)[8], float sc, int tid) {
+    using gemm128::pack2;
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+        const int id = tid + 256 * i, mg = id & 31, kg = id >> 5;
+        const float4 v0 = pv[i * 4 + 0], v1 = pv[i * 4 + 1], v2 = pv[i * 4 + 2], v3 = pv[i * 4 + 3];
+        uint2 w;
+        half_t* base = Pt + (mg * 4) * 72 + kg * 4;
+        w.x = pack2(v0.x * sc, v1.x * sc); w.y = pack2(v2.x * sc, v3.x * sc); *(uint2*)(base) = w;
+        w.x = pack2(v0.y * sc, v1.y * sc); w.y = pack2(v2.y * sc, v3.y * sc); *(uint2*)(base + 72) = w;
+        w.x = pack2(v0.z * sc, v1.z * sc); w.y = pack2(v2.z * sc, v3.z * sc); *(uint2*)(base + 2 * 72) = w;
+        w.x = pack2(v0.w * sc, v1.w * sc); w.y = pack2(v2.w * sc, v3.w * sc); *(uint2*)(base + 3 * 72) = w;
+    }
+}
+__global__ __launch_bounds__(256) void leaf_a_kernel(LeafArgs a, const float* __restrict__ Cv, float* __restrict__ Sp, float* __restrict__ Xp,
+                                                     int nlow, int iters, int nb, float in_scale) {
+    float* As = (float*)gh_smem;                         // [64][129] = 8256 floats
+    float* Cs = (float*)gh_smem + 8256;                  // [128][GH_TS]
+    half_t* Ts = (half_t*)gh_smem;                       // [128][72] halves, reuses the As region after the MFMAs
+    half_t* Pt = (half_t*)(gh_smem + FL_PT_OFF);         // [128][72] halves: the next panel's rows, transposed
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    KT_DECL; KT();
+    floatx16p xa[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++)
+#pragma unroll
+        for (int e = 0; e < 16; e++) xa[q][e] = 0.f;
+    auto store_x = [&]() {
+        float* out = Xp + (long)blockIdx.x * (GW * GW);
+        const int r = lane & 31, h = lane >> 5;
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+#pragma unroll
+            for (int e = 0; e < 16; e++) out[(32 * wave + (e & 3) + 8 * (e >> 2) + 4 * h) * GW + 32 * j + r] = xa[j][e];
+    };
+    if ((int)blockIdx.x >= nlow) {                        // top-block rows: V^T tile straight from the fp16 copy gh_solve left
+        const int trow0 = a.c0 + ((int)blockIdx.x - nlow) * 64;
+        float4 pv[8];
+#pragma unroll
+        for (int i = 0; i < 2; i++) {
+            const int id = tid + 256 * i, mg = id & 31, kg = id >> 5;
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int row = trow0 + kg * 4 + j;
+                pv[i * 4 + j] = *(const float4*)(a.A + (long)min(row, a.mrows - 1) * a.lda + nb + 4 * mg);
+                if (row >= a.c1 || row >= a.mrows) pv[i * 4 + j] = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
+        for (int e = tid; e < GW * 64; e += 256) {
+            const int c = e & 127, lr = e >> 7, row = trow0 + lr, gc = a.cb + c;
+            half_t v = (half_t)0.f;
+            if (row < a.c1 && gc >= a.c0 && gc < a.c1 && row >= gc) v = a.Vh[(long)row * a.ldvh + gc];
+            Ts[c * 72 + lr] = v;
+        }
+        fl_stage_pt(Pt, pv, in_scale, tid);
+        __syncthreads();
+        gh_partial_gram(Ts, Sp + (long)blockIdx.x * (GW * GW), lane, wave);
+        fl_x_add(Pt, Ts, xa, lane, wave);
+        store_x();
+        return;
+    }
+    // low rows.  All global loads of a row block first (C -- once --, the leaf's rows, the next panel's rows: one memory latency), the exact-f32
+    // product V = A_low C with the triangular C's K blocks balanced over the waves, then V goes through LDS once more so that every global
+    // store is a whole 16-byte (fp32, into A) or 8-byte (fp16 copy) piece of a row -- as 4- and 2-byte stores straight from the MFMA layout
+    // (gh_apply_kernel) they were half of this kernel's time (in-kernel stamps, tools/ktrace_fl.sh).
+    float* Vs = (float*)(gh_smem + FL_VS_OFF);            // [64][132] fp32: V of this row block, row-major
+    floatx16p ga[3];
+#pragma unroll
+    for (int q = 0; q < 3; q++)
+#pragma unroll
+        for (int e = 0; e < 16; e++) ga[q][e] = 0.f;
+    float4 av[8], pv[8];
+    auto issue_loads = [&](int row0) {
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            const int id = tid + 256 * i, lr = id >> 5, c4 = id & 31, row = min(row0 + lr, a.mrows - 1);
+            av[i] = *(const float4*)(a.A + (long)row * a.lda + a.cb + 4 * c4);
+        }
+#pragma unroll
+        for (int i = 0; i < 2; i++) {
+            const int id = tid + 256 * i, mg = id & 31, kg = id >> 5;
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int row = row0 + kg * 4 + j;
+                pv[i * 4 + j] = *(const float4*)(a.A + (long)min(row, a.mrows - 1) * a.lda + nb + 4 * mg);
+            }
+        }
+    };
+    {   // C arrives in window coordinates, zero outside the leaf and below the diagonal; its loads and the first row block's in flight together
+        float4 cv[16];
+#pragma unroll
+        for (int q = 0; q < 16; q++) { const int e4 = tid + 256 * q; cv[q] = *(const float4*)&Cv[(e4 >> 5) * GW + (e4 & 31) * 4]; }
+        issue_loads(a.c1 + (int)blockIdx.x * iters * 64);
+#pragma unroll
+        for (int q = 0; q < 16; q++) { const int e4 = tid + 256 * q; *(float4*)&Cs[(e4 >> 5) * GH_TS + (e4 & 31) * 4] = cv[q]; }
+    }
+    for (int it = 0; it < iters; it++) {
+    const int row0 = a.c1 + ((int)blockIdx.x * iters + it) * 64;
+    if (row0 >= a.mrows) break;
+    if (it) { __syncthreads(); issue_loads(row0); }        // (the previous block's V^T rows and next-panel rows have been read)
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        const int id = tid + 256 * i, lr = id >> 5, c4 = id & 31, row = row0 + lr;
+        const float4 v = (row < a.mrows) ? av[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+        float* d = &As[lr * 129 + 4 * c4];
+        d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+    }
+    __syncthreads();
+    KT();
+    floatx16p acc0, acc1;
+#pragma unroll
+    for (int e = 0; e < 16; e++) { acc0[e] = 0.f; acc1[e] = 0.f; }
+    // C is upper triangular (C[k][j] = 0 for k > j): column tile ct needs k < 32 (ct + 1).  Wave w takes rows 0-31 of column tile w and
+    // rows 32-63 of column tile 3 - w: five K blocks of 32 per wave (gh_apply_kernel: both row tiles of column tile w, up to eight)
+    const int r = lane & 31, kk = lane >> 5;
+    const int nA = 32 * wave, nB = 32 * (3 - wave);
+    const int kendA = nA + 32, kendB = nB + 32;
+    for (int k1 = 0; k1 < GW; k1 += 16) {
+        if (k1 < kendA) {
+            float a0[8], b[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) { const int k = k1 + 2 * u + kk; a0[u] = As[r * 129 + k]; b[u] = Cs[k * GH_TS + nA + r]; }
+#pragma unroll
+            for (int u = 0; u < 8; u++) acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[u], b[u], acc0, 0, 0, 0);
+        }
+        if (k1 < kendB) {
+            float a1[8], b[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) { const int k = k1 + 2 * u + kk; a1[u] = As[(32 + r) * 129 + k]; b[u] = Cs[k * GH_TS + nB + r]; }
+#pragma unroll
+            for (int u = 0; u < 8; u++) acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[u], b[u], acc1, 0, 0, 0);
+        }
+    }
+    __syncthreads();                                     // As is dead: reuse as the transpose buffer
+    KT();
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+        const int id = tid + 256 * i, kg = id >> 5;
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+            if (row0 + kg * 4 + j >= a.mrows) pv[i * 4 + j] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    fl_stage_pt(Pt, pv, in_scale, tid);                    // (the next panel's rows landed during the product)
+#pragma unroll
+    for (int mt = 0; mt < 2; mt++) {
+        const int n0 = mt == 0 ? nA : nB;
+#pragma unroll
+        for (int e = 0; e < 16; e++) {
+            const int lm = mt * 32 + (e & 3) + 8 * (e >> 2) + 4 * kk;
+            const float v = mt == 0 ? acc0[e] : acc1[e];
+            Vs[lm * 132 + n0 + r] = v;
+            Ts[(n0 + r) * 72 + lm] = (half_t)v;
+        }
+    }
+    __syncthreads();
+    KT();
+    {
+        typedef half_t half4a __attribute__((ext_vector_type(4)));
+        const bool whole = a.c0 == a.cb && a.c1 == a.cb + GW;       // the leaf fills its window (the fused path's case)
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            const int id = tid + 256 * i, lr = id >> 5, c4 = id & 31, row = row0 + lr;
+            if (row >= a.mrows) continue;
+            const float4 v = *(const float4*)&Vs[lr * 132 + 4 * c4];
+            const int gc = a.cb + 4 * c4;
+            if (whole) {
+                *(float4*)(a.A + (long)row * a.lda + gc) = v;
+                half4a hv; hv[0] = (half_t)v.x; hv[1] = (half_t)v.y; hv[2] = (half_t)v.z; hv[3] = (half_t)v.w;
+                *(half4a*)(a.Vh + (long)row * a.ldvh + gc) = hv;
+            } else {
+                const float vv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int c = 0; c < 4; c++)
+                    if (gc + c >= a.c0 && gc + c < a.c1) { a.A[(long)row * a.lda + gc + c] = vv[c]; a.Vh[(long)row * a.ldvh + gc + c] = (half_t)vv[c]; }
+            }
+        }
+    }
+    gh_partial_gram_add(Ts, ga, lane, wave);
+    fl_x_add(Pt, Ts, xa, lane, wave);
+    KT();
+    // V^T rows: 128 columns x 64 rows of this workgroup, 16-B chunks along the row index
+    for (int e = tid; e < GW * 8; e += 256) {
+        const int c = e >> 3, ch = e & 7;
+        const int gcol = a.cb + c;
+        if (gcol >= a.c0 && gcol < a.c1) {
+            half_t* dst = a.Vt + (long)gcol * a.ldvt + row0 + 8 * ch;
+            if ((row0 & 7) == 0 && row0 + 8 * ch + 8 <= a.mrows) {
+                *(uint4*)dst = *(const uint4*)&Ts[c * 72 + 8 * ch];
+            } else {
+                for (int q = 0; q < 8; q++)
+                    if (row0 + 8 * ch + q < a.mrows) dst[q] = Ts[c * 72 + 8 * ch + q];
+            }
+        }
+    }
+    }                                                      // row blocks
+    KT();
+    gh_partial_gram_store(ga, Sp + (long)blockIdx.x * (GW * GW), lane, wave);
+    store_x();
+    KT(); KT_DUMP(2, "leaf_a loads+stage A,C|mfma|stage P,V|store V+gram+x|vt|store partials");
+}
+
+struct LeafM2Args {
+    const float* Sp; const float* Xp; int nslab;          // gh_num_partials partial Gram matrices / partial X's (128 x 128 each)
+    float* S; float* Xs; int ngrp;                        // sums: ngrp windows each (the partials are cut into ngrp ranges)
+    int* counter;                                         // zero between launches (the last arriver resets it)
+    int sh, a0, c0, c1; float* T; half_t* Th; half_t* Tth; int ldt, ld;
+    half_t* Y;                                            // [128 columns of the next panel][128 reflectors]
+};
+typedef half_t half4m __attribute__((ext_vector_type(4)));
+typedef float float4m __attribute__((ext_vector_type(4)));
+// 1024 threads: the tail (one workgroup: loads of S and X, the inverse, Y, the stores of T) is latency- and issue-bound per thread; with 256
+// threads it took 29 us of the kernel's 40 (in-kernel stamps, tools/ktrace_fl.sh), and the sixteen waves of a reducer take the partials in ONE
+// batch of loads each.
+__global__ __launch_bounds__(1024) void leaf_m_kernel(LeafM2Args m) {
+    const int nred = MID_RB * m.ngrp;                        // reducers per matrix (S first, then X)
+    __shared__ float4 part[16][64];
+    __shared__ float tdiag[TP];
+    __shared__ int is_last;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+#ifdef MPQR_KTRACE
+    long kt_[16]; int kn_ = 0; const bool kon_ = (threadIdx.x == 0);
+#endif
+    KT();
+    const int kind = (int)blockIdx.x / nred, b = (int)blockIdx.x % nred;      // 0: S, 1: X
+    const int grp = b / MID_RB;
+    const int q_lo = (int)((long)m.nslab * grp / m.ngrp), q_hi = (int)((long)m.nslab * (grp + 1) / m.ngrp);
+    const int e = ((b % MID_RB) * 64 + lane) * 4;            // four consecutive entries of one row of the window
+    const bool act = kind ? true : (((e >> 7) >> 5) <= ((e & 127) >> 5));      // S: the partials hold the 10 upper 32 x 32 tiles only
+    const float* src = kind ? m.Xp : m.Sp;
+    float* dst = (kind ? m.Xs : m.S) + (long)grp * (GW * GW);
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (act) {                                               // wave w: partials q_lo + w, + 16, ...; 16 loads in flight, four interleaved chains
+        float4 s0 = s, s1 = s, s2 = s, s3 = s;
+        auto add = [](float4& a, const float4& b) { a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w; };
+        for (int q = q_lo + wave; q < q_hi; q += 256) {
+            float4 v[16];
+#pragma unroll
+            for (int u = 0; u < 16; u++) v[u] = *(const float4*)&src[(long)min(q + 16 * u, q_hi - 1) * (GW * GW) + e];
+#pragma unroll
+            for (int u = 0; u < 16; u++) if (q + 16 * u >= q_hi) v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int u = 0; u < 16; u += 4) { add(s0, v[u]); add(s1, v[u + 1]); add(s2, v[u + 2]); add(s3, v[u + 3]); }
+        }
+        s.x = (s0.x + s1.x) + (s2.x + s3.x); s.y = (s0.y + s1.y) + (s2.y + s3.y);
+        s.z = (s0.z + s1.z) + (s2.z + s3.z); s.w = (s0.w + s1.w) + (s2.w + s3.w);
+    }
+    part[wave][lane] = s;
+    __syncthreads();
+    if (wave == 0) {
+        float4 t[4];
+#pragma unroll
+        for (int g4 = 0; g4 < 4; g4++) {                     // fixed order: ((p0 + p1) + (p2 + p3)) per group of four waves, then the same over the groups
+            const float4 p0 = part[4 * g4][lane], p1 = part[4 * g4 + 1][lane], p2 = part[4 * g4 + 2][lane], p3 = part[4 * g4 + 3][lane];
+            t[g4] = make_float4((p0.x + p1.x) + (p2.x + p3.x), (p0.y + p1.y) + (p2.y + p3.y), (p0.z + p1.z) + (p2.z + p3.z), (p0.w + p1.w) + (p2.w + p3.w));
+        }
+        float4m r4;
+        r4[0] = (t[0].x + t[1].x) + (t[2].x + t[3].x); r4[1] = (t[0].y + t[1].y) + (t[2].y + t[3].y);
+        r4[2] = (t[0].z + t[1].z) + (t[2].z + t[3].z); r4[3] = (t[0].w + t[1].w) + (t[2].w + t[3].w);
+        // one 16-byte store with sc1 (write-through: the hand-off table's producer side)
+        const __amdgpu_buffer_rsrc_t rs_d = __builtin_amdgcn_make_buffer_rsrc((void*)dst, 0, 0x7fffffff, 0x00020000);
+        typedef unsigned u4s __attribute__((ext_vector_type(4)));
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4s, r4), rs_d, e * 4, 0, 16);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the stores have left before this workgroup signals
+    }
+    __syncthreads();
+    if (tid == 0) is_last = __hip_atomic_fetch_add(m.counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 2 * nred - 1;
+    __syncthreads();
+    if (!is_last) return;
+    KT();
+    if (tid == 0) __hip_atomic_store(m.counter, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // S and X were written (sc1, drained) by other workgroups of this launch: every load of them is a 16-byte buffer load with sc1 (aux bit 4;
+    // MI355X_MICROARCH.md's hand-off table lists buffer_load_dwordx4 sc1 for the consumer side), all of a lane's loads in flight together.
+    // X in MFMA fragment layout (v_mfma_f32_16x16x16_f16, A operand: lane (li, lg) = row li, k = 4 lg .. 4 lg + 3): wave w takes the 16 rows
+    // of row tile w % 8 and the column tiles 4 (w / 8) .. + 3.  S: four consecutive entries of a row per load (the fused path takes full,
+    // aligned leaves: window = leaf, sh = 0).
+    const int li = lane & 15, lg = lane >> 4;
+    const int rtile = wave & 7, nhalf = wave >> 3;
+    const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc((void*)m.Xs, 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_s = __builtin_amdgcn_make_buffer_rsrc((void*)m.S, 0, 0x7fffffff, 0x00020000);
+    float4m xr[8], sv[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) sv[q] = __builtin_bit_cast(float4m, __builtin_amdgcn_raw_buffer_load_b128(rs_s, (tid + 1024 * q) * 16, 0, 16));
+#pragma unroll
+    for (int ks = 0; ks < 8; ks++)
+        xr[ks] = __builtin_bit_cast(float4m, __builtin_amdgcn_raw_buffer_load_b128(rs_x, ((16 * rtile + li) * GW + 16 * ks + 4 * lg) * 4, 0, 16));
+    for (int g = 1; g < m.ngrp; g++) {
+#pragma unroll
+        for (int q = 0; q < 4; q++) sv[q] += __builtin_bit_cast(float4m, __builtin_amdgcn_raw_buffer_load_b128(rs_s, (g * GW * GW + (tid + 1024 * q) * 4) * 4, 0, 16));
+#pragma unroll
+        for (int ks = 0; ks < 8; ks++)
+            xr[ks] += __builtin_bit_cast(float4m, __builtin_amdgcn_raw_buffer_load_b128(rs_x, (g * GW * GW + (16 * rtile + li) * GW + 16 * ks + 4 * lg) * 4, 0, 16));
+    }
+    float* Ss = (float*)gh_smem;
+    float* Ts = Ss + TP * TPS;
+    KT();
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const int e4 = tid + 1024 * q, i = e4 >> 5, j = (e4 & 31) * 4;
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+            float v = (j + c >= i) ? sv[q][c] : 0.f;
+            if (i == j + c) { tdiag[i] = v > 0.f ? 2.0f / v : 0.f; v = 0.f; }
+            Ss[i * TPS + j + c] = v;
+            Ts[i * TPS + j + c] = 0.f;
+        }
+    }
+    __syncthreads();
+    tri_inverse_128(Ss, tdiag, Ts, 4, tid);
+    KT();
+    // Y[c][n] = fp16( tau_n * sum_k (X_hi + X_lo)[c][k] * fp16(T[k][n] / tau_n) ),  k <= n  -- leaf_xt_kernel's arithmetic with Bt = T^T's fp16
+    // copy (t_panel_store: Tth[n][k] = fp16(T[k][n] * (1 / T[n][n]))), formed here from the fp32 T in LDS
+    {
+        half4m xh[8], xl[8];
+#pragma unroll
+        for (int ks = 0; ks < 8; ks++)
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+                const half_t hv = (half_t)xr[ks][c];
+                xh[ks][c] = hv; xl[ks][c] = (half_t)(xr[ks][c] - (float)hv);
+            }
+#pragma unroll
+        for (int cq = 0; cq < 4; cq++) {
+            const int ct = 4 * nhalf + cq;
+            const int n = 16 * ct + li;
+            const float tnn = Ts[n * TPS + n];
+            const float rti = tnn != 0.f ? 1.0f / tnn : 0.f;
+            float4m acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < 8; ks++) {
+                if (ks > ct) continue;                        // T^T rows end at the diagonal (tri == 2); wave-uniform
+                half4m bv;
+#pragma unroll
+                for (int c = 0; c < 4; c++) {
+                    const int k = 16 * ks + 4 * lg + c;
+                    bv[c] = (half_t)((k <= n ? Ts[k * TPS + n] : 0.f) * rti);
+                }
+                acc = __builtin_amdgcn_mfma_f32_16x16x16f16(xh[ks], bv, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x16f16(xl[ks], bv, acc, 0, 0, 0);
+            }
+#pragma unroll
+            for (int e2 = 0; e2 < 4; e2++) m.Y[(long)(16 * rtile + 4 * lg + e2) * GW + n] = (half_t)(tnn * acc[e2]);
+        }
+    }
+    KT();
+    t_panel_store<1024>(Ts, m.a0, m.c0, m.c1, m.T, m.Th, m.Tth, m.ldt, m.ld);
+    KT(); KT_DUMP(7, "leaf_m reduce+arrive|loads issue|fill+invert|Y|store T");
+}
+
+// P[rows >= c0][nb .. nb + 128) -= alpha V Y^T  (V = the leaf's fp16 reflectors, Y from leaf_m), 64 rows per workgroup, and the partial Gram
+// matrix (fp64, upper 16 x 16 tiles) of the updated rows from c1 on: the next leaf's gh_gram.  Workgroups 0 / 1 take the leaf's top rows
+// [c0, c1) -- R rows, no Gram --, workgroup 2 + p the rows c1 + 64 (p iters + it).
+constexpr int FL_B_ROWS = 64;
+__global__ __launch_bounds__(256) void leaf_b_kernel(LeafArgs a, int nb, const half_t* __restrict__ Y, float alpha, double* __restrict__ Gp,
+                                                     int iters, int do_gram, int* pub_flag, int pub_value) {
+    if (pub_flag && blockIdx.x == 0 && threadIdx.x == 0) __hip_atomic_store(pub_flag, pub_value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    double* tile = (double*)gh_smem;                      // [64][GH_TD] doubles
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5, li = lane & 15, lk = lane >> 4;
+#ifdef MPQR_KTRACE
+    long kt_[16]; int kn_ = 0; const bool kon_ = (threadIdx.x == 0 && blockIdx.x == 2);
+#endif
+    KT();
+    const bool top = blockIdx.x < 2;
+    const int p = (int)blockIdx.x - 2;
+    typedef double double4g __attribute__((ext_vector_type(4)));
+    // Gram tiles of this wave: t = wave + 4 s (s < 9) among the 36 upper tiles of the 8 x 8 tile grid, row-major
+    int ca[9], cb[9];
+    double4g acc[9];
+#pragma unroll
+    for (int s = 0; s < 9; s++) {
+        int t = wave + 4 * s, ti = 0;
+        while (t >= 8 - ti) { t -= 8 - ti; ti++; }
+        ca[s] = 16 * ti; cb[s] = 16 * (ti + t);
+        acc[s] = double4g{0, 0, 0, 0};
+    }
+    const int rt = wave & 1, cp = wave >> 1;               // this wave's 32-row tile and pair of 32-column tiles of the 64 x 128 block
+    for (int it = 0; it < (top ? 1 : iters); it++) {
+        const int row0 = top ? a.c0 + (int)blockIdx.x * 64 : a.c1 + (p * iters + it) * FL_B_ROWS;
+        const int rend = top ? a.c1 : a.mrows;
+        if (row0 >= rend) break;
+        if (it) __syncthreads();
+        // operands in MFMA fragment layout straight from global memory (L2): V rows (k = reflector, 16-B = 8 reflectors), Y rows, old values
+        half8f va[8], yb[2][8];
+        float oldv[2][16];
+        const int vrow = min(row0 + 32 * rt + r, a.mrows - 1);
+#pragma unroll
+        for (int ks = 0; ks < 8; ks++) va[ks] = *(const half8f*)&a.Vh[(long)vrow * a.ldvh + a.c0 + 16 * ks + 8 * h];
+#pragma unroll
+        for (int j = 0; j < 2; j++)
+#pragma unroll
+            for (int ks = 0; ks < 8; ks++) yb[j][ks] = *(const half8f*)&Y[(long)(64 * cp + 32 * j + r) * GW + 16 * ks + 8 * h];
+#pragma unroll
+        for (int j = 0; j < 2; j++)
+#pragma unroll
+            for (int e = 0; e < 16; e++) {
+                const int row = min(row0 + 32 * rt + (e & 3) + 8 * (e >> 2) + 4 * h, a.mrows - 1);
+                oldv[j][e] = a.A[(long)row * a.lda + nb + 64 * cp + 32 * j + r];
+            }
+        floatx16p ua[2];
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+#pragma unroll
+            for (int e = 0; e < 16; e++) ua[j][e] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < 8; ks++) ua[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(va[ks], yb[j][ks], ua[j], 0, 0, 0);
+        }
+#pragma unroll
+        for (int j = 0; j < 2; j++)
+#pragma unroll
+            for (int e = 0; e < 16; e++) {
+                const int lr = 32 * rt + (e & 3) + 8 * (e >> 2) + 4 * h, row = row0 + lr, col = 64 * cp + 32 * j + r;
+                const float nv = oldv[j][e] - alpha * ua[j][e];
+                const bool valid = row < rend;
+                if (valid) a.A[(long)row * a.lda + nb + col] = nv;
+                if (!top) tile[lr * GH_TD + col] = valid ? (double)nv : 0.0;
+            }
+        if (top || !do_gram) continue;
+        __syncthreads();
+        KT();
+        for (int k0 = 0; k0 < FL_B_ROWS; k0 += 8) {        // gh_gram_kernel's loop (two K steps per iteration), nine tiles per wave
+            const double* tr0 = &tile[(k0 + lk) * GH_TD + li];
+            const double* tr1 = tr0 + 4 * GH_TD;
+            double a0[9], b0[9], a1[9], b1[9];
+#pragma unroll
+            for (int s = 0; s < 9; s++) { a0[s] = tr0[ca[s]]; b0[s] = tr0[cb[s]]; a1[s] = tr1[ca[s]]; b1[s] = tr1[cb[s]]; }
+#pragma unroll
+            for (int s = 0; s < 9; s++) acc[s] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[s], b0[s], acc[s], 0, 0, 0);
+#pragma unroll
+            for (int s = 0; s < 9; s++) acc[s] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[s], b1[s], acc[s], 0, 0, 0);
+        }
+    }
+    if (top || !do_gram) return;
+    KT();
+    double* out = Gp + (long)p * (GW * GW);
+#pragma unroll
+    for (int s = 0; s < 9; s++)
+#pragma unroll
+        for (int v = 0; v < 4; v++) out[(ca[s] + lk + 4 * v) * GW + cb[s] + li] = acc[s][v];   // upper tiles only: gh_reduce mirrors
+    KT(); KT_DUMP(5, "leaf_b load+update+tile|gram mfma|store");
+}
+
+int fl_gram_partials(const LeafArgs& a) {                   // partial Gram matrices leaf_b leaves for the NEXT leaf (rows from a.c1 on)
+    const int rows = a.mrows - a.c1;
+    const int it = rows >= 49152 ? 4 : rows >= 24576 ? 2 : 1;
+    return ((rows + FL_B_ROWS - 1) / FL_B_ROWS + it - 1) / it;
+}
+void launch_leaf_a(const LeafArgs& a, const float* Cv, float* Sp, float* Xp, int nb, float in_scale, hipStream_t s) {
+    MPQR_ONCE_PER_DEVICE((void)hipFuncSetAttribute((const void*)leaf_a_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, FL_A_LDS));
+    const int it = gh_apply_iters(a);
+    const int nlow = ((a.mrows - a.c1 + 63) / 64 + it - 1) / it;
+    const int ntop = (a.c1 - a.c0 + 63) / 64;
+    hipLaunchKernelGGL(leaf_a_kernel, dim3(nlow + ntop), dim3(256), FL_A_LDS, s, a, Cv, Sp, Xp, nlow, it, nb, in_scale);
+}
+void launch_leaf_m(const float* Sp, const float* Xp, int nslab, float* S, float* Xs, int* counter, int sh, int a0, int c0, int c1,
+                   float* T, half_t* Th, half_t* Tth, int ldt, int ld, half_t* Y, hipStream_t s) {
+    constexpr int LDS = 2 * TP * TPS * 4;
+    MPQR_ONCE_PER_DEVICE((void)hipFuncSetAttribute((const void*)leaf_m_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+    LeafM2Args m{};
+    m.Sp = Sp; m.Xp = Xp; m.nslab = nslab; m.S = S; m.Xs = Xs; m.counter = counter;
+    m.ngrp = std::max(1, std::min(LEAF_MID_MAX_GROUPS, nslab / 256));
+    m.sh = sh; m.a0 = a0; m.c0 = c0; m.c1 = c1; m.T = T; m.Th = Th; m.Tth = Tth; m.ldt = ldt; m.ld = ld <= 0 ? ldt : ld; m.Y = Y;
+    hipLaunchKernelGGL(leaf_m_kernel, dim3(2 * MID_RB * m.ngrp), dim3(1024), LDS, s, m);
+}
+void launch_leaf_b(const LeafArgs& a, int nb, const half_t* Y, float alpha, double* Gp, bool do_gram, int* pub_flag, int pub_value, hipStream_t s) {
+    constexpr int LDS = FL_B_ROWS * GH_TD * 8;
+    MPQR_ONCE_PER_DEVICE((void)hipFuncSetAttribute((const void*)leaf_b_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+    const int rows = a.mrows - a.c1;
+    const int it = rows >= 49152 ? 4 : rows >= 24576 ? 2 : 1;
+    const int ng = rows > 0 ? ((rows + FL_B_ROWS - 1) / FL_B_ROWS + it - 1) / it : 0;
+    hipLaunchKernelGGL(leaf_b_kernel, dim3(2 + ng), dim3(256), LDS, s, a, nb, Y, alpha, Gp, it, do_gram ? 1 : 0, pub_flag, pub_value);
+}
+// the reduction of leaf_b's partials (the second half of launch_gh_gram)
+void launch_gh_gram_reduce(const double* Gp, int nwg, double* G, hipStream_t s) {
+    hipLaunchKernelGGL(gh_reduce_kernel, dim3(256), dim3(256), 0, s, Gp, nwg, G);
 }
 
 // fp16 copies of one column block of a block-level T: Th[0:rows, c:c+w] = T[0:rows, c:c+w], Tth[c:c+w, 0:rows] = its transpose

@@ -153,6 +153,17 @@ void launch_gh_reduce_f32(const float* Sp, int nslab, float* S, hipStream_t s);
 constexpr int LEAF_MID_MAX_GROUPS = 4;      // S must hold this many 128 x 128 windows
 void launch_leaf_mid(const GemmArgs& g1, const float* Sp, int nslab, float* S, int sh, int* counter, int a0, int c0, int c1,
                      float* T, half_t* Th, half_t* Tth, int ldt, int ld, hipStream_t s);
+// Fused leaf (round 5, kernels_panel.hip): the chain stream's work between two solves in three launches that touch only the NEXT leaf's 128
+// columns [nb, nb + 128).  leaf_a = gh_apply + partial X = (in_scale P)^T V over the same row blocks (Xp: one 128 x 128 fp32 partial per
+// workgroup, gh_num_partials(a) of them, like Sp); leaf_m = sums of the partials, T of the leaf and Y = fp16(X T') (Y: 128 x 128 fp16,
+// [column of the next panel][reflector]); leaf_b = P -= alpha V Y^T and, if do_gram, the next leaf's partial Gram matrices (fl_gram_partials(a) of
+// them in Gp, for launch_gh_gram_reduce + launch_gh_solve); it also publishes pub_value in *pub_flag (launch_wait_flag's word).
+void launch_leaf_a(const LeafArgs& a, const float* Cv, float* Sp, float* Xp, int nb, float in_scale, hipStream_t s);
+void launch_leaf_m(const float* Sp, const float* Xp, int nslab, float* S, float* Xs, int* counter, int sh, int a0, int c0, int c1,
+                   float* T, half_t* Th, half_t* Tth, int ldt, int ld, half_t* Y, hipStream_t s);
+void launch_leaf_b(const LeafArgs& a, int nb, const half_t* Y, float alpha, double* Gp, bool do_gram, int* pub_flag, int pub_value, hipStream_t s);
+int fl_gram_partials(const LeafArgs& a);
+void launch_gh_gram_reduce(const double* Gp, int nwg, double* G, hipStream_t s);
 void launch_t_leaf(const float* S, int nslab, long slab_stride, int lds_, int a0, int c0, int c1,
                    float* T, half_t* Th, half_t* Tth, int ldt, hipStream_t s, int ld = 0);
 // fp16 copies (plain and transposed) of column block [c, c+w) x rows [0, rows) of a T with leading dimension ld

@@ -18,7 +18,7 @@ solves = [r for r in run if 'gh_solve' in r['Kernel_Name']]
 cq = solves[0]['Queue_Id']
 chain = [r for r in run if r['Queue_Id'] == cq]
 first = next(i for i, r in enumerate(chain) if 'gh_gram' in r['Kernel_Name'])
-last = max(i for i, r in enumerate(chain) if 'gh_apply' in r['Kernel_Name'])
+last = max(i for i, r in enumerate(chain) if 'gh_apply' in r['Kernel_Name'] or 'leaf_a_kernel' in r['Kernel_Name'])
 chain = chain[first:last + 1]
 span = (chain[-1]['e'] - chain[0]['s']) / 1e3
 solves = [r for r in chain if 'gh_solve' in r['Kernel_Name']]      # (bench.py's stand-alone solve timing comes after the slice)
@@ -29,7 +29,7 @@ leaf = -1; gaps = []
 prev_e = chain[0]['s']
 for r in chain:
     n = short(r['Kernel_Name'])
-    if 'gh_gram' in n: leaf += 1
+    if 'gh_reduce_kernel' in r['Kernel_Name']: leaf += 1      # (one per leaf: behind gh_gram, or behind the fused leaf's leaf_b)
     g = max(0, r['s'] - prev_e) / 1e3; d = (r['e'] - r['s']) / 1e3
     busy[n] += d; gap[n] += g; cnt[n] += 1
     pos_gap[leaf % 8] += g; pos_busy[leaf % 8] += d
@@ -39,9 +39,9 @@ print("%-30s %6s %9s %9s %9s" % ("kernel", "calls", "busy ms", "idle ms", "avg i
 for n in sorted(busy, key=lambda k: -(busy[k] + gap[k])):
     print("%-30s %6d %9.2f %9.2f %9.1f" % (n, cnt[n], busy[n] / 1e3, gap[n] / 1e3, gap[n] / cnt[n]))
 print("total busy %.2f ms, idle %.2f ms" % (sum(busy.values()) / 1e3, sum(gap.values()) / 1e3))
-grams = [r for r in chain if 'gh_gram' in r['Kernel_Name']]
+grams = [r for r in chain if 'gh_solve' in r['Kernel_Name']]
 per = [(b['s'] - a['s']) / 1e3 for a, b in zip(grams, grams[1:])]
-print("leaf periods (gh_gram to gh_gram, us) per top-level block of 8 leaves:")
+print("leaf periods (gh_solve to gh_solve, us) per top-level block of 8 leaves:")
 for blk in range(0, (len(per) + 7) // 8):
     p8 = per[8 * blk:8 * blk + 8]
     print("  block %2d: %s  sum %.0f" % (blk, " ".join("%4.0f" % x for x in p8), sum(p8)))
