@@ -1244,6 +1244,11 @@ __device__ __forceinline__ void fl_stage_pt(half_t* Pt, const float4 (&pv)[8], f
         w.x = pack2(v0.w * sc, v1.w * sc); w.y = pack2(v2.w * sc, v3.w * sc); *(uint2*)(base + 3 * 72) = w;
     }
 }
+// workgroup b of n -> row block i with (ab0 + i) % 8 == b % 8 (a rotation inside every complete group of eight; the last, incomplete group keeps i = b)
+__device__ __forceinline__ int fl_row_block(int b, int n, int ab0) {
+    if ((b | 7) >= n) return b;
+    return (b & ~7) + ((b - ab0) & 7);
+}
 __global__ __launch_bounds__(256) void leaf_a_kernel(LeafArgs a, const float* __restrict__ Cv, float* __restrict__ Sp, float* __restrict__ Xp,
                                                      int nlow, int iters, int nb, float in_scale) {
     float* As = (float*)gh_smem;                         // [64][129] = 8256 floats
@@ -1257,8 +1262,8 @@ __global__ __launch_bounds__(256) void leaf_a_kernel(LeafArgs a, const float* __
     for (int q = 0; q < 4; q++)
 #pragma unroll
         for (int e = 0; e < 16; e++) xa[q][e] = 0.f;
-    auto store_x = [&]() {
-        float* out = Xp + (long)blockIdx.x * (GW * GW);
+    auto store_x = [&](int slot) {
+        float* out = Xp + (long)slot * (GW * GW);
         const int r = lane & 31, h = lane >> 5;
 #pragma unroll
         for (int j = 0; j < 4; j++)
@@ -1288,7 +1293,7 @@ __global__ __launch_bounds__(256) void leaf_a_kernel(LeafArgs a, const float* __
         __syncthreads();
         gh_partial_gram(Ts, Sp + (long)blockIdx.x * (GW * GW), lane, wave);
         fl_x_add(Pt, Ts, xa, lane, wave);
-        store_x();
+        store_x((int)blockIdx.x);
         return;
     }
     // low rows.  All global loads of a row block first (C -- once --, the leaf's rows, the next panel's rows: one memory latency), the exact-f32
@@ -1318,16 +1323,21 @@ __global__ __launch_bounds__(256) void leaf_a_kernel(LeafArgs a, const float* __
             }
         }
     };
+    // XCD-aware block -> rows mapping (speed only): workgroups b and b + 8 share an XCD and its L2 (observed round-robin placement,
+    // MI355X_MICROARCH.md), so the 64-row block with ABSOLUTE index ab (row / 64 / iters) goes to a workgroup with b % 8 == ab % 8 -- in every
+    // launch of leaf_a and leaf_b, for every leaf: the rows leaf_b wrote (the next panel) are read by the next leaf's leaf_a on the same XCD,
+    // and leaf_b finds the reflector rows leaf_a has just written, and the panel rows it read, in its own L2.
+    const int rb = fl_row_block((int)blockIdx.x, nlow, a.c1 / (64 * iters));
     {   // C arrives in window coordinates, zero outside the leaf and below the diagonal; its loads and the first row block's in flight together
         float4 cv[16];
 #pragma unroll
         for (int q = 0; q < 16; q++) { const int e4 = tid + 256 * q; cv[q] = *(const float4*)&Cv[(e4 >> 5) * GW + (e4 & 31) * 4]; }
-        issue_loads(a.c1 + (int)blockIdx.x * iters * 64);
+        issue_loads(a.c1 + rb * iters * 64);
 #pragma unroll
         for (int q = 0; q < 16; q++) { const int e4 = tid + 256 * q; *(float4*)&Cs[(e4 >> 5) * GH_TS + (e4 & 31) * 4] = cv[q]; }
     }
     for (int it = 0; it < iters; it++) {
-    const int row0 = a.c1 + ((int)blockIdx.x * iters + it) * 64;
+    const int row0 = a.c1 + (rb * iters + it) * 64;
     if (row0 >= a.mrows) break;
     if (it) { __syncthreads(); issue_loads(row0); }        // (the previous block's V^T rows and next-panel rows have been read)
 #pragma unroll
@@ -1426,8 +1436,8 @@ __global__ __launch_bounds__(256) void leaf_a_kernel(LeafArgs a, const float* __
     }
     }                                                      // row blocks
     KT();
-    gh_partial_gram_store(ga, Sp + (long)blockIdx.x * (GW * GW), lane, wave);
-    store_x();
+    gh_partial_gram_store(ga, Sp + (long)rb * (GW * GW), lane, wave);
+    store_x(rb);
     KT(); KT_DUMP(2, "leaf_a loads+stage A,C|mfma|stage P,V|store V+gram+x|vt|store partials");
 }
 
@@ -1593,7 +1603,10 @@ __global__ __launch_bounds__(256) void leaf_b_kernel(LeafArgs a, int nb, const h
 #endif
     KT();
     const bool top = blockIdx.x < 2;
-    const int p = (int)blockIdx.x - 2;
+    const int ngram = (int)gridDim.x - 2;
+    // (XCD-aware: the block with absolute index ab goes to a workgroup with blockIdx % 8 == ab % 8 -- see leaf_a_kernel; workgroup g = 2 + u)
+    const int u = (int)blockIdx.x - 2;
+    const int p = top ? 0 : (((u | 7) >= ngram) ? u : (u & ~7) + ((u + 2 - a.c1 / (FL_B_ROWS * iters)) & 7));
     typedef double double4g __attribute__((ext_vector_type(4)));
     // Gram tiles of this wave: t = wave + 4 s (s < 9) among the 36 upper tiles of the 8 x 8 tile grid, row-major
     int ca[9], cb[9];
@@ -1642,13 +1655,18 @@ __global__ __launch_bounds__(256) void leaf_b_kernel(LeafArgs a, int nb, const h
             for (int e = 0; e < 16; e++) {
                 const int lr = 32 * rt + (e & 3) + 8 * (e >> 2) + 4 * h, row = row0 + lr, col = 64 * cp + 32 * j + r;
                 const float nv = oldv[j][e] - alpha * ua[j][e];
-                const bool valid = row < rend;
-                if (valid) a.A[(long)row * a.lda + nb + col] = nv;
-                if (!top) tile[lr * GH_TD + col] = valid ? (double)nv : 0.0;
+                tile[lr * GH_TD + col] = row < rend ? (double)nv : 0.0;      // (exact: the Gram matrix and the stores below see the fp32 value)
             }
-        if (top || !do_gram) continue;
         __syncthreads();
         KT();
+        // the updated rows go out as whole 16-byte pieces (as 4-byte stores straight from the MFMA layout they cost this kernel ~3 us)
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            const int id = tid + 256 * i, lr = id >> 5, c4 = id & 31, row = row0 + lr;
+            const double2 d0 = *(const double2*)&tile[lr * GH_TD + 4 * c4], d1 = *(const double2*)&tile[lr * GH_TD + 4 * c4 + 2];
+            if (row < rend) *(float4*)(a.A + (long)row * a.lda + nb + 4 * c4) = make_float4((float)d0.x, (float)d0.y, (float)d1.x, (float)d1.y);
+        }
+        if (top || !do_gram) continue;
         for (int k0 = 0; k0 < FL_B_ROWS; k0 += 8) {        // gh_gram_kernel's loop (two K steps per iteration), nine tiles per wave
             const double* tr0 = &tile[(k0 + lk) * GH_TD + li];
             const double* tr1 = tr0 + 4 * GH_TD;
