@@ -76,7 +76,9 @@ def gemm_source_sha():
     """sha256 (16 hex digits) of the sources the dominant GEMM kernel is built from: ties a committed PMC profile to a build."""
     import hashlib
     hsh = hashlib.sha256()
-    for f in ("kernels_gemm2.hip", "gemm_epilogue.h", "mpqr_internal.h"):
+    # (every source the GEMM kernels are compiled from; mpqr_internal.h is left out since round 5: it also declares the panel kernels'
+    #  launchers, and a change there would void a valid GEMM profile)
+    for f in ("kernels_gemm2.hip", "kernels_gemm.hip", "gemm_body.h", "gemm_epilogue.h"):
         with open(os.path.join(ROOT, "mixedprecisionblockqr_amd", "csrc", f), "rb") as fh:
             hsh.update(fh.read())
     return hsh.hexdigest()[:16]

@@ -98,6 +98,8 @@ typedef struct mpqr_timings {
     float us_gh_solve;    /* one gh_solve launch at this plan's leaf width, timed alone (mpqr_bench_leaf_solve; 0 = not measured) */
     int   n_q_ident_rows; /* Q formation: rows of X = Q2^T V copied from V because their columns of Q were still identity columns */
     int   restart_block;  /* the top-level block the LAST pass started from (n_passes > 1: a flagged leaf's block; the blocks left of it were kept) */
+    int   n_fused_leaves; /* leaves of the last pass whose chain-stream work between two solves ran as the three fused launches (leaf_a / leaf_m / leaf_b) */
+    int   n_tpoll_retries;/* 1: a polling wait of the T stream timed out and the factorisation was repeated with event hand-offs (stderr says so) */
 } mpqr_timings;
 
 typedef struct mpqr_handle_s* mpqr_handle_t;

@@ -124,9 +124,14 @@ struct mpqr_handle_s {
     half_t* Yfl = nullptr;        // Y = fp16(X T') for the next panel, 128 x 128
     int gram_ready_c0 = -1, gram_ready_rows = 0, gram_ready_n = 0;   // leaf_b left the partial Gram matrices (n of them) of the leaf that starts at this column, over this many rows
     int n_fused_leaves = 0;       // of the last mpqr_factor
+    int rest_first_cols = 0;      // apply_node, lane 2: the update's first this-many columns as a launch of their own, ev_rest recorded behind it
+    bool rest_recorded = false;   // ... done: the caller does not record ev_rest again
+    int lane2_twait = 0;          // apply_node, lane 2: wait for this value of the chain's T word in front of Y = X T (0: nothing to wait for)
     int* tflag = nullptr;         // device word the chain publishes its progress in (leaf_xt_kernel / leaf_b_kernel), polled by the T stream (wait_flag_kernel)
     int tseq = 0, xt_pub = 0;     // last published value; value the next leaf_xt launch of apply_node is to publish (0: none)
     bool tpoll = true;            // MPQR_TPOLL=0: the T stream follows the chain through an event (costs the chain ~4 us per leaf)
+    unsigned long long tpoll_ticks = 500000000ull;   // how long a wait_flag_kernel polls before it gives up (100 MHz ticks: 5 s; MPQR_TPOLL_TIMEOUT_MS)
+    int n_tpoll_retries = 0;      // factorisations repeated with event hand-offs after a polling wait timed out (last mpqr_factor)
     float* P = nullptr;    int maxwg = 0;
     double* Gp = nullptr; double* Gs = nullptr; float* Cv = nullptr; int* dflag = nullptr;   // Gram-Householder leaf workspace
     float* Sp = nullptr;          // per-workgroup partial Grams of the fp16 reflectors (fused into gh_apply)
@@ -523,6 +528,10 @@ void apply_node(mpqr_handle_t h, const Node& nd, float* C, long ldc, int clo, in
     }
     if (st1 != st) { HIPQ(h, hipEventRecord(h->ev_x, st1)); HIPQ(h, hipStreamWaitEvent(st, h->ev_x, 0)); }
     if (record) HIPQ(h, hipEventRecord(e1, st));
+    if (lane == 2 && h->lane2_twait) {                      // fused leaf: T_j comes from the chain stream's leaf_m; its progress word is published by leaf_b
+        launch_wait_flag(h->tflag, h->lane2_twait, h->hflag_dev + h->flag_words - 1, h->tpoll_ticks, st, 0);
+        h->lane2_twait = 0;
+    }
     // op2: Yt[M1 x Kr] = fp16( Xt * T' ) -- the first use of T: it was built on the T stream beside op1
     if (st1 == st && h->tq_on && nd.id >= 0 && nd.id < (int)h->ev_T.size()) HIPQ(h, hipStreamWaitEvent(st, h->ev_T[nd.id], 0));
     GemmArgs g2{};
@@ -555,6 +564,7 @@ void apply_node(mpqr_handle_t h, const Node& nd, float* C, long ldc, int clo, in
         static const int nt_env = []() { const char* e = getenv("MPQR_NT_C"); return e ? atoi(e) : 3; }();
         if ((nt_env & 1) && far) g3.nt_c = 1;
         if ((nt_env & 2) && q_apply) g3.nt_c = 1;
+        if ((nt_env & 4) && lane == 2) g3.nt_c = 1;        // (A/B hook: the deferred in-block updates of the T stream)
     }
     if (h->shadow && h->shadow_write && lane == 0 && !far) { g3.Ct = h->shadow + (long)clo_al * h->ldshadow + rlo; g3.ldct = h->ldshadow; g3.ct_scale = in_scale; }
     if (record) HIPQ(h, hipEventRecord(e2, st));
@@ -564,8 +574,23 @@ void apply_node(mpqr_handle_t h, const Node& nd, float* C, long ldc, int clo, in
         f3.A = h->V8n; f3.lda = h->ld8k; f3.Bt = (const half_t*)h->Y8; f3.ldb = h->ld8k;
         f3.alpha = g3.alpha * (4.f / 256.f);
         launch_gemm_fp8(E_SUB_F32, f3, st);
+    } else if (lane == 2 && h->rest_first_cols > 0 && clo == clo_al && !g3.Ct && M1 == h->rest_first_cols) {
+        gemm_dispatch(A_H16, E_SUB_F32, g3, st);            // (this call's range IS those columns: a pre-updated leaf's first piece)
+        HIPQ(h, hipEventRecord(h->ev_rest, st)); h->rest_recorded = true;
+    } else if (lane == 2 && h->rest_first_cols > 0 && clo == clo_al && !g3.Ct && M1 > h->rest_first_cols) {
+        // fused leaf: the chain waits for the deferred update of the NEXT leaf's next panel only (the first columns of this range) -- they go
+        // out as a launch of their own with the event behind it, the other columns follow (under a far update this range's one launch took
+        // 80 us instead of 15 and the chain stood still for it: kernel trace)
+        const int n1 = h->rest_first_cols;
+        GemmArgs ga = g3; ga.N = n1;
+        gemm_dispatch(A_H16, E_SUB_F32, ga, st);
+        HIPQ(h, hipEventRecord(h->ev_rest, st)); h->rest_recorded = true;
+        GemmArgs gb = g3; gb.N = M1 - n1; gb.Bt = Yt + (long)n1 * Kr; gb.C = (float*)g3.C + n1; gb.col_lo = 0;
+        gemm_dispatch(A_H16, E_SUB_F32, gb, st);
+        h->rest_first_cols = 0;
     } else
     gemm_dispatch(A_H16, E_SUB_F32, g3, st);
+    if (lane == 2) h->rest_first_cols = 0;
     if (record) {
         HIPQ(h, hipEventRecord(e3, st));
         h->far_flops.push_back(2.0 * M1 * (double)Kr * Kw);
@@ -590,7 +615,7 @@ static inline bool flag_words_set(mpqr_handle_t h, int upto) {
 }
 // Checked before every leaf: any raised word ends the pass (everything downstream of a flagged leaf is redone anyway).
 static inline bool pass_is_flagged(mpqr_handle_t h) {
-    return h->watch_flags && flag_words_set(h, h->flag_words);
+    return h->watch_flags && flag_words_set(h, h->flag_words - 1);      // (the last word is the T stream's time-out word)
 }
 
 // Robust path for a tall (<=128-column) leaf: factor it through a temporary sub-tree of 32-column leaves
@@ -934,6 +959,8 @@ int factor_block_flat(mpqr_handle_t h, int top, const std::vector<int>& leaves) 
         if (h->rest_pending) {
             // the previous leaf's deferred update (T stream) wrote columns this leaf's X reads and the next gh_gram needs: it finished
             // ~100 us ago (it ran beside this leaf's gh_solve), the wait only orders the streams
+            static const int dbg_norestwait = []() { const char* e = getenv("MPQR_DBG_NORESTWAIT"); return e ? atoi(e) : 0; }();   // timing experiment only (a race)
+            if (!dbg_norestwait)
             HIPQ(h, hipStreamWaitEvent(h->s0, h->ev_rest, 0));
             h->rest_pending = false;
         }
@@ -943,13 +970,20 @@ int factor_block_flat(mpqr_handle_t h, int top, const std::vector<int>& leaves) 
             bool next_gh = !is_tail(h, lf.c1) && !h->robust;
             if (next_gh && j + 1 < leaves.size()) { const int nid = leaves[j + 1]; next_gh = !(nid < (int)h->leaf_robust.size() && h->leaf_robust[nid]); }
             launch_leaf_a(gh_args, h->Cv, h->Sp, h->Xp, lf.c1, h->a_scale, h->s0);
+            static const int dbg_nopub_fl = []() { const char* e = getenv("MPQR_DBG_NOPUB"); return e ? atoi(e) : 0; }();   // test hook: the words are never published -> the waiter times out
+            ++h->tseq;
+            // two progress words for the T stream: leaf_m (behind leaf_a in this stream) publishes "the leaf's reflectors are complete" -- the
+            // T stream's X = C_rest^T V_j starts then, beside leaf_m --, leaf_b publishes "T_j is complete" for the Y = X T_j behind it
             launch_leaf_m(h->Sp, h->Xp, gh_partials, h->Sleaf, h->Xs, h->mid_counter, gh_sh, lf.a0, lf.c0, lf.c1, h->Tf + lf.toff, h->Th + lf.toff,
-                          h->Tth + lf.toff, lf.ldt, ld, h->Yfl, h->s0);
-            launch_leaf_b(gh_args, lf.c1, h->Yfl, 1.0f / h->a_scale, h->Gp, next_gh, h->tflag, ++h->tseq, h->s0);
+                          h->Tth + lf.toff, lf.ldt, ld, h->Yfl, h->s0, h->tflag + 2, dbg_nopub_fl ? -1 : h->tseq);
+            launch_leaf_b(gh_args, lf.c1, h->Yfl, 1.0f / h->a_scale, h->Gp, next_gh, h->tflag, dbg_nopub_fl ? -1 : h->tseq, h->s0);
             if (next_gh) { h->gram_ready_c0 = lf.c1; h->gram_ready_rows = h->m - lf.c1; h->gram_ready_n = fl_gram_partials(gh_args); }
             h->n_fused_leaves++;
-            // the T stream goes on (the previous leaf's column block of T, this leaf's update of the rest of the block) once the chain is past T_j
-            launch_wait_flag(h->tflag, h->tseq, h->hflag_dev + h->flag_words - 1, h->sT);
+            // the T stream goes on with this leaf's update of the rest of the block: X once the chain is past V_j, Y = X T_j once it is past T_j
+            // (apply_node, lane 2, launches that second wait in front of its op2)
+            launch_wait_flag(h->tflag, h->tseq, h->hflag_dev + h->flag_words - 1, h->tpoll_ticks, h->sT, 2);
+            h->lane2_twait = h->tseq;
+            if (!have_rest) { launch_wait_flag(h->tflag, h->tseq, h->hflag_dev + h->flag_words - 1, h->tpoll_ticks, h->sT, 0); h->lane2_twait = 0; }
         } else
         if (lf.c1 < own_end) {
             Range rg("mpqr:in_block_update");
@@ -965,7 +999,7 @@ int factor_block_flat(mpqr_handle_t h, int top, const std::vector<int>& leaves) 
             if (h->mid || h->xt_pub) { h->mid = nullptr; h->xt_pub = 0; h->dispatch_error = true; }   // (apply_node took another path than predicted)
             // the T stream may go on (with the previous leaf's column block of T) once the chain is past this leaf's T: it polls the
             // published word instead of waiting for an event the chain stream would have to record
-            if (poll) launch_wait_flag(h->tflag, h->tseq, h->hflag_dev + h->flag_words - 1, h->sT);
+            if (poll) launch_wait_flag(h->tflag, h->tseq, h->hflag_dev + h->flag_words - 1, h->tpoll_ticks, h->sT);
             else if (mid_leaf && tq) t_stream_follows_chain(h);
         }
         if (have_rest) {                                   // the rest, on the T stream
@@ -975,6 +1009,8 @@ int factor_block_flat(mpqr_handle_t h, int top, const std::vector<int>& leaves) 
                 HIPQ(h, hipStreamWaitEvent(h->sT, h->ev_def, 0));
             }                                               // (la_mid: the T stream is already behind wait_flag_kernel for this leaf)
             int lo = own_end;
+            h->rest_recorded = false;
+            h->rest_first_cols = fl ? 128 : 0;             // (the next leaf's leaf_a reads exactly these columns)
             if (pre_split && lo < cpre) {                   // columns the previous block already brought up to date: no far update to wait for
                 apply_node(h, lf, h->Aeff, h->lda, lo, cpre, true, h->a_scale, false, 2);
                 lo = cpre;
@@ -985,7 +1021,8 @@ int factor_block_flat(mpqr_handle_t h, int top, const std::vector<int>& leaves) 
             // chain stream and reads the columns this update writes (a leaf on the two-stream form is ordered behind it by the T stream
             // itself; the extra wait is harmless there).  Without it the first one-launch leaf behind a block's two-stream leaves raced
             // with the second leaf's rest: R differed from run to run from that leaf's successor on (tools/determinism_check.py).
-            HIPQ(h, hipEventRecord(h->ev_rest, h->sT)); h->rest_pending = true;
+            if (!h->rest_recorded) HIPQ(h, hipEventRecord(h->ev_rest, h->sT));
+            h->rest_pending = true; h->rest_first_cols = 0;
         }
         // background, behind this leaf's X GEMM in the side stream's queue: the PREVIOUS leaf's column block of T
         if (prev_o >= 0) t_column_block(prev, prev_o);
@@ -1487,8 +1524,9 @@ static int plan_common(mpqr_handle_t h, int m, int n, int r, const mpqr_opts* op
     if ((rc = dalloc(h, &h->Sleaf, (size_t)128 * 128 * LEAF_MID_MAX_GROUPS))) return rc;
     if ((rc = dalloc(h, &h->mid_counter, (size_t)1))) return rc;
     HIPCHK(h, hipMemsetAsync(h->mid_counter, 0, sizeof(int), h->s0));
-    if ((rc = dalloc(h, &h->tflag, (size_t)1))) return rc;
-    HIPCHK(h, hipMemsetAsync(h->tflag, 0, sizeof(int), h->s0));
+    if ((rc = dalloc(h, &h->tflag, (size_t)4))) return rc;                               // [0] the chain is past this leaf's T, [1] "a wait has timed out", [2] ... past this leaf's reflectors
+    HIPCHK(h, hipMemsetAsync(h->tflag, 0, 4 * sizeof(int), h->s0));
+    if (const char* e = getenv("MPQR_TPOLL_TIMEOUT_MS")) h->tpoll_ticks = (unsigned long long)std::max(1, atoi(e)) * 100000ull;
     h->tseq = 0;
     if ((rc = dalloc(h, &h->P, (size_t)2 * h->maxwg * 32))) return rc;
     if ((rc = dalloc(h, &h->Gp, (size_t)(h->m_pad / 64 + 2) * 16384))) return rc;      // (leaf_b: one partial per 64 rows)
@@ -1632,7 +1670,7 @@ int mpqr_generate_matrix(mpqr_handle_t h, uint64_t seed) {
 static int run_block_loop(mpqr_handle_t h, int start = 0) {
     int rc;
     h->v8_node = -1;
-    h->gram_ready_c0 = -1;
+    h->gram_ready_c0 = -1; h->lane2_twait = 0;
     if (start <= 0) h->n_fused_leaves = 0;
     h->pairs_ready = false; h->q_first = (size_t)-1;
     const auto host_t0 = std::chrono::steady_clock::now();  // host time to enqueue the block loop (ms_host_enqueue)
@@ -1828,7 +1866,8 @@ int mpqr_factor(mpqr_handle_t h) {
     // returns with Q formation still running, as before).  A flagged pass has a speculative Q formation in the queue; it is simply
     // formed again after the repair passes.
     std::vector<int> flags;
-    h->n_passes = 0;
+    h->n_passes = 0; h->n_tpoll_retries = 0;
+    const bool tpoll_saved = h->tpoll; bool tpoll_retry = false;
     int start = 0, gh_total = 0;
     const int nblocks = (int)h->tops.size();
     for (int pass = 0; pass < 18; pass++) {
@@ -1842,9 +1881,22 @@ int mpqr_factor(mpqr_handle_t h) {
         HIPCHK(h, hipEventRecord(h->ev[2], h->s0));
         HIPCHK(h, hipEventSynchronize(h->ev[1]));           // the block loop (not Q formation) is done: the flag word is final
         HIPCHK(h, hipGetLastError());
-        if (h->hflag_host && h->flag_words > 0 && __atomic_load_n(h->hflag_host + h->flag_words - 1, __ATOMIC_RELAXED) != 0)
-            return fail(h, MPQR_ERR_HIP, "the T stream's wait for the chain stream timed out (wait_flag_kernel)");
-        if (!flag_words_set(h, h->flag_words) && !h->pass_aborted) break;
+        if (h->hflag_host && h->flag_words > 0 && __atomic_load_n(h->hflag_host + h->flag_words - 1, __ATOMIC_RELAXED) != 0) {
+            // A polling wait of the T stream gave up: that stream ran ahead of the chain, the pass is garbage.  A slow chain cannot be told
+            // from a lost publish, so the factorisation is repeated ONCE with event hand-offs (no polling, no fused leaves) before failing.
+            HIPCHK(h, hipStreamSynchronize(h->s0));
+            if (h->s1) HIPCHK(h, hipStreamSynchronize(h->s1));
+            if (h->sT) HIPCHK(h, hipStreamSynchronize(h->sT));
+            fprintf(stderr, "mpqr: the T stream's wait for the chain stream timed out (wait_flag_kernel)%s\n", (h->tpoll && !tpoll_retry) ? "; repeating the factorisation with event hand-offs" : "");
+            if (!h->tpoll || tpoll_retry) { h->tpoll = tpoll_saved; return fail(h, MPQR_ERR_HIP, "the T stream's wait for the chain stream timed out (wait_flag_kernel)"); }
+            __atomic_store_n(h->hflag_host + h->flag_words - 1, 0, __ATOMIC_RELAXED);
+            HIPCHK(h, hipMemsetAsync(h->tflag, 0, 4 * sizeof(int), h->s0)); h->tseq = 0;
+            tpoll_retry = true; h->tpoll = false; h->n_tpoll_retries++;
+            h->factored = false; h->q_formed = false; h->q_inited = false; h->v_clean = false;
+            start = 0;
+            continue;
+        }
+        if (!flag_words_set(h, h->flag_words - 1) && !h->pass_aborted) break;
         h->factored = false; h->q_formed = false;
         flags.assign(h->nodes.size(), 0);
         HIPCHK(h, hipMemcpyAsync(flags.data(), h->dflag, flags.size() * sizeof(int), hipMemcpyDeviceToHost, h->s0));
@@ -1874,8 +1926,10 @@ int mpqr_factor(mpqr_handle_t h) {
     h->n_gh_leaves = gh_total;
     h->n_robust_leaves = 0;
     for (char c : h->leaf_robust) h->n_robust_leaves += c ? 1 : 0;
-    h->v_clean = h->n_passes == 1 && !h->robust && h->n_robust_leaves == 0 && h->world == 1;
+    h->tpoll = tpoll_saved;
+    h->v_clean = false;
     if (dispatch_failed(h)) return fail(h, MPQR_ERR_STATE, "a GEMM of the factorisation found no kernel for its operand staging / epilogue, or an enqueue call failed (stderr)");
+    h->v_clean = h->n_passes == 1 && !h->robust && h->n_robust_leaves == 0 && h->world == 1;      // (only a factorisation that returns MPQR_OK leaves the stores clean)
     return MPQR_OK;
 }
 
@@ -1946,6 +2000,7 @@ int mpqr_get_timings(mpqr_handle_t h, mpqr_timings* t) {
     t->us_gh_solve = h->us_gh_solve;
     t->n_q_ident_rows = h->n_q_ident_rows;
     t->restart_block = h->restart_block;
+    t->n_fused_leaves = h->n_fused_leaves; t->n_tpoll_retries = h->n_tpoll_retries;
     h->last_t = *t;
     return MPQR_OK;
 }
@@ -2687,7 +2742,9 @@ int mpqr_dist_flags(mpqr_handle_t h, int* any) {
     int rc = need_plan(h, true); if (rc) return rc;
     if (!any) return MPQR_ERR_INVALID;
     HIPCHK(h, hipStreamSynchronize(h->s0));
-    *any = flag_words_set(h, h->flag_words) ? 1 : 0;
+    if (h->hflag_host && h->flag_words > 0 && __atomic_load_n(h->hflag_host + h->flag_words - 1, __ATOMIC_RELAXED) != 0)
+        return fail(h, MPQR_ERR_HIP, "the T stream's wait for the chain stream timed out (wait_flag_kernel): this pass's results are invalid");
+    *any = flag_words_set(h, h->flag_words - 1) ? 1 : 0;
     return MPQR_OK;
 }
 // on != 0: every tall leaf of the following factorisations takes the column-by-column kernels (all ranks must agree)

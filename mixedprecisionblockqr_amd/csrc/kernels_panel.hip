@@ -876,21 +876,27 @@ void launch_leaf_xt(const float* X, int nslab, long slab_stride, int M1, const h
 // dependency that costs the publishing stream nothing.  The kernels behind this one start after it has ended, i.e. with the usual
 // start-of-kernel acquire, so they see what the publisher's predecessors wrote.  The values of a handle only grow (a restarted pass
 // publishes larger ones), so a stale word can only end the wait early for work whose inputs are older still.  Exit condition every
-// wave reaches: the publisher is always enqueued BEFORE the waiter (host order); should it never run, the wait gives up after 0.2 s and
-// raises *timeout_word (mapped host memory), which mpqr_factor reports as an error.
-__global__ __launch_bounds__(64) void wait_flag_kernel(const int* __restrict__ flag, int value, int* __restrict__ timeout_word) {
+// wave reaches: the publisher is always enqueued BEFORE the waiter (host order); should it never run, the wait gives up after `ticks`
+// (100 MHz; MPQR_TPOLL_TIMEOUT_MS, default 5 s: a slow chain -- a shared GPU, a serialising tool, other ranks' blocks in front of an unpack --
+// is not a lost publish) and raises *timeout_word (mapped host memory) and flag[1]; later waiters see flag[1] and return at once.  mpqr_factor
+// then repeats the factorisation with event hand-offs; the mpqr_dist_* steps report the error.
+__global__ __launch_bounds__(64) void wait_flag_kernel(int* __restrict__ flag, int word, int value, int* __restrict__ timeout_word, unsigned long long ticks) {
     if (threadIdx.x != 0) return;
+    if (__hip_atomic_load(flag + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return;      // an earlier wait of this pass has timed out
+    int* const marker = flag + 1;
+    flag += word;                                            // (0: the chain is past the leaf's T; 2: past the leaf's reflectors)
     const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();       // 100 MHz
     while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < value) {
         __builtin_amdgcn_s_sleep(8);
-        if (__builtin_amdgcn_s_memrealtime() - t0 > 20000000ull) {
+        if (__builtin_amdgcn_s_memrealtime() - t0 > ticks) {
             __hip_atomic_store(timeout_word, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(marker, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             break;
         }
     }
 }
-void launch_wait_flag(const int* flag, int value, int* timeout_word, hipStream_t s) {
-    hipLaunchKernelGGL(wait_flag_kernel, dim3(1), dim3(64), 0, s, flag, value, timeout_word);
+void launch_wait_flag(int* flag, int value, int* timeout_word, unsigned long long ticks, hipStream_t s, int word) {
+    hipLaunchKernelGGL(wait_flag_kernel, dim3(1), dim3(64), 0, s, flag, word, value, timeout_word, ticks);
 }
 
 // ------------------------------------------------------------------ T of a leaf (up to 128 reflectors)
@@ -1447,6 +1453,7 @@ struct LeafM2Args {
     int* counter;                                         // zero between launches (the last arriver resets it)
     int sh, a0, c0, c1; float* T; half_t* Th; half_t* Tth; int ldt, ld;
     half_t* Y;                                            // [128 columns of the next panel][128 reflectors]
+    int* pub_flag; int pub_value;                         // published at the start: every earlier launch of the chain stream (the leaf's reflectors) is complete
 };
 typedef half_t half4m __attribute__((ext_vector_type(4)));
 typedef float float4m __attribute__((ext_vector_type(4)));
@@ -1463,6 +1470,7 @@ __global__ __launch_bounds__(1024) void leaf_m_kernel(LeafM2Args m) {
     long kt_[16]; int kn_ = 0; const bool kon_ = (threadIdx.x == 0);
 #endif
     KT();
+    if (m.pub_flag && blockIdx.x == 0 && tid == 0) __hip_atomic_store(m.pub_flag, m.pub_value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const int kind = (int)blockIdx.x / nred, b = (int)blockIdx.x % nred;      // 0: S, 1: X
     const int grp = b / MID_RB;
     const int q_lo = (int)((long)m.nslab * grp / m.ngrp), q_hi = (int)((long)m.nslab * (grp + 1) / m.ngrp);
@@ -1702,13 +1710,14 @@ void launch_leaf_a(const LeafArgs& a, const float* Cv, float* Sp, float* Xp, int
     hipLaunchKernelGGL(leaf_a_kernel, dim3(nlow + ntop), dim3(256), FL_A_LDS, s, a, Cv, Sp, Xp, nlow, it, nb, in_scale);
 }
 void launch_leaf_m(const float* Sp, const float* Xp, int nslab, float* S, float* Xs, int* counter, int sh, int a0, int c0, int c1,
-                   float* T, half_t* Th, half_t* Tth, int ldt, int ld, half_t* Y, hipStream_t s) {
+                   float* T, half_t* Th, half_t* Tth, int ldt, int ld, half_t* Y, hipStream_t s, int* pub_flag, int pub_value) {
     constexpr int LDS = 2 * TP * TPS * 4;
     MPQR_ONCE_PER_DEVICE((void)hipFuncSetAttribute((const void*)leaf_m_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
     LeafM2Args m{};
     m.Sp = Sp; m.Xp = Xp; m.nslab = nslab; m.S = S; m.Xs = Xs; m.counter = counter;
     m.ngrp = std::max(1, std::min(LEAF_MID_MAX_GROUPS, nslab / 256));
     m.sh = sh; m.a0 = a0; m.c0 = c0; m.c1 = c1; m.T = T; m.Th = Th; m.Tth = Tth; m.ldt = ldt; m.ld = ld <= 0 ? ldt : ld; m.Y = Y;
+    m.pub_flag = pub_flag; m.pub_value = pub_value;
     hipLaunchKernelGGL(leaf_m_kernel, dim3(2 * MID_RB * m.ngrp), dim3(1024), LDS, s, m);
 }
 void launch_leaf_b(const LeafArgs& a, int nb, const half_t* Y, float alpha, double* Gp, bool do_gram, int* pub_flag, int pub_value, hipStream_t s) {

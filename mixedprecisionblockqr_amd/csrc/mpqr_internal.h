@@ -142,7 +142,9 @@ void launch_gh_solve3(const LeafArgs& a, const double* G, float* Cv, int* flag, 
 void launch_leaf_xt(const float* X, int nslab, long slab_stride, int M1, const half_t* Bt, long ldb, int tri, half_t* Y, long ldy,
                     const float* cscale, long cscale_ld, hipStream_t s, int* pub_flag = nullptr, int pub_value = 0);
 // cross-stream dependency without an event: stream s goes on once *flag >= value (published by leaf_xt_kernel: pub_flag / pub_value)
-void launch_wait_flag(const int* flag, int value, int* timeout_word, hipStream_t s);
+// flag[0]: the published word, flag[1]: set once a wait has timed out (ticks of 100 MHz)
+// word: which of the chain's two progress words to wait for (flag[0]: past the leaf's T, flag[2]: past the leaf's reflectors)
+void launch_wait_flag(int* flag, int value, int* timeout_word, unsigned long long ticks, hipStream_t s, int word = 0);
 void launch_gh_reduce_f32(const float* Sp, int nslab, float* S, hipStream_t s);
 
 // T of a leaf (<= 128 reflectors) from its Gram slabs S (row stride lds_, aligned range starting at a0)
@@ -160,7 +162,7 @@ void launch_leaf_mid(const GemmArgs& g1, const float* Sp, int nslab, float* S, i
 // them in Gp, for launch_gh_gram_reduce + launch_gh_solve); it also publishes pub_value in *pub_flag (launch_wait_flag's word).
 void launch_leaf_a(const LeafArgs& a, const float* Cv, float* Sp, float* Xp, int nb, float in_scale, hipStream_t s);
 void launch_leaf_m(const float* Sp, const float* Xp, int nslab, float* S, float* Xs, int* counter, int sh, int a0, int c0, int c1,
-                   float* T, half_t* Th, half_t* Tth, int ldt, int ld, half_t* Y, hipStream_t s);
+                   float* T, half_t* Th, half_t* Tth, int ldt, int ld, half_t* Y, hipStream_t s, int* pub_flag = nullptr, int pub_value = 0);
 void launch_leaf_b(const LeafArgs& a, int nb, const half_t* Y, float alpha, double* Gp, bool do_gram, int* pub_flag, int pub_value, hipStream_t s);
 int fl_gram_partials(const LeafArgs& a);
 void launch_gh_gram_reduce(const double* Gp, int nwg, double* G, hipStream_t s);

@@ -168,6 +168,8 @@ def factor(engine, comm, form_q=True, lookahead=True):
     every tall leaf on the column-by-column kernels."""
     _factor_once(engine, comm, form_q, lookahead)
     if hasattr(engine, "flagged") and comm.allreduce_max(engine.flagged()) > 0:
+        # (the robust mode belongs to the INPUT: a later factor() of the same matrix would flag again, so it starts robust at once; a new
+        #  input -- mpqr_dist_set_local_matrix_host / mpqr_dist_generate_matrix -- clears it in the library)
         engine.set_robust(True)
         _factor_once(engine, comm, form_q, lookahead)
 

@@ -22,4 +22,5 @@ A64 = A.astype(np.float64)
 be = float(np.linalg.norm(A64 - Q.astype(np.float64) @ R.astype(np.float64)) / np.linalg.norm(A64))
 oe = float(np.abs(Q.astype(np.float64).T @ Q.astype(np.float64) - np.eye(m)).max())
 print(json.dumps({"backward_error": be, "orth_max": oe, "absdiag": [float(abs(x)) for x in np.diag(R[:n])],
-                  "n_far_launches": tm["n_far_launches"], "gbytes_far_nn": tm["gbytes_far_nn"], "n_q_ident_rows": tm["n_q_ident_rows"], "n_q_launches": tm["n_q_launches"]}))
+                  "n_far_launches": tm["n_far_launches"], "gbytes_far_nn": tm["gbytes_far_nn"], "n_q_ident_rows": tm["n_q_ident_rows"], "n_q_launches": tm["n_q_launches"],
+                  "n_fused_leaves": tm["n_fused_leaves"], "n_tpoll_retries": tm["n_tpoll_retries"]}))

@@ -99,7 +99,8 @@ def test_cpp_multi_gpu_host_driver_on_one_gpu(tmp_path):
         mt = re.search(r"multi-GPU block QR: 1 GPU\(s\), 4096 x 3072, r = 128, outer block (\d+), (\w+): ([0-9.]+) ms per factorisation incl. Q, ([0-9.]+) GFLOP/s", p.stdout)
         assert mt, p.stdout
         assert mt.group(2) == dtype and float(mt.group(3)) > 0 and float(mt.group(4)) > 100.0
-        # the N > 1 host evaluates the reference's three criteria (Cuda/qr.cu:115-196) on the gathered result, p = operand precision
+        # the N > 1 host evaluates the reference's three criteria (Cuda/qr.cu:115-196) on the gathered result with the reference's p = 11
+        # (qr.cu:1889; the criterion is 2^-p m, which an e4m3 result of 3.5e-2 also meets at m = 4096 -- the value itself is asserted below)
         crit = {k: (float(v), ok == "True") for k, v, ok in CRIT.findall(p.stdout)}
         assert len(crit) == 3 and all(ok for _, ok in crit.values()), (dtype, crit, p.stdout)
         be = crit["||A - QR||/||A||"][0]

@@ -515,6 +515,35 @@ def test_tall_leaves_with_leaf_lookahead_are_bit_repeatable(mp):
         hh.close()
 
 
+@pytest.mark.gpu
+def test_fused_leaves_are_bit_repeatable_and_a_plan_can_be_reused(mp):
+    """Round 5: a tall leaf's chain work is three launches (leaf_a / leaf_m / leaf_b) that hand partial sums over through fixed-order
+    reductions and an arrival counter -- no floating-point atomics: factorisations of the same matrix give the same R and Q bit for bit.
+    And a plan that has factored A gives, for a different matrix B, exactly what a fresh plan gives (the reflector stores are not cleared
+    between clean factorisations: every stale entry is rewritten before it is read) -- with ragged / tail leaves and r = 64."""
+    for (m, n, r) in ((6144, 4096, 128), (3000, 1500, 64), (2320, 1980, 64)):
+        hh = mp.Handle(0)
+        try:
+            hh.plan(m, n, r)
+            hh.generate(4242); hh.factor(); hh.sync()
+            assert hh.timings()["n_fused_leaves"] > 0
+            R1, Q1 = hh.r_matrix(), hh.q()
+            hh.factor(); hh.sync()
+            assert np.array_equal(R1, hh.r_matrix()) and np.array_equal(Q1, hh.q())
+            hh.generate(99); hh.factor(); hh.sync()          # a different matrix on the used plan
+            RB, QB = hh.r_matrix(), hh.q()
+            mt = hh.metrics()
+            assert mt["backward_error"] <= 1e-3, mt
+        finally:
+            hh.close()
+        h2 = mp.Handle(0)
+        try:
+            h2.plan(m, n, r); h2.generate(99); h2.factor(); h2.sync()
+            assert np.array_equal(RB, h2.r_matrix()) and np.array_equal(QB, h2.q()), (m, n, r)
+        finally:
+            h2.close()
+
+
 @pytest.mark.baseline(3)
 def test_config3_synthetic_jacobian_through_the_file_format(mp, h, po, tmp_path):
     """BASELINE config 3 (EuRoC bundle-adjustment Jacobian, r = 64): the real files are an absent LFS blob, so a
@@ -891,7 +920,8 @@ OPT_IN = [
     {"MPQR_TPOLL": "0"},                           # the T stream follows the chain through an event instead of polling the word leaf_xt publishes
     {"MPQR_LEAF_MID": "0"},                        # a leaf's X on the side stream, Gram sum and T as two launches on the chain (before round 4's leaf_mid_kernel)
     {"MPQR_TAIL_LEAF": "0"},                       # the last <= 128 rows as 32-column leaves + merges (before round 4's leaf_tail_kernel)
-    {"MPQR_LEAF_LA": "1"},                         # leaf-level look-ahead: every leaf's update of the rest of its block on the T stream
+    {"MPQR_FUSED_LEAF": "0"},                      # the seven-launch leaf of round 4 (gh_apply, leaf_mid, leaf_xt, K = 128 update, gh_gram) instead of leaf_a / leaf_m / leaf_b
+    {"MPQR_FUSED_LEAF": "0", "MPQR_LEAF_LA": "1"}, # ... with leaf-level look-ahead: every leaf's update of the rest of its block on the T stream
     {"MPQR_RESTART": "0", "MPQR_WATCH_FLAGS": "0"},   # robust fallback as in round 2 (no early stop, every pass from block 0)
 ]
 # (round 4: the variants that lost for two rounds are gone with their code -- MPQR_SOLVE3=0, MPQR_FLAT=0, MPQR_FUSE_XT=0, MPQR_X16=0,
@@ -921,16 +951,21 @@ def test_tall_matrix_one_shot_q_formation():
 
 @pytest.mark.gpu
 def test_t_stream_wait_gives_up_instead_of_hanging():
-    """The T stream follows the chain by polling a word that leaf_xt publishes (wait_flag_kernel).  Exit condition: should the word
-    never arrive (MPQR_DBG_NOPUB=1 makes leaf_xt publish -1), every waiter gives up after 0.2 s and raises a mapped host word;
-    mpqr_factor then returns an error instead of results built on a T stream that ran ahead of the chain -- and nothing hangs."""
-    import os, subprocess, sys, time
+    """The T stream follows the chain by polling a word that the chain publishes (leaf_b / leaf_xt -> wait_flag_kernel).  Exit condition:
+    should the word never arrive (MPQR_DBG_NOPUB=1 makes the publisher store -1), the first waiter gives up after the time-out
+    (MPQR_TPOLL_TIMEOUT_MS; default 5 s), raises a mapped host word and a device word that lets every later waiter return at once;
+    mpqr_factor then repeats the factorisation ONCE with event hand-offs (no polling) instead of returning results built on a T stream
+    that ran ahead of the chain -- nothing hangs, the result is good, and the retry is reported (stderr, mpqr_timings.n_tpoll_retries)."""
+    import json, os, subprocess, sys, time
     child = os.path.join(os.path.dirname(os.path.abspath(__file__)), "optin_child.py")
-    env = dict(os.environ); env["MPQR_DBG_NOPUB"] = "1"
+    env = dict(os.environ); env["MPQR_DBG_NOPUB"] = "1"; env["MPQR_TPOLL_TIMEOUT_MS"] = "300"
     t0 = time.time()
     p = subprocess.run([sys.executable, child, "1024", "1024", "128"], env=env, capture_output=True, text=True, timeout=120)
-    assert p.returncode != 0, p.stdout[-500:]
-    assert "timed out" in (p.stderr + p.stdout), p.stderr[-1500:]
+    assert p.returncode == 0, p.stderr[-1500:]
+    assert "timed out" in p.stderr and "repeating the factorisation with event hand-offs" in p.stderr, p.stderr[-1500:]
+    o = json.loads(p.stdout.strip().splitlines()[-1])
+    assert o["n_tpoll_retries"] == 1, o
+    assert o["backward_error"] <= 1e-3 and o["orth_max"] <= 2e-3, o
     assert time.time() - t0 < 60
 
 

@@ -1,0 +1,13 @@
+#!/bin/bash
+# A/B of environment settings on the default bench (config 4): bash tools/ab.sh "VAR=1" "VAR=2 OTHER=3" ...   ("-" = defaults)
+for cfg in "$@"; do
+  if [ "$cfg" = "-" ]; then e=""; else e="$cfg"; fi
+  for rep in 1 2; do
+  env $e python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-dropin --no-alone 2>/dev/null | python3 -c "
+import sys,json
+for l in sys.stdin:
+    if l.startswith('{'):
+        d=json.loads(l); b=d['breakdown_ms']; print('%-40s step %.2f panel %.2f far tn/nn %.2f/%.2f q %.2f be %.2e' % ('$cfg', d['ms_per_step'], b['ms_panel'], b['ms_far_tn'], b['ms_far_nn'], b['ms_form_q'], d['error']['backward_error']))
+"
+  done
+done
