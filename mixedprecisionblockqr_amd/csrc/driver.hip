@@ -124,6 +124,8 @@ struct mpqr_handle_s {
     half_t* Yfl = nullptr;        // Y = fp16(X T') for the next panel, 128 x 128
     int gram_ready_c0 = -1, gram_ready_rows = 0, gram_ready_n = 0;   // leaf_b left the partial Gram matrices (n of them) of the leaf that starts at this column, over this many rows
     int n_fused_leaves = 0;       // of the last mpqr_factor
+    int rest_seq = 0;             // value the T stream last published in tflag[3] behind a deferred update the chain waits for (polling plans)
+    bool rest_in_solve = false;   // ... and the gh_solve launched last polls it at its end (no event wait in front of the next launch)
     int rest_first_cols = 0;      // apply_node, lane 2: the update's first this-many columns as a launch of their own, ev_rest recorded behind it
     bool rest_recorded = false;   // ... done: the caller does not record ev_rest again
     int lane2_twait = 0;          // apply_node, lane 2: wait for this value of the chain's T word in front of Y = X T (0: nothing to wait for)
@@ -392,6 +394,7 @@ int gram(mpqr_handle_t h, const Node& L, const Node& R, int* nslab, long* slab, 
     return MPQR_OK;
 }
 
+static void rest_done(mpqr_handle_t h, hipStream_t st);
 // C[rows >= rdown(nd.c0,64)][cols clo..chi) <- (I - V T' V^T) C,  T' = T^T (trans_t) or T
 void apply_node(mpqr_handle_t h, const Node& nd, float* C, long ldc, int clo, int chi, bool trans_t, float in_scale,
                 bool record, int lane = 0, bool far = false) {
@@ -576,7 +579,7 @@ void apply_node(mpqr_handle_t h, const Node& nd, float* C, long ldc, int clo, in
         launch_gemm_fp8(E_SUB_F32, f3, st);
     } else if (lane == 2 && h->rest_first_cols > 0 && clo == clo_al && !g3.Ct && M1 == h->rest_first_cols) {
         gemm_dispatch(A_H16, E_SUB_F32, g3, st);            // (this call's range IS those columns: a pre-updated leaf's first piece)
-        HIPQ(h, hipEventRecord(h->ev_rest, st)); h->rest_recorded = true;
+        rest_done(h, st); h->rest_recorded = true;
     } else if (lane == 2 && h->rest_first_cols > 0 && clo == clo_al && !g3.Ct && M1 > h->rest_first_cols) {
         // fused leaf: the chain waits for the deferred update of the NEXT leaf's next panel only (the first columns of this range) -- they go
         // out as a launch of their own with the event behind it, the other columns follow (under a far update this range's one launch took
@@ -584,7 +587,7 @@ void apply_node(mpqr_handle_t h, const Node& nd, float* C, long ldc, int clo, in
         const int n1 = h->rest_first_cols;
         GemmArgs ga = g3; ga.N = n1;
         gemm_dispatch(A_H16, E_SUB_F32, ga, st);
-        HIPQ(h, hipEventRecord(h->ev_rest, st)); h->rest_recorded = true;
+        rest_done(h, st); h->rest_recorded = true;
         GemmArgs gb = g3; gb.N = M1 - n1; gb.Bt = Yt + (long)n1 * Kr; gb.C = (float*)g3.C + n1; gb.col_lo = 0;
         gemm_dispatch(A_H16, E_SUB_F32, gb, st);
         h->rest_first_cols = 0;
@@ -654,6 +657,22 @@ static void t_stream_follows_chain(mpqr_handle_t h) {
     HIPQ(h, hipStreamWaitEvent(h->sT, h->ev_v, 0));
 }
 
+// T stream: "the deferred update the chain stream waits for is complete" -- an event, or (polling plans) the progress word tflag[3]
+static inline bool rest_polls(mpqr_handle_t h) { return h->tpoll && h->tflag && h->hflag_dev && h->flag_words > 0 && h->fused_leaf; }
+static void rest_done(mpqr_handle_t h, hipStream_t st) {
+    if (rest_polls(h)) launch_publish_word(h->tflag, 3, ++h->rest_seq, st);
+    else HIPQ(h, hipEventRecord(h->ev_rest, st));
+}
+// chain stream: wait for it (unless the last gh_solve already did, at its end)
+static void rest_wait(mpqr_handle_t h) {
+    if (!h->rest_pending) return;
+    static const int dbg_norestwait = []() { const char* e = getenv("MPQR_DBG_NORESTWAIT"); return e ? atoi(e) : 0; }();   // timing experiment only (a race)
+    if (!dbg_norestwait) {
+        if (!rest_polls(h)) HIPQ(h, hipStreamWaitEvent(h->s0, h->ev_rest, 0));
+        else if (!h->rest_in_solve) launch_wait_flag(h->tflag, h->rest_seq, h->hflag_dev + h->flag_words - 1, h->tpoll_ticks, h->s0, 3);
+    }
+    h->rest_pending = false; h->rest_in_solve = false;
+}
 // the Gram matrix of a Gram-Householder leaf: gh_gram + gh_reduce, or the reduction alone when the previous leaf's leaf_b has already left
 // the partials (fused leaf)
 static void leaf_gram(mpqr_handle_t h, const LeafArgs& a) {
@@ -875,6 +894,11 @@ int factor_block_flat(mpqr_handle_t h, int top, const std::vector<int>& leaves) 
             // the previous block's far update is enqueued HERE (run_block_loop): its stream starts when this leaf's gh_solve does,
             // so its first GEMMs fill the other 255 CUs during the solve instead of holding them while gh_gram wants them
             if (h->far_hook) { auto fh = std::move(h->far_hook); h->far_hook = nullptr; if ((rc = fh())) return rc; }
+            if (h->rest_pending && rest_polls(h)) {            // this solve ends by polling the T stream's word: nothing to wait for behind it
+                const SolveWait ws{h->tflag, 3, h->rest_seq, h->hflag_dev + h->flag_words - 1, h->tpoll_ticks};
+                launch_gh_solve(a, h->Gs, h->Cv, h->dflag + (id < h->nflag ? id : 0), h->s0, &ws);
+                h->rest_in_solve = true;
+            } else
             launch_gh_solve(a, h->Gs, h->Cv, h->dflag + (id < h->nflag ? id : 0), h->s0);
             gh_args = a;                                     // (gh_apply, or the fused leaf's leaf_a, is launched below once the leaf's form is known)
             h->n_gh_leaves++;
@@ -956,14 +980,9 @@ int factor_block_flat(mpqr_handle_t h, int top, const std::vector<int>& leaves) 
         // the word its leaf_xt publishes -- no event on the chain stream for it
         const bool la_mid = la_split && (mid_leaf || fl);
         if (have_rest && la_split && !la_mid) HIPQ(h, hipEventRecord(h->ev_def, h->s0));   // T_j and V_j are complete here: the rest may start beside the urgent part
-        if (h->rest_pending) {
-            // the previous leaf's deferred update (T stream) wrote columns this leaf's X reads and the next gh_gram needs: it finished
-            // ~100 us ago (it ran beside this leaf's gh_solve), the wait only orders the streams
-            static const int dbg_norestwait = []() { const char* e = getenv("MPQR_DBG_NORESTWAIT"); return e ? atoi(e) : 0; }();   // timing experiment only (a race)
-            if (!dbg_norestwait)
-            HIPQ(h, hipStreamWaitEvent(h->s0, h->ev_rest, 0));
-            h->rest_pending = false;
-        }
+        // the previous leaf's deferred update (T stream) wrote columns this leaf's X reads and the next gh_gram needs: it ran beside this
+        // leaf's gh_solve, which polled its progress word at its end (or: an event wait / a one-wave polling kernel here)
+        rest_wait(h);
         if (fl) {
             Range rg("mpqr:fused_leaf");
             // next leaf: does it take the partial Gram matrices leaf_b can leave?  (a Gram-Householder leaf: not the tail, not on the robust path)
@@ -1021,15 +1040,15 @@ int factor_block_flat(mpqr_handle_t h, int top, const std::vector<int>& leaves) 
             // chain stream and reads the columns this update writes (a leaf on the two-stream form is ordered behind it by the T stream
             // itself; the extra wait is harmless there).  Without it the first one-launch leaf behind a block's two-stream leaves raced
             // with the second leaf's rest: R differed from run to run from that leaf's successor on (tools/determinism_check.py).
-            if (!h->rest_recorded) HIPQ(h, hipEventRecord(h->ev_rest, h->sT));
-            h->rest_pending = true; h->rest_first_cols = 0;
+            if (!h->rest_recorded) rest_done(h, h->sT);
+            h->rest_pending = true; h->rest_in_solve = false; h->rest_first_cols = 0;
         }
         // background, behind this leaf's X GEMM in the side stream's queue: the PREVIOUS leaf's column block of T
         if (prev_o >= 0) t_column_block(prev, prev_o);
         prev = lf; prev_o = o;
         if (!tq) { t_column_block(prev, prev_o); prev_o = -1; }          // single stream: nothing to defer
     }
-    if (h->rest_pending) { HIPQ(h, hipStreamWaitEvent(h->s0, h->ev_rest, 0)); h->rest_pending = false; }
+    rest_wait(h);
     if (prev_o >= 0) {                                     // the last leaf's column block needs its T (chain stream)
         if (tq) t_stream_follows_chain(h);
         t_column_block(prev, prev_o);
@@ -1670,7 +1689,7 @@ int mpqr_generate_matrix(mpqr_handle_t h, uint64_t seed) {
 static int run_block_loop(mpqr_handle_t h, int start = 0) {
     int rc;
     h->v8_node = -1;
-    h->gram_ready_c0 = -1; h->lane2_twait = 0;
+    h->gram_ready_c0 = -1; h->lane2_twait = 0; h->rest_pending = false; h->rest_in_solve = false;
     if (start <= 0) h->n_fused_leaves = 0;
     h->pairs_ready = false; h->q_first = (size_t)-1;
     const auto host_t0 = std::chrono::steady_clock::now();  // host time to enqueue the block loop (ms_host_enqueue)

@@ -614,13 +614,19 @@ void launch_gh_gram(const LeafArgs& a, double* Gp, double* G, hipStream_t s) {
     hipLaunchKernelGGL(gh_gram_kernel, dim3(2 * nwg), dim3(256), GH_ROWS * GH_TD * 8, s, a, Gp, it);
     hipLaunchKernelGGL(gh_reduce_kernel, dim3(256), dim3(256), 0, s, Gp, nwg, G);
 }
-void launch_gh_solve(const LeafArgs& a, const double* G, float* Cv, int* flag, hipStream_t s) {
+__global__ __launch_bounds__(64) void publish_word_kernel(int* flag, int word, int value) {
+    if (threadIdx.x == 0) __hip_atomic_store(flag + word, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+void launch_publish_word(int* flag, int word, int value, hipStream_t s) {
+    hipLaunchKernelGGL(publish_word_kernel, dim3(1), dim3(64), 0, s, flag, word, value);
+}
+void launch_gh_solve(const LeafArgs& a, const double* G, float* Cv, int* flag, hipStream_t s, const SolveWait* ws) {
     gh_set_attrs();
     static const int dbg_skip = []() { const char* e = getenv("MPQR_DBG_NOSOLVE"); return e ? atoi(e) : 0; }();
     if (dbg_skip) return;                                  // timing experiment only (results are garbage): is the chain host-bound?
     // gh_solve3 (kernels_solve.hip): the recursion blocked by 16, chains in single waves.  (Round 2's step-by-step kernel, one
     // barrier per reflector, 104 us against 65, was kept behind MPQR_SOLVE3=0 for a round and is gone: git history.)
-    launch_gh_solve3(a, G, Cv, flag, s);
+    launch_gh_solve3(a, G, Cv, flag, s, ws);
 }
 void launch_gh_apply(const LeafArgs& a, const float* Cv, float* Sp, hipStream_t s) {
     gh_set_attrs();

@@ -368,7 +368,7 @@ __device__ __forceinline__ void s3_b_update(float4s& acc, const float* vp, const
 }
 
 __global__ __launch_bounds__(S3_THREADS) void gh_solve3_kernel(LeafArgs a, const double* __restrict__ G, float* __restrict__ Cv,
-                                                               int* __restrict__ flag) {
+                                                               int* __restrict__ flag, SolveWait ws) {
     float* Ws = (float*)(gh_smem + S3_OFF_WS);
     double* buf = (double*)(gh_smem + S3_OFF_BUF);
     float* bpr = (float*)(gh_smem + S3_OFF_BPR);
@@ -697,6 +697,22 @@ __global__ __launch_bounds__(S3_THREADS) void gh_solve3_kernel(LeafArgs a, const
         }
         *(float4*)&Cv[4 * e4] = make_float4(c4[0], c4[1], c4[2], c4[3]);
     }
+    // Round 5: the launch behind this one (leaf_a) reads columns that the T stream's deferred update of the previous leaf wrote.  As an event
+    // wait between the two launches that dependency cost the chain ~6 us per leaf although the update had long finished; here ONE lane of
+    // this one-workgroup kernel polls the word the T stream publishes behind that update (launch_publish_word) -- normally set tens of
+    // microseconds ago.  It cannot starve the publisher (one workgroup), gives up after ws.ticks like wait_flag_kernel, and the next launch
+    // starts with the usual start-of-kernel acquire.
+    if (ws.flag && tid == 0 && __hip_atomic_load(ws.flag + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
+        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+        while (__hip_atomic_load(ws.flag + ws.word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < ws.value) {
+            __builtin_amdgcn_s_sleep(2);
+            if (__builtin_amdgcn_s_memrealtime() - t0 > ws.ticks) {
+                __hip_atomic_store(ws.timeout_word, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                __hip_atomic_store(ws.flag + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                break;
+            }
+        }
+    }
     KT(); KT_DUMP(7, "gh_solve3 zero|loads|barrier0|loop|out|inverse|cstore");
 #ifdef MPQR_KTRACE
     __syncthreads();
@@ -721,9 +737,10 @@ __global__ __launch_bounds__(S3_THREADS) void gh_solve3_kernel(LeafArgs a, const
 #endif
 }
 
-void launch_gh_solve3(const LeafArgs& a, const double* G, float* Cv, int* flag, hipStream_t s) {
+void launch_gh_solve3(const LeafArgs& a, const double* G, float* Cv, int* flag, hipStream_t s, const SolveWait* ws) {
     MPQR_ONCE_PER_DEVICE((void)hipFuncSetAttribute((const void*)gh_solve3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, S3_LDS_BYTES));
-    hipLaunchKernelGGL(gh_solve3_kernel, dim3(1), dim3(S3_THREADS), S3_LDS_BYTES, s, a, G, Cv, flag);
+    SolveWait w{}; if (ws) w = *ws;
+    hipLaunchKernelGGL(gh_solve3_kernel, dim3(1), dim3(S3_THREADS), S3_LDS_BYTES, s, a, G, Cv, flag, w);
 }
 
 }  // namespace mpqr

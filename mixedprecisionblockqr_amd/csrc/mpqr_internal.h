@@ -134,10 +134,14 @@ void launch_leaf_gram_householder(const LeafArgs& a, double* Gp /* nwg x 16384 *
 int gh_num_partials(const LeafArgs& a);
 // the same leaf in separately launchable steps
 void launch_gh_gram(const LeafArgs& a, double* Gp, double* G, hipStream_t s);
-void launch_gh_solve(const LeafArgs& a, const double* G, float* Cv, int* flag, hipStream_t s);
+// gh_solve can end by polling a progress word of ANOTHER stream (flag[word] >= value; flag[1] = "a wait has timed out", see wait_flag_kernel)
+struct SolveWait { int* flag; int word; int value; int* timeout_word; unsigned long long ticks; };
+void launch_gh_solve(const LeafArgs& a, const double* G, float* Cv, int* flag, hipStream_t s, const SolveWait* ws = nullptr);
+// one thread stores flag[word] = value (a stream publishes "everything I have run so far is complete")
+void launch_publish_word(int* flag, int word, int value, hipStream_t s);
 void launch_gh_apply(const LeafArgs& a, const float* Cv, float* Sp, hipStream_t s);
 // blocked form of gh_solve (kernels_solve.hip): same inputs and outputs
-void launch_gh_solve3(const LeafArgs& a, const double* G, float* Cv, int* flag, hipStream_t s);
+void launch_gh_solve3(const LeafArgs& a, const double* G, float* Cv, int* flag, hipStream_t s, const SolveWait* ws = nullptr);
 // Y[M1 x 128] (fp16, ld ldy) = fp16(sum of nslab X slabs, M1 x 128 fp32) * T', Bt[n][k] = T'[k][n] (fp16, ld ldb), tri as GemmArgs::tri
 void launch_leaf_xt(const float* X, int nslab, long slab_stride, int M1, const half_t* Bt, long ldb, int tri, half_t* Y, long ldy,
                     const float* cscale, long cscale_ld, hipStream_t s, int* pub_flag = nullptr, int pub_value = 0);
