@@ -86,28 +86,36 @@ def gemm_source_sha():
 
 def _pmc_traffic():
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes of this same command
-    (profiles/, tools/pmc_traffic.py); PMC counters cannot be read from inside the timed run.  Returns (bytes or None, source):
-    the figure is only quoted when the profile was taken on THIS build's GEMM sources (`kernel_source_sha` in the profile,
-    written by tools/collect_profiles.sh) -- a stale profile yields traffic = null and says why in `traffic_source`."""
+    (profiles/*_traffic_rmw.json, tools/pmc_traffic.py); PMC counters cannot be read from inside the timed run.  Returns (bytes or None,
+    source).  The figure is quoted only (1) when the profile was taken on THIS build's GEMM sources (`kernel_source_sha`) and (2) together
+    with the algorithmic bytes and the launch count of exactly the launches it was measured on (the tool matches the PMC rows launch by
+    launch against mpqr_get_update_records; round 4 compared 24 launches of a truncated pass with the algorithmic bytes of 37): `source`
+    carries launches / algorithmic_bytes_per_launch / ratio, for the whole set and for the far updates and Q formation separately."""
     best = None
     pdir = os.path.join(ROOT, "profiles")
     if os.path.isdir(pdir):
         for f in sorted(os.listdir(pdir)):
-            if f.endswith("traffic_far_nn.json"):
+            if f.endswith("traffic_rmw.json"):
                 try:
                     best = (f, json.load(open(os.path.join(pdir, f))))
                 except Exception:
                     pass
     if best is None:
-        return None, {"file": None, "note": "no PMC profile committed"}
+        return None, {"file": None, "note": "no PMC profile of this build's format committed"}
     f, d = best
     sha = gemm_source_sha()
     src = {"file": "profiles/" + f, "profile_kernel_source_sha": d.get("kernel_source_sha"), "build_kernel_source_sha": sha,
-           "how": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) of `python bench.py --steps 1 --warmup 0`, FETCH_SIZE x 2 (gfx950), per launch"}
+           "how": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) of `python bench.py --steps 1 --warmup 0 --dump-records`, FETCH_SIZE x 2 "
+                  "(gfx950), matched launch by launch against the library's records (tools/pmc_traffic.py)"}
     if d.get("kernel_source_sha") != sha:
         src["note"] = "profile taken on other GEMM sources than this build: not quoted"
         return None, src
-    return d["hbm_bytes_per_launch"], src
+    src.update({"launches": d.get("launches"), "complete": d.get("complete"), "algorithmic_bytes_per_launch": d.get("algorithmic_bytes_per_launch"),
+                "ratio": d.get("ratio")})
+    for k in ("far", "q"):
+        if k in d:
+            src[k] = {kk: d[k].get(kk) for kk in ("launches", "records", "complete", "measured_bytes", "algorithmic_bytes", "ratio", "dispatch_ids_fetch_pass")}
+    return d.get("hbm_bytes_per_launch"), src
 
 
 def main():
@@ -123,6 +131,8 @@ def main():
     ap.add_argument("--alone", action="store_true", help="also time the dominant GEMM kernels alone on the GPU at this run's shapes (roofline.kernel_alone); "
                     "off by default: those launches carry the same kernel names as the factorisation's and would enter a profiler's per-kernel averages")
     ap.add_argument("--no-lookahead", action="store_true")
+    ap.add_argument("--dump-records", default=None, help="write the last step's recorded C -= V Y^T launches (launch order: M, N, K, algorithmic "
+                    "flops and bytes; far updates and Q formation) to this JSON file: tools/pmc_traffic.py matches a PMC pass of the same command against it")
     ap.add_argument("--precision", default=None, choices=["fp16", "fp8", "fp32"],
                     help="operand precision of the trailing-update GEMMs (default: fp8 for c5 = BASELINE config 5, fp16 otherwise)")
     args = ap.parse_args()
@@ -175,6 +185,10 @@ def main():
     # of the panel chain no other kernel can overlap (breakdown_ms.ms_gh_solve)
     us_solve = h.bench_leaf_solve(min(r, 128), 50) if prec_name != "fp32" else 0.0
     tm = h.timings()                      # HIP-event timings of the LAST step, on the library's own stream
+    if args.dump_records:
+        with open(args.dump_records, "w") as fh:
+            json.dump({"config": args.config, "m": m, "n": n, "r": r, "records": h.update_records(),
+                       "n_far_launches": tm["n_far_launches"], "n_q_launches": tm["n_q_launches"]}, fh, indent=1)
     mt = h.metrics()
     # dominant kernel: the far trailing-update GEMM  A2 -= V Y^T  (fp16 MFMA, K = outer block); achieved =
     # algorithmic flops (2 M N K summed over its launches) / their HIP-event time on the library's update stream

@@ -162,6 +162,12 @@ int mpqr_gemm_test_f32(mpqr_handle_t h, const float* A, const float* B, float* C
  * mode:   0: C = A B (fp32 store), 1: fp16 store, 2: C -= A B (fp32 read-modify-write), 3: mode 2 + the transposed fp16 shadow store.
  * M, N multiples of 256, K of 64.  Replaces nothing in the reference (its GEMM tests check values only, Cuda/mmult.cuh:387-435). */
 int mpqr_bench_gemm(mpqr_handle_t h, int kernel, int mode, int M, int N, int K, int iters, float* ms_per_launch);
+/* measurement aid (bench.py --dump-records, tools/pmc_traffic.py): the recorded read-modify-write GEMM launches  C -= V Y^T  of the last
+ * factorisation IN LAUNCH ORDER -- the far trailing updates (is_q = 0; one per launch of the far-update stream) and Q formation's applies
+ * (is_q = 1) -- with their algorithmic flops (2 M N K), algorithmic HBM bytes (fp32 C read + write, the fp16 shadow where it is written,
+ * both fp16 operands once) and dims[3 i .. 3 i + 2] = M (rows), N (columns), K.  *n = number of records (also when cap is smaller).  A PMC
+ * pass of the same command is matched against this list launch by launch, so that measured and algorithmic bytes cover the SAME launches. */
+int mpqr_get_update_records(mpqr_handle_t h, int cap, double* flops, double* bytes, int* dims, int* is_q, int* n);
 /* measurement aid (bench.py: roofline.mfma_measured): a bare MFMA loop on random fp16 operands held in registers, one 512-thread
  * workgroup per CU, shape 0 = v_mfma_f32_32x32x16_f16, 1 = v_mfma_f32_16x16x32_f16 -> TFLOP/s of the whole device and the shader clock
  * it holds meanwhile (GHz).  The dense peak of MI355X_MICROARCH.md (2.5 PFLOP/s) is width x 2.4 GHz; under load the chip lowers its

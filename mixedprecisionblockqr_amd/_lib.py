@@ -71,6 +71,7 @@ SIGNATURES = {
     "mpqr_gemm_test_f32": (_i, [_H, _f32, _f32, _f32, _i, _i, _i, _i, _i]),
     "mpqr_bench_gemm": (_i, [_H, _i, _i, _i, _i, _i, _i, C.POINTER(C.c_float)]),
     "mpqr_bench_mfma_peak": (_i, [_H, _i, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
+    "mpqr_get_update_records": (_i, [_H, _i, _p, _p, _p, _p, C.POINTER(C.c_int)]),
     "mpqr_get_factor_host": (_i, [_H, _f32]),
     "mpqr_get_q_host": (_i, [_H, _f32]),
     "mpqr_get_r_host": (_i, [_H, _f32]),

@@ -88,6 +88,19 @@ class Handle:
         self._chk(L.lib().mpqr_bench_mfma_peak(self._h, shape, C.byref(tf), C.byref(ghz)))
         return tf.value, ghz.value
 
+    def update_records(self):
+        """The recorded C -= V Y^T launches of the last factorisation in launch order (far updates, then Q formation):
+        list of dicts {set, M, N, K, flops, bytes} (include/mpqr.h: mpqr_get_update_records)."""
+        n = C.c_int()
+        self._chk(L.lib().mpqr_get_update_records(self._h, 0, None, None, None, None, C.byref(n)))
+        k = n.value
+        fl, by = np.zeros(k, np.float64), np.zeros(k, np.float64)
+        dm, iq = np.zeros(3 * k, np.int32), np.zeros(k, np.int32)
+        self._chk(L.lib().mpqr_get_update_records(self._h, k, fl.ctypes.data_as(C.c_void_p), by.ctypes.data_as(C.c_void_p),
+                                                  dm.ctypes.data_as(C.c_void_p), iq.ctypes.data_as(C.c_void_p), C.byref(n)))
+        return [{"set": "q" if iq[i] else "far", "M": int(dm[3 * i]), "N": int(dm[3 * i + 1]), "K": int(dm[3 * i + 2]),
+                 "flops": float(fl[i]), "bytes": float(by[i])} for i in range(k)]
+
     def bench_leaf_solve(self, w=128, iters=50):
         """Mean launch time (us) of the serial core of one Gram-Householder leaf of width w, timed alone."""
         us = C.c_float()

@@ -206,6 +206,7 @@ struct mpqr_handle_s {
     size_t far_used = 0;
     std::vector<double> far_flops;
     std::vector<double> far_bytes;     // algorithmic HBM bytes of the same launches' C -= V Y^T
+    std::vector<int> far_dims;         // M, N, K of the same launches (3 per record): mpqr_get_update_records
     std::vector<hipEvent_t> chain_ev; // pool, 2 per top-level block: around factor_node on the chain stream
     size_t chain_used = 0;
     mpqr_timings last_t;
@@ -598,6 +599,7 @@ void apply_node(mpqr_handle_t h, const Node& nd, float* C, long ldc, int clo, in
         HIPQ(h, hipEventRecord(e3, st));
         h->far_flops.push_back(2.0 * M1 * (double)Kr * Kw);
         h->far_bytes.push_back((g3.Ct ? 10.0 : 8.0) * M1 * (double)Kw + 2.0 * Kr * ((double)M1 + Kw));
+        h->far_dims.push_back(Kw); h->far_dims.push_back(M1); h->far_dims.push_back(Kr);
     }
 }
 
@@ -1196,6 +1198,7 @@ static int form_q_one_shot(mpqr_handle_t h) {
         h->q_first = h->far_used; h->far_used += 4;
         h->far_flops.push_back(2.0 * (double)h->m * (double)h->m * Kr);
         h->far_bytes.push_back(4.0 * (double)h->m * h->m + 2.0 * Kr * (2.0 * h->m));
+        h->far_dims.push_back(h->m); h->far_dims.push_back(h->m); h->far_dims.push_back(Kr);
     }
     GemmArgs w{};                                         // W[m x Kr] = V T   (T upper triangular: k <= n)
     w.A = h->Vh + (long)rlo * h->ldvh + rt.a0; w.lda = h->ldvh;
@@ -1697,11 +1700,11 @@ static int run_block_loop(mpqr_handle_t h, int start = 0) {
         // restart: the aborted pass's recordings for blocks >= start describe work that is thrown away -- rewind the event pools to
         // where block `start` began, so that ms_panel / ms_far_* / the roofline figures cover only work that is kept
         h->far_used = h->far_mark[start]; h->chain_used = h->chain_mark[start];
-        h->far_flops.resize(h->far_used / 4); h->far_bytes.resize(h->far_used / 4);
+        h->far_flops.resize(h->far_used / 4); h->far_bytes.resize(h->far_used / 4); h->far_dims.resize(3 * (h->far_used / 4));
     }
     if (start <= 0) {
         start = 0;
-        h->far_used = 0; h->far_flops.clear(); h->far_bytes.clear(); h->chain_used = 0;
+        h->far_used = 0; h->far_flops.clear(); h->far_bytes.clear(); h->far_dims.clear(); h->chain_used = 0;
         if (!h->copied_in)                                  // (a later pass from block 0; the first one found the copy made by mpqr_factor)
             HIPCHK(h, hipMemcpyAsync(h->dA, h->dA0, (size_t)h->m_pad * h->lda * sizeof(float), hipMemcpyDeviceToDevice, h->s0));
         h->copied_in = false;
@@ -2026,6 +2029,20 @@ int mpqr_get_timings(mpqr_handle_t h, mpqr_timings* t) {
 
 // measurement aid: the serial core of a Gram-Householder leaf (gh_solve, one workgroup) timed alone on scratch data -- an
 // identity-dominated Gram matrix and a unit top block; the kernel's instruction stream does not depend on the values.
+int mpqr_get_update_records(mpqr_handle_t h, int cap, double* flops, double* bytes, int* dims, int* is_q, int* n) {
+    int rc = need_plan(h, true); if (rc) return rc;
+    if (!n) return MPQR_ERR_INVALID;
+    const size_t nr = std::min({h->far_flops.size(), h->far_bytes.size(), h->far_dims.size() / 3, h->far_used / 4});
+    *n = (int)nr;
+    for (size_t i = 0; i < nr && (int)i < cap; i++) {
+        if (flops) flops[i] = h->far_flops[i];
+        if (bytes) bytes[i] = h->far_bytes[i];
+        if (dims) { dims[3 * i] = h->far_dims[3 * i]; dims[3 * i + 1] = h->far_dims[3 * i + 1]; dims[3 * i + 2] = h->far_dims[3 * i + 2]; }
+        if (is_q) is_q[i] = (4 * i >= h->q_first) ? 1 : 0;
+    }
+    return MPQR_OK;
+}
+
 int mpqr_bench_leaf_solve(mpqr_handle_t h, int w, int iters, float* us_per_launch) {
     if (!h || !us_per_launch || w < 1 || w > 128 || iters < 1) return MPQR_ERR_INVALID;
     HIPCHK(h, hipSetDevice(h->device));
@@ -2716,7 +2733,7 @@ int mpqr_dist_begin(mpqr_handle_t h, float absmax) {
     float sc = 1.f;
     if (absmax > 0.f && std::isfinite(absmax)) { int e; frexpf(absmax * sqrtf((float)h->m), &e); sc = ldexpf(1.f, 8 - e); }
     h->a_scale = sc;
-    h->far_used = 0; h->far_flops.clear(); h->far_bytes.clear(); h->chain_used = 0; h->v8_node = -1;
+    h->far_used = 0; h->far_flops.clear(); h->far_bytes.clear(); h->far_dims.clear(); h->chain_used = 0; h->v8_node = -1;
     h->pairs_ready = false; h->n_passes = 1; h->n_robust_leaves = 0; h->n_gh_leaves = 0;
     HIPCHK(h, hipEventRecord(h->ev[0], h->s0));
     HIPCHK(h, hipMemcpyAsync(h->dA, h->dA0, (size_t)h->m_pad * h->lda * sizeof(float), hipMemcpyDeviceToDevice, h->s0));

@@ -3,7 +3,7 @@
 tag=$1; shift
 root=${GRAFT_REPO_ROOT:-/root/repo}
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum TCC_REQ_sum -d $root/gpurun_out/pmc_l2_$tag -o l2 --output-format csv -- python3 $root/bench.py --no-cpu-baseline --no-dropin --no-alone --steps 1 --warmup 0 --no-lookahead "$@" > $root/gpurun_out/pmc_l2_$tag.log 2>&1
+MPQR_TPOLL=0 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum TCC_REQ_sum -d $root/gpurun_out/pmc_l2_$tag -o l2 --output-format csv -- python3 $root/bench.py --no-cpu-baseline --no-dropin --no-alone --steps 1 --warmup 0 --no-lookahead "$@" > $root/gpurun_out/pmc_l2_$tag.log 2>&1
 cd $root
 python3 - "$(find gpurun_out/pmc_l2_$tag -name "l2_counter_collection.csv" | head -1)" <<'PY'
 import csv, sys, collections

@@ -2,7 +2,7 @@
 cfg=${1:-c4}
 root=${GRAFT_REPO_ROOT:-/root/repo}
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE -d $root/gpurun_out/pmc_sq -o $cfg --output-format csv -- python3 $root/bench.py --config $cfg --no-cpu-baseline --no-dropin --no-alone --steps 1 --warmup 0 > $root/gpurun_out/pmc_sq_$cfg.log 2>&1
+MPQR_TPOLL=0 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE -d $root/gpurun_out/pmc_sq -o $cfg --output-format csv -- python3 $root/bench.py --config $cfg --no-cpu-baseline --no-dropin --no-alone --steps 1 --warmup 0 > $root/gpurun_out/pmc_sq_$cfg.log 2>&1
 cd $root
 python3 - "$(find gpurun_out/pmc_sq -name "${cfg}_counter_collection.csv" | head -1)" <<'PY'
 import csv, sys, collections
