@@ -124,6 +124,7 @@ struct mpqr_handle_s {
     half_t* Yfl = nullptr;        // Y = fp16(X T') for the next panel, 128 x 128
     int gram_ready_c0 = -1, gram_ready_rows = 0, gram_ready_n = 0;   // leaf_b left the partial Gram matrices (n of them) of the leaf that starts at this column, over this many rows
     int n_fused_leaves = 0;       // of the last mpqr_factor
+    unsigned long long* dbg_stamps = nullptr; int dbg_stamps_n = 0;   // MPQR_DBG_STAMPS=1: start / end device times of every flat-schedule gh_solve (mapped host memory)
     int rest_seq = 0;             // value the T stream last published in tflag[3] behind a deferred update the chain waits for (polling plans)
     bool rest_in_solve = false;   // ... and the gh_solve launched last polls it at its end (no event wait in front of the next launch)
     int rest_first_cols = 0;      // apply_node, lane 2: the update's first this-many columns as a launch of their own, ev_rest recorded behind it
@@ -259,6 +260,7 @@ void free_plan(mpqr_handle_t h) {
                     h->S2, h->tmp1b, h->tmp2b, h->Qt, h->At, h->Xh, h->Wh, h->Xl, h->Xh1, h->Xl1};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (h->hflag_host) (void)hipHostFree(h->hflag_host);
+    if (h->dbg_stamps) { (void)hipHostFree(h->dbg_stamps); h->dbg_stamps = nullptr; h->dbg_stamps_n = 0; }
     h->hflag_host = h->hflag_dev = nullptr; h->flag_words = 0; h->cur_block = 0;
     h->S2 = h->tmp1b = h->tmp2b = nullptr; h->s2_elems = 0; h->Qt = nullptr; h->shadow = nullptr; h->At = nullptr; h->at_read = false; h->Xh = nullptr; h->Xl = h->Xh1 = h->Xl1 = nullptr; h->Wh = nullptr; h->qroot = -1; h->qmerge_after.clear(); h->qpair.clear(); h->pairs_ready = false;
     h->dA = h->dA0 = h->dQ = nullptr; h->Vh = h->Vt = nullptr; h->vdiag = nullptr; h->Xt = nullptr; h->Yt = nullptr;
@@ -896,10 +898,14 @@ int factor_block_flat(mpqr_handle_t h, int top, const std::vector<int>& leaves) 
             // the previous block's far update is enqueued HERE (run_block_loop): its stream starts when this leaf's gh_solve does,
             // so its first GEMMs fill the other 255 CUs during the solve instead of holding them while gh_gram wants them
             if (h->far_hook) { auto fh = std::move(h->far_hook); h->far_hook = nullptr; if ((rc = fh())) return rc; }
+            unsigned long long* stamp = (h->dbg_stamps && 2 * (lf.c0 / 128) + 1 < h->dbg_stamps_n) ? h->dbg_stamps + 2 * (lf.c0 / 128) : nullptr;
             if (h->rest_pending && rest_polls(h)) {            // this solve ends by polling the T stream's word: nothing to wait for behind it
-                const SolveWait ws{h->tflag, 3, h->rest_seq, h->hflag_dev + h->flag_words - 1, h->tpoll_ticks};
+                const SolveWait ws{h->tflag, 3, h->rest_seq, h->hflag_dev + h->flag_words - 1, h->tpoll_ticks, stamp};
                 launch_gh_solve(a, h->Gs, h->Cv, h->dflag + (id < h->nflag ? id : 0), h->s0, &ws);
                 h->rest_in_solve = true;
+            } else if (stamp) {
+                const SolveWait ws{nullptr, 0, 0, nullptr, 0, stamp};
+                launch_gh_solve(a, h->Gs, h->Cv, h->dflag + (id < h->nflag ? id : 0), h->s0, &ws);
             } else
             launch_gh_solve(a, h->Gs, h->Cv, h->dflag + (id < h->nflag ? id : 0), h->s0);
             gh_args = a;                                     // (gh_apply, or the fused leaf's leaf_a, is launched below once the leaf's form is known)
@@ -1571,6 +1577,14 @@ static int plan_common(mpqr_handle_t h, int m, int n, int r, const mpqr_opts* op
         HIPCHK(h, hipHostGetDevicePointer(&dp, hp, 0));
         h->hflag_dev = (int*)dp;
     }
+    {
+        static const int stamps_env = []() { const char* e = getenv("MPQR_DBG_STAMPS"); return e ? atoi(e) : 0; }();
+        if (stamps_env && !h->dbg_stamps) {
+            void* hp = nullptr;
+            h->dbg_stamps_n = 2 * (h->n_pad / 128 + 2);
+            if (hipHostMalloc(&hp, (size_t)h->dbg_stamps_n * 8, hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess) { h->dbg_stamps = (unsigned long long*)hp; memset(hp, 0, (size_t)h->dbg_stamps_n * 8); }
+        }
+    }
     h->leaf_robust.assign(h->nodes.size(), 0);
     // T arena of a robustly factored tall leaf (sub-tree of 32-column leaves over <= 128 columns: 7 nodes, ldt <= 192)
     h->rb_elems = (size_t)8 * 192 * 192;
@@ -2013,6 +2027,17 @@ int mpqr_get_timings(mpqr_handle_t h, mpqr_timings* t) {
             if (i + 2 < h->chain_used) (void)hipEventElapsedTime(&gap, h->chain_ev[i + 1], h->chain_ev[i + 2]);
             fprintf(stderr, "mpqr: block %2zu chain %8.1f us, then %6.1f us before the next block\n", i / 2, x * 1e3f, gap * 1e3f);
         }
+    }
+    if (h->dbg_stamps) {                                   // measurement aid: unprofiled leaf periods (gh_solve start to start) and the time between two solves
+        fprintf(stderr, "mpqr: leaf solve-start period / solve time / time to the next solve (us), 8 leaves per line:\n");
+        const int nl = h->n / 128;
+        for (int l = 0; l + 1 < nl; l++) {
+            const unsigned long long s0_ = h->dbg_stamps[2 * l], e0 = h->dbg_stamps[2 * l + 1], s1_ = h->dbg_stamps[2 * l + 2];
+            if (!s0_ || !s1_) continue;
+            fprintf(stderr, "%s%5.0f/%3.0f/%4.0f", (l % 8) ? " " : "mpqr:  ", (s1_ - s0_) * 0.01, (e0 - s0_) * 0.01, (s1_ - e0) * 0.01);
+            if ((l % 8) == 7) fprintf(stderr, "\n");
+        }
+        fprintf(stderr, "\n");
     }
     t->ms_panel = ch;
     t->ms_chain_wait = t->ms_factor - ch;

@@ -369,6 +369,7 @@ __device__ __forceinline__ void s3_b_update(float4s& acc, const float* vp, const
 
 __global__ __launch_bounds__(S3_THREADS) void gh_solve3_kernel(LeafArgs a, const double* __restrict__ G, float* __restrict__ Cv,
                                                                int* __restrict__ flag, SolveWait ws) {
+    if (ws.stamp && threadIdx.x == 0) ws.stamp[0] = __builtin_amdgcn_s_memrealtime();
     float* Ws = (float*)(gh_smem + S3_OFF_WS);
     double* buf = (double*)(gh_smem + S3_OFF_BUF);
     float* bpr = (float*)(gh_smem + S3_OFF_BPR);
@@ -713,6 +714,7 @@ __global__ __launch_bounds__(S3_THREADS) void gh_solve3_kernel(LeafArgs a, const
             }
         }
     }
+    if (ws.stamp && tid == 0) ws.stamp[1] = __builtin_amdgcn_s_memrealtime();
     KT(); KT_DUMP(7, "gh_solve3 zero|loads|barrier0|loop|out|inverse|cstore");
 #ifdef MPQR_KTRACE
     __syncthreads();

@@ -135,7 +135,8 @@ int gh_num_partials(const LeafArgs& a);
 // the same leaf in separately launchable steps
 void launch_gh_gram(const LeafArgs& a, double* Gp, double* G, hipStream_t s);
 // gh_solve can end by polling a progress word of ANOTHER stream (flag[word] >= value; flag[1] = "a wait has timed out", see wait_flag_kernel)
-struct SolveWait { int* flag; int word; int value; int* timeout_word; unsigned long long ticks; };
+struct SolveWait { int* flag; int word; int value; int* timeout_word; unsigned long long ticks;
+                   unsigned long long* stamp; };     // measurement aid (MPQR_DBG_STAMPS): stamp[0] / stamp[1] = s_memrealtime (100 MHz) at the kernel's start / end
 void launch_gh_solve(const LeafArgs& a, const double* G, float* Cv, int* flag, hipStream_t s, const SolveWait* ws = nullptr);
 // one thread stores flag[word] = value (a stream publishes "everything I have run so far is complete")
 void launch_publish_word(int* flag, int word, int value, hipStream_t s);

@@ -314,15 +314,24 @@ def bench_main(args, m, n, r, world, rank, local_rank, cpu_baseline_fn=None):
 
     # host-side verification on a gloo side group (the m-vectors stay on the host)
     chk = None
+    g = None
     try:
         g = dist.new_group(backend="gloo") if world > 1 else None
         chk = residual_check(eng, comm, group=g)
     except Exception as e:  # verification must never take the benchmark down
         chk = {"error": repr(e)}
+    # every rank's own HIP-event timings of the last step, gathered on rank 0 (max / sum over ranks below)
+    tm = eng.timings()
+    tms = [tm]
+    if world > 1:
+        try:
+            tms = [None] * world
+            dist.all_gather_object(tms, tm, group=g)
+        except Exception:
+            tms = [tm]
     if rank == 0:
         from . import api
         fl = api.flops(m, n, r)
-        tm = eng.timings()              # rank 0's own HIP-event timings of the last step
         roof = None
         if tm["n_far_launches"] > 0 and tm["ms_far_nn"] > 0:
             ach = tm["flops_far_nn"] / (tm["ms_far_nn"] * 1e-3) / 1e12
@@ -345,9 +354,21 @@ def bench_main(args, m, n, r, world, rank, local_rank, cpu_baseline_fn=None):
                        "parallelism": f"{world} gpu(s), 1-D block-cyclic column superblocks, look-ahead, RCCL broadcast of V,T per block"},
             "error": chk,
             "breakdown_ms_rank0": {k: tm[k] for k in ("ms_total", "ms_factor", "ms_form_q", "ms_trailing", "ms_panel", "ms_far_tn", "ms_far_nn")},
+            # max over ranks of every phase (the step is as long as its slowest rank), and the panel chain summed over the ranks: block t + 1
+            # cannot start before block t's reflectors exist, so the owners' chains add up (the quantity tools/scale_model.py budgets)
+            "breakdown_ms_max_over_ranks": {k: max(t_[k] for t_ in tms) for k in ("ms_total", "ms_factor", "ms_form_q", "ms_trailing", "ms_panel", "ms_far_tn", "ms_far_nn")},
+            "ms_panel_sum_over_ranks": sum(t_["ms_panel"] for t_ in tms), "ranks_reporting": len(tms),
+            "comm": {"backend": (dist.get_backend() if world > 1 else "none"), "world_size": (dist.get_world_size() if world > 1 else 1),
+                     "note": "backend nccl = RCCL on ROCm; one broadcast of [V^T | T | T^T] per top-level block"},
             "gflops_with_q_flops": (fl["geqrf"] + fl["form_q"]) / dt / 1e9,
             "roofline": roof,
         }
+        # the panel step against the HBM roof, as at N = 1 (2 W r 4 bytes per panel): chain time = the owners' chains added up
+        pbytes = sum(2.0 * (m - lam) * min(r, n - lam) * 4 for lam in range(0, n, r))
+        psum = sum(t_["ms_panel"] for t_ in tms)
+        if roof is not None and psum > 0:
+            roof["panel"] = {"bound": "hbm", "algorithmic_bytes": pbytes, "ms": psum, "achieved": pbytes / (psum * 1e-3) / 1e9, "peak": 8000.0,
+                             "unit": "GB/s", "frac": pbytes / (psum * 1e-3) / 1e9 / 8000.0, "note": "ms = sum over ranks of ms_panel (the owners' chains are serial)"}
         if cpu_baseline_fn is not None and not args.no_cpu_baseline:
             out["cpu_baseline"], port = cpu_baseline_fn()
             if port is not None:
