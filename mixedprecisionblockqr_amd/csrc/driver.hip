@@ -1767,7 +1767,11 @@ static int run_block_loop(mpqr_handle_t h, int start = 0) {
     {
         std::vector<int> lv;
         static const int ext_on = []() { const char* e = getenv("MPQR_EXT_LOOKAHEAD"); return e ? atoi(e) : 1; }();
-        static const int ext_leaves = []() { const char* e = getenv("MPQR_EXT_LEAVES"); return e ? std::max(1, atoi(e)) : 2; }();
+        // (round 5: four leaves with the fused leaf -- the chain stream then works on ONE next panel per leaf whatever the range, the wider
+        //  range only costs the T stream's deferred updates a few columns, and the wait for part (a) moves from the block's second leaf,
+        //  where gh_solve's final poll sat 100 - 250 us in every block (MPQR_DBG_STAMPS), to its fourth: 33.45 -> 33.03 ms; 5 / 6 / 8: 33.4 / 34.0 / 35.2)
+        static const int ext_env = []() { const char* e = getenv("MPQR_EXT_LEAVES"); return e ? std::max(1, atoi(e)) : 0; }();
+        const int ext_leaves = ext_env ? ext_env : ((h->fused_leaf && h->Xp) ? 4 : 2);
         for (size_t t = 0; t < nt; t++) {
             flat[t] = flat_block_ok(h, h->tops[t], lv);
             ext[t] = la && ext_on && h->tq_on && t + 1 < nt && flat[t];
