@@ -211,7 +211,7 @@ def main():
                 "traffic": None, "launches": tm["n_far_launches"] + (tm.get("n_q_launches", 0) if q_nn else 0),
                 "avg_launch_ms": (tm["ms_far_nn"] + (tm["ms_q_nn"] if q_nn else 0.0)) / (tm["n_far_launches"] + (tm.get("n_q_launches", 0) if q_nn else 0)),
                 "far_update_achieved": ach_far, "q_formation_achieved": q_nn,
-                "q_formation_tn_achieved": (tm["tflop_q"] / (tm["ms_q_tn"] * 1e-3)) if q_nn and tm["ms_q_tn"] > 0 else None,
+                "q_formation_tn_achieved": (tm["tflop_q_tn"] / (tm["ms_q_tn"] * 1e-3)) if q_nn and tm["ms_q_tn"] > 0 else None,      # executed flops (identity / zero parts of Q skipped)
                 "tn_achieved": (tm["flops_far_tn"] / (tm["ms_far_tn"] * 1e-3) / 1e12) if tm["ms_far_tn"] > 0 else None}
         if args.config == "c4" and not args.outer_block and prec_name == "fp16":
             roof["traffic"], roof["traffic_source"] = _pmc_traffic()

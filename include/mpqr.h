@@ -100,6 +100,10 @@ typedef struct mpqr_timings {
     int   restart_block;  /* the top-level block the LAST pass started from (n_passes > 1: a flagged leaf's block; the blocks left of it were kept) */
     int   n_fused_leaves; /* leaves of the last pass whose chain-stream work between two solves ran as the three fused launches (leaf_a / leaf_m / leaf_b) */
     int   n_tpoll_retries;/* 1: a polling wait of the T stream timed out and the factorisation was repeated with event hand-offs (stderr says so) */
+    int   n_deflated_columns; /* columns whose Gram-Householder pivot was clamped at its threshold (rho_k < 1e-8: numerically dependent on their
+                             predecessors) in the last factorisation's last pass: handled in line, R_kk off by <= 1e-4 ||a_k||, no restart  */
+    float tflop_q_tn;     /* flops (1e12) the X = Q2^T V launches of Q formation EXECUTED: identity columns of Q are copied and the zero rows of the
+                             untouched columns are skipped, so this is less than tflop_q (which the Q2 -= V Y^T launches execute in full)     */
 } mpqr_timings;
 
 typedef struct mpqr_handle_s* mpqr_handle_t;

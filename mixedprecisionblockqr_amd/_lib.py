@@ -34,7 +34,7 @@ class MpqrTimings(C.Structure):
                 ("n_robust_leaves", C.c_int), ("ms_q_tn", C.c_float), ("ms_q_nn", C.c_float), ("n_q_launches", C.c_int),
                 ("tflop_q", C.c_float), ("ms_host_enqueue", C.c_float), ("gbytes_far_nn", C.c_double), ("gbytes_q_nn", C.c_double),
                 ("n_gh_leaves", C.c_int), ("us_gh_solve", C.c_float), ("n_q_ident_rows", C.c_int), ("restart_block", C.c_int),
-                ("n_fused_leaves", C.c_int), ("n_tpoll_retries", C.c_int)]
+                ("n_fused_leaves", C.c_int), ("n_tpoll_retries", C.c_int), ("n_deflated_columns", C.c_int), ("tflop_q_tn", C.c_float)]
 
 
 def build(force=False):

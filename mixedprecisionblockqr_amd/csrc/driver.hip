@@ -125,7 +125,10 @@ struct mpqr_handle_s {
     int gram_ready_c0 = -1, gram_ready_rows = 0, gram_ready_n = 0;   // leaf_b left the partial Gram matrices (n of them) of the leaf that starts at this column, over this many rows
     int n_fused_leaves = 0;       // of the last mpqr_factor
     unsigned long long* dbg_stamps = nullptr; int dbg_stamps_n = 0;   // MPQR_DBG_STAMPS=1: start / end device times of every flat-schedule gh_solve (mapped host memory)
+    std::vector<double> far_flops_tn;  // flops the X GEMM of the same record EXECUTED (Q formation skips identity / zero parts of Q: less than far_flops)
     int rest_seq = 0;             // value the T stream last published in tflag[3] behind a deferred update the chain waits for (polling plans)
+    bool rest_split = false;      // ... and it was announced behind its first 128 columns only (fused leaf)
+    bool next_block_flat = false; // run_block_loop: the block after the one being factored takes the flat schedule (its first leaf handles a pending deferred update)
     bool rest_in_solve = false;   // ... and the gh_solve launched last polls it at its end (no event wait in front of the next launch)
     int rest_first_cols = 0;      // apply_node, lane 2: the update's first this-many columns as a launch of their own, ev_rest recorded behind it
     bool rest_recorded = false;   // ... done: the caller does not record ev_rest again
@@ -509,6 +512,11 @@ void apply_node(mpqr_handle_t h, const Node& nd, float* C, long ldc, int clo, in
                 g1.C = Xhi + (long)idc * Kr; if (Xlo) g1.C2 = Xlo + (long)idc * Kr;
                 g1.M = M1 - idc;
                 h->n_q_ident_rows += idc;
+                // ... and the OTHER columns of Q (right of the node's own) are still zero in the node's own rows [c0, c1): every apply so far
+                // touched rows >= its own first column >= c1 only.  Their K range starts at row c1 (round 5: 14 % of Q formation's X flops)
+                if (idc == nd.c1 - nd.c0 && (idc % 64) == 0 && Kw - idc >= 64) {
+                    g1.A = (const half_t*)g1.A + idc; g1.Bt += idc; g1.K = Kw - idc;
+                }
             }
             gemm_dispatch(A_H16, E_STORE_H16, g1, st1);
         }
@@ -602,6 +610,7 @@ void apply_node(mpqr_handle_t h, const Node& nd, float* C, long ldc, int clo, in
         h->far_flops.push_back(2.0 * M1 * (double)Kr * Kw);
         h->far_bytes.push_back((g3.Ct ? 10.0 : 8.0) * M1 * (double)Kw + 2.0 * Kr * ((double)M1 + Kw));
         h->far_dims.push_back(Kw); h->far_dims.push_back(M1); h->far_dims.push_back(Kr);
+        h->far_flops_tn.push_back(2.0 * (double)g1.M * (double)Kr * (double)g1.K);
     }
 }
 
@@ -622,7 +631,7 @@ static inline bool flag_words_set(mpqr_handle_t h, int upto) {
 }
 // Checked before every leaf: any raised word ends the pass (everything downstream of a flagged leaf is redone anyway).
 static inline bool pass_is_flagged(mpqr_handle_t h) {
-    return h->watch_flags && flag_words_set(h, h->flag_words - 1);      // (the last word is the T stream's time-out word)
+    return h->watch_flags && flag_words_set(h, h->flag_words - 2);      // (the last two words: the T stream's time-out word, the deflated-columns count)
 }
 
 // Robust path for a tall (<=128-column) leaf: factor it through a temporary sub-tree of 32-column leaves
@@ -667,15 +676,21 @@ static void rest_done(mpqr_handle_t h, hipStream_t st) {
     if (rest_polls(h)) launch_publish_word(h->tflag, 3, ++h->rest_seq, st);
     else HIPQ(h, hipEventRecord(h->ev_rest, st));
 }
-// chain stream: wait for it (unless the last gh_solve already did, at its end)
-static void rest_wait(mpqr_handle_t h) {
+// chain stream: wait for it (unless the last gh_solve already did, at its end).  A fused leaf's deferred update announces itself behind its FIRST
+// 128 columns -- all the next fused leaf's chain work reads; the other columns are ordered by the T stream itself, where the next leaf's
+// deferred update follows.  A leaf that is NOT fused (robust path, tail, ragged end, tree-scheduled block) updates the whole range on the
+// chain stream: it waits for everything the T stream has been given so far (need_all; an event recorded now -- rare, so its cost does not matter).
+static void rest_wait(mpqr_handle_t h, bool need_all) {
     if (!h->rest_pending) return;
     static const int dbg_norestwait = []() { const char* e = getenv("MPQR_DBG_NORESTWAIT"); return e ? atoi(e) : 0; }();   // timing experiment only (a race)
-    if (!dbg_norestwait) {
+    if (need_all && h->rest_split) {
+        HIPQ(h, hipEventRecord(h->ev_rest, h->sT));
+        HIPQ(h, hipStreamWaitEvent(h->s0, h->ev_rest, 0));
+    } else if (!dbg_norestwait) {
         if (!rest_polls(h)) HIPQ(h, hipStreamWaitEvent(h->s0, h->ev_rest, 0));
         else if (!h->rest_in_solve) launch_wait_flag(h->tflag, h->rest_seq, h->hflag_dev + h->flag_words - 1, h->tpoll_ticks, h->s0, 3);
     }
-    h->rest_pending = false; h->rest_in_solve = false;
+    h->rest_pending = false; h->rest_in_solve = false; h->rest_split = false;
 }
 // the Gram matrix of a Gram-Householder leaf: gh_gram + gh_reduce, or the reduction alone when the previous leaf's leaf_b has already left
 // the partials (fused leaf)
@@ -711,7 +726,7 @@ int factor_rec(mpqr_handle_t h, int id, bool do_panel) {
             Range rg("mpqr:panel");
             a.A = h->Aeff; a.lda = h->lda; a.mrows = h->m; a.cb = rdown(nd.c0, tall || tail ? 128 : 32); a.c0 = nd.c0; a.c1 = nd.c1;
             a.Vh = h->Vh; a.ldvh = h->ldvh; a.Vt = h->Vt; a.ldvt = h->ldvt; a.vdiag = h->vdiag;
-            a.P = h->P; a.maxwg = h->maxwg; a.hostflag = h->hflag_dev + h->cur_block;
+            a.P = h->P; a.maxwg = h->maxwg; a.hostflag = h->hflag_dev + h->cur_block; a.deflword = h->hflag_dev + h->flag_words - 2;
             const bool fused = tall && !h->Vf;    // fp16 mode: the Gram of the rounded reflectors comes out of gh_apply
             int* flag = h->dflag + (id < h->nflag ? id : 0);
             if (tall) {
@@ -893,7 +908,7 @@ int factor_block_flat(mpqr_handle_t h, int top, const std::vector<int>& leaves) 
             LeafArgs a{};
             a.A = h->Aeff; a.lda = h->lda; a.mrows = h->m; a.cb = rdown(lf.c0, 128); a.c0 = lf.c0; a.c1 = lf.c1;
             a.Vh = h->Vh; a.ldvh = h->ldvh; a.Vt = h->Vt; a.ldvt = h->ldvt; a.vdiag = h->vdiag;
-            a.P = h->P; a.maxwg = h->maxwg; a.hostflag = h->hflag_dev + h->cur_block;
+            a.P = h->P; a.maxwg = h->maxwg; a.hostflag = h->hflag_dev + h->cur_block; a.deflword = h->hflag_dev + h->flag_words - 2;
             leaf_gram(h, a);
             // the previous block's far update is enqueued HERE (run_block_loop): its stream starts when this leaf's gh_solve does,
             // so its first GEMMs fill the other 255 CUs during the solve instead of holding them while gh_gram wants them
@@ -990,7 +1005,7 @@ int factor_block_flat(mpqr_handle_t h, int top, const std::vector<int>& leaves) 
         if (have_rest && la_split && !la_mid) HIPQ(h, hipEventRecord(h->ev_def, h->s0));   // T_j and V_j are complete here: the rest may start beside the urgent part
         // the previous leaf's deferred update (T stream) wrote columns this leaf's X reads and the next gh_gram needs: it ran beside this
         // leaf's gh_solve, which polled its progress word at its end (or: an event wait / a one-wave polling kernel here)
-        rest_wait(h);
+        rest_wait(h, !fl);
         if (fl) {
             Range rg("mpqr:fused_leaf");
             // next leaf: does it take the partial Gram matrices leaf_b can leave?  (a Gram-Householder leaf: not the tail, not on the robust path)
@@ -1050,13 +1065,14 @@ int factor_block_flat(mpqr_handle_t h, int top, const std::vector<int>& leaves) 
             // with the second leaf's rest: R differed from run to run from that leaf's successor on (tools/determinism_check.py).
             if (!h->rest_recorded) rest_done(h, h->sT);
             h->rest_pending = true; h->rest_in_solve = false; h->rest_first_cols = 0;
+            h->rest_split = h->rest_recorded;               // announced behind its first columns only
         }
         // background, behind this leaf's X GEMM in the side stream's queue: the PREVIOUS leaf's column block of T
         if (prev_o >= 0) t_column_block(prev, prev_o);
         prev = lf; prev_o = o;
         if (!tq) { t_column_block(prev, prev_o); prev_o = -1; }          // single stream: nothing to defer
     }
-    rest_wait(h);
+    if (!h->next_block_flat) rest_wait(h, true);           // (a flat successor's first leaf takes the wait over: its gh_solve polls at its end, or the leaf waits as a non-fused one)
     if (prev_o >= 0) {                                     // the last leaf's column block needs its T (chain stream)
         if (tq) t_stream_follows_chain(h);
         t_column_block(prev, prev_o);
@@ -1205,6 +1221,7 @@ static int form_q_one_shot(mpqr_handle_t h) {
         h->far_flops.push_back(2.0 * (double)h->m * (double)h->m * Kr);
         h->far_bytes.push_back(4.0 * (double)h->m * h->m + 2.0 * Kr * (2.0 * h->m));
         h->far_dims.push_back(h->m); h->far_dims.push_back(h->m); h->far_dims.push_back(Kr);
+        h->far_flops_tn.push_back(0.0);
     }
     GemmArgs w{};                                         // W[m x Kr] = V T   (T upper triangular: k <= n)
     w.A = h->Vh + (long)rlo * h->ldvh + rt.a0; w.lda = h->ldvh;
@@ -1706,7 +1723,7 @@ int mpqr_generate_matrix(mpqr_handle_t h, uint64_t seed) {
 static int run_block_loop(mpqr_handle_t h, int start = 0) {
     int rc;
     h->v8_node = -1;
-    h->gram_ready_c0 = -1; h->lane2_twait = 0; h->rest_pending = false; h->rest_in_solve = false;
+    h->gram_ready_c0 = -1; h->lane2_twait = 0; h->rest_pending = false; h->rest_in_solve = false; h->rest_split = false; h->next_block_flat = false;
     if (start <= 0) h->n_fused_leaves = 0;
     h->pairs_ready = false; h->q_first = (size_t)-1;
     const auto host_t0 = std::chrono::steady_clock::now();  // host time to enqueue the block loop (ms_host_enqueue)
@@ -1714,11 +1731,11 @@ static int run_block_loop(mpqr_handle_t h, int start = 0) {
         // restart: the aborted pass's recordings for blocks >= start describe work that is thrown away -- rewind the event pools to
         // where block `start` began, so that ms_panel / ms_far_* / the roofline figures cover only work that is kept
         h->far_used = h->far_mark[start]; h->chain_used = h->chain_mark[start];
-        h->far_flops.resize(h->far_used / 4); h->far_bytes.resize(h->far_used / 4); h->far_dims.resize(3 * (h->far_used / 4));
+        h->far_flops.resize(h->far_used / 4); h->far_bytes.resize(h->far_used / 4); h->far_dims.resize(3 * (h->far_used / 4)); h->far_flops_tn.resize(h->far_used / 4);
     }
     if (start <= 0) {
         start = 0;
-        h->far_used = 0; h->far_flops.clear(); h->far_bytes.clear(); h->far_dims.clear(); h->chain_used = 0;
+        h->far_used = 0; h->far_flops.clear(); h->far_bytes.clear(); h->far_dims.clear(); h->far_flops_tn.clear(); h->chain_used = 0;
         if (!h->copied_in)                                  // (a later pass from block 0; the first one found the copy made by mpqr_factor)
             HIPCHK(h, hipMemcpyAsync(h->dA, h->dA0, (size_t)h->m_pad * h->lda * sizeof(float), hipMemcpyDeviceToDevice, h->s0));
         h->copied_in = false;
@@ -1841,7 +1858,9 @@ static int run_block_loop(mpqr_handle_t h, int start = 0) {
         const bool timed = h->chain_used + 2 <= h->chain_ev.size();
         if (timed) HIPCHK(h, hipEventRecord(h->chain_ev[h->chain_used], h->s0));
         if (pending_far >= 0) { const size_t tp = (size_t)pending_far; pending_far = -1; h->far_hook = [&far_update, tp]() { return far_update(tp); }; }
+        h->next_block_flat = t + 1 < nt && flat[t + 1] && flat[t];
         rc = factor_node(h, h->tops[t], true);
+        h->next_block_flat = false;
         h->ext_c1 = 0;
         if (rc == MPQR_ABORT_PASS) {          // a leaf of this pass is flagged: nothing enqueued from here on would be kept
             aborted = true;
@@ -1936,7 +1955,7 @@ int mpqr_factor(mpqr_handle_t h) {
             start = 0;
             continue;
         }
-        if (!flag_words_set(h, h->flag_words - 1) && !h->pass_aborted) break;
+        if (!flag_words_set(h, h->flag_words - 2) && !h->pass_aborted) break;
         h->factored = false; h->q_formed = false;
         flags.assign(h->nodes.size(), 0);
         HIPCHK(h, hipMemcpyAsync(flags.data(), h->dflag, flags.size() * sizeof(int), hipMemcpyDeviceToHost, h->s0));
@@ -1994,7 +2013,7 @@ int mpqr_get_timings(mpqr_handle_t h, mpqr_timings* t) {
     t->ms_total = t->ms_factor + t->ms_form_q;
     double f = 0;
     float tr = 0;
-    double fq = 0;
+    double fq = 0, fq_tn = 0;
     for (size_t i = 0; i + 3 < h->far_used; i += 4) {
         float a = 0, b = 0, x = 0;
         HIPCHK(h, hipEventElapsedTime(&a, h->far_ev[i], h->far_ev[i + 1]));
@@ -2003,6 +2022,7 @@ int mpqr_get_timings(mpqr_handle_t h, mpqr_timings* t) {
         if (i >= h->q_first) {                                                    // Q formation's applies
             t->ms_q_tn += a; t->ms_q_nn += b; t->n_q_launches++;
             fq += h->far_flops[i / 4];
+            if (i / 4 < h->far_flops_tn.size()) fq_tn += h->far_flops_tn[i / 4];
             if (i / 4 < h->far_bytes.size()) t->gbytes_q_nn += h->far_bytes[i / 4] * 1e-9;
             continue;
         }
@@ -2015,6 +2035,7 @@ int mpqr_get_timings(mpqr_handle_t h, mpqr_timings* t) {
         t->n_far_launches++;
     }
     t->tflop_q = (float)(fq * 1e-12);
+    t->tflop_q_tn = (float)(fq_tn * 1e-12);
     t->ms_host_enqueue = h->host_enqueue_ms;
     t->flops_far_tn = f; t->flops_far_nn = f;
     t->ms_trailing = tr;
@@ -2052,6 +2073,7 @@ int mpqr_get_timings(mpqr_handle_t h, mpqr_timings* t) {
     t->n_q_ident_rows = h->n_q_ident_rows;
     t->restart_block = h->restart_block;
     t->n_fused_leaves = h->n_fused_leaves; t->n_tpoll_retries = h->n_tpoll_retries;
+    t->n_deflated_columns = (h->hflag_host && h->flag_words >= 2) ? __atomic_load_n(h->hflag_host + h->flag_words - 2, __ATOMIC_RELAXED) : 0;
     h->last_t = *t;
     return MPQR_OK;
 }
@@ -2762,7 +2784,7 @@ int mpqr_dist_begin(mpqr_handle_t h, float absmax) {
     float sc = 1.f;
     if (absmax > 0.f && std::isfinite(absmax)) { int e; frexpf(absmax * sqrtf((float)h->m), &e); sc = ldexpf(1.f, 8 - e); }
     h->a_scale = sc;
-    h->far_used = 0; h->far_flops.clear(); h->far_bytes.clear(); h->far_dims.clear(); h->chain_used = 0; h->v8_node = -1;
+    h->far_used = 0; h->far_flops.clear(); h->far_bytes.clear(); h->far_dims.clear(); h->far_flops_tn.clear(); h->chain_used = 0; h->v8_node = -1;
     h->pairs_ready = false; h->n_passes = 1; h->n_robust_leaves = 0; h->n_gh_leaves = 0;
     HIPCHK(h, hipEventRecord(h->ev[0], h->s0));
     HIPCHK(h, hipMemcpyAsync(h->dA, h->dA0, (size_t)h->m_pad * h->lda * sizeof(float), hipMemcpyDeviceToDevice, h->s0));
@@ -2809,7 +2831,7 @@ int mpqr_dist_flags(mpqr_handle_t h, int* any) {
     HIPCHK(h, hipStreamSynchronize(h->s0));
     if (h->hflag_host && h->flag_words > 0 && __atomic_load_n(h->hflag_host + h->flag_words - 1, __ATOMIC_RELAXED) != 0)
         return fail(h, MPQR_ERR_HIP, "the T stream's wait for the chain stream timed out (wait_flag_kernel): this pass's results are invalid");
-    *any = flag_words_set(h, h->flag_words - 1) ? 1 : 0;
+    *any = flag_words_set(h, h->flag_words - 2) ? 1 : 0;
     return MPQR_OK;
 }
 // on != 0: every tall leaf of the following factorisations takes the column-by-column kernels (all ranks must agree)

@@ -84,10 +84,19 @@ __device__ __forceinline__ void s3_chol_row(double& dgi, double& n0, double& n1,
                      : "=&v"(t), "+v"(dgi) : "v"(src), "v"(mdg), "n"(I));
 }
 // the scalar chain of one pivot, in links: y = ok ? 1 / sqrt(p) : 0 (fp32 seed, two Newton steps: refine_rsqrt), y2 = y^2
-struct S3Piv { double p, hp, y0, t, y, y2; float c1; };
+struct S3Piv { double p, hp, y0, t, y, y2, th; float c1; };
 constexpr int S3_PIV_LINKS = 10;
 template <int J>
 __device__ __forceinline__ void s3_piv_link(S3Piv& q) {
+    // Round 5, in-line deflation.  A column whose remaining norm ||u_k||^2 is below its threshold th = GH_RHO_MIN max(||a_k||^2, 1e-6 max_j
+    // ||a_j||^2) -- numerically dependent on its predecessors; the reference's exactly-zero column (qr.cu:242-244, th = 0) is the extreme
+    // case -- is SKIPPED in line, exactly as a zero column is: y = 0 (no Cholesky row, no downdate), the Householder chain sees ok = 0 and
+    // leaves v_k = 0, w = 0, R_kk = B[k][k].  What is dropped is the column's remainder below the diagonal, <= sqrt(th) = 1e-4 ||a_k||; what
+    // the later columns of the leaf keep too much of is row k's contribution B[k][j]^2 to their norms (the skipped downdate), a relative
+    // 1 / (2 rows) on their reflectors' scale -- both inside the 1e-3 tolerance.  Before: flag the leaf, stop the pass, redo the leaf on the
+    // column-by-column kernels, restart its block (1.4 - 1.7 x per ill-conditioned leaf, one restart per leaf).  (Clamping the pivot at
+    // th instead and carrying on was tried first: the in-kernel updates of the top block then assume a unit reflector that the actual V is
+    // not, row k of R comes out wrong by O(1): backward error 2e-3 ... 2e-2.)
     if constexpr (J == 0) { q.hp = -0.5 * q.p; q.c1 = (float)q.p; s3_pin(q.hp); s3_pin(q.c1); }
     else if constexpr (J == 1) { q.c1 = __builtin_amdgcn_rsqf(q.c1); s3_pin(q.c1); }
     else if constexpr (J == 2) { q.y0 = (double)q.c1; s3_pin(q.y0); }
@@ -97,14 +106,14 @@ __device__ __forceinline__ void s3_piv_link(S3Piv& q) {
     else if constexpr (J == 6) { q.t = q.y0 * q.y0; s3_pin(q.t); }
     else if constexpr (J == 7) { q.t = fma(q.hp, q.t, 1.5); s3_pin(q.t); }
     else if constexpr (J == 8) {
-        const bool ok = q.p > 1e-30 && q.p < 1e30;           // false: zero / cancelled column or out of range -> flagged
+        const bool ok = q.p > q.th && q.p < 1e30;            // false: zero / dependent / cancelled column (skipped in line), or out of range (flagged)
         q.y = ok ? q.y0 * q.t : 0.0; s3_pin(q.y);
     } else if constexpr (J == 9) { q.y2 = q.y * q.y; s3_pin(q.y2); }
 }
 template <int NS>
-__device__ __forceinline__ void s3_chol_block(double (&dg)[16], double (&n)[16][2], int li, double& piv) {
+__device__ __forceinline__ void s3_chol_block(double (&dg)[16], double (&n)[16][2], int li, double& piv, double thv) {
     S3Piv cur;
-    cur.p = dpp_bcast64<0, 0>(dg[0]);
+    cur.p = dpp_bcast64<0, 0>(dg[0]); cur.th = dpp_bcast64<0, 0>(thv);
     static_range<0, S3_PIV_LINKS>([&](auto J) { s3_piv_link<decltype(J)::value>(cur); });
     static_for16<0>([&](auto KK) {
         constexpr int kk = decltype(KK)::value;
@@ -116,7 +125,7 @@ __device__ __forceinline__ void s3_chol_block(double (&dg)[16], double (&n)[16][
         S3Piv nxt;
         if constexpr (kk < 15) {
             s3_chol_row<NS, kk + 1>(dg[kk + 1], n[kk + 1][0], n[kk + 1][1], dg[kk], mdg, m[0], m[1]);
-            nxt.p = dpp_bcast64<kk + 1, 1>(dg[kk + 1]);
+            nxt.p = dpp_bcast64<kk + 1, 1>(dg[kk + 1]); nxt.th = dpp_bcast64<kk + 1, 0>(thv);
             static_for16<kk + 2>([&](auto II) {
                 constexpr int i = decltype(II)::value;
                 s3_chol_row<NS, i>(dg[i], n[i][0], n[i][1], dg[kk], mdg, m[0], m[1]);
@@ -234,7 +243,7 @@ __device__ __forceinline__ void s3_hh_block(float (&dgR)[16], float (&dgC)[16], 
 // ---- one block of a chain wave: panels in from LDS, the 16 steps, results out.  NS = slots of 64 columns / rows beyond the
 // diagonal block (a template parameter, so that each case allocates only the registers it needs)
 template <int NS>
-__device__ __forceinline__ void s3_ch_round(unsigned pb, int k0, int nrest, int lane, const double* thr, int* cmask, int& bad) {
+__device__ __forceinline__ void s3_ch_round(unsigned pb, int k0, int nrest, int lane, const double* thr, int* cmask, int& bad, int& ndefl) {
     asm volatile("" : "+v"(lane));                           // per-lane masks are recomputed per round, not hoisted out of the loop and spilled
     const int li = lane & 15;
     const unsigned o_dg = s3_opaque(pb + (k0 + li) * 8);
@@ -249,12 +258,13 @@ __device__ __forceinline__ void s3_ch_round(unsigned pb, int k0, int nrest, int 
         for (int rr = 0; rr < 16; rr++) { const double x = S3D(o_n + (rr * S3_BS + 64 * s) * 8); n[rr][s] = live ? x : 0.0; }
     }
     double piv = 1.0;
-    S3T(4, 20 + 2 * (k0 >> 4));
-    s3_chol_block<NS>(dg, n, li, piv);
-    S3T(4, 21 + 2 * (k0 >> 4));
     const double th = thr[k0 + li];
-    const int okl = (piv > 1e-30 && piv < 1e30) ? 1 : 0;     // lane li: the pivot of step li
-    bad |= (!okl || piv < th) ? 1 : 0;
+    S3T(4, 20 + 2 * (k0 >> 4));
+    s3_chol_block<NS>(dg, n, li, piv, th);
+    S3T(4, 21 + 2 * (k0 >> 4));
+    const int okl = (piv > th && piv < 1e30) ? 1 : 0;        // lane li: the pivot of step li (the same test as inside the chain)
+    bad |= (piv != piv || piv >= 1e30 || piv < -th - 1e-30) ? 1 : 0;   // flagged: NaN / Inf / out-of-range or a pivot that cancelled far below zero -- not a zero or dependent column
+    ndefl += (lane < 16 && !okl && th > 1e-30) ? 1 : 0;      // deflated columns (reported: mpqr_timings.n_deflated_columns; exactly-zero columns, th = 0, are not counted)
     const unsigned q_dg = s3_opaque(pb + (k0 + li) * 8), q_n = s3_opaque(pb + (k0 + 16 + (lane < nrest ? lane : 0)) * 8);
     if (lane < 16) {
         cmask[k0 + li] = okl;                               // lane kk holds step kk's flag
@@ -271,7 +281,7 @@ __device__ __forceinline__ void s3_ch_round(unsigned pb, int k0, int nrest, int 
 }
 template <int NS>
 __device__ __forceinline__ void s3_hhr_round(int b, int k0, int nrest, int lane, int w, const LeafArgs& a, const int* cmask,
-                                             float* sgn, float* vdl, float* tdiag) {
+                                             float* sgn, float* vdl, float* tdiag, float skip_row_max2, int* lflag) {
     asm volatile("" : "+v"(lane));
     const int li = lane & 15;
     const int lz = lane < nrest ? lane : 0;                  // lanes beyond the leaf read their slot's first column and are zeroed
@@ -310,6 +320,30 @@ __device__ __forceinline__ void s3_hhr_round(int b, int k0, int nrest, int lane,
     s3_hh_block<NS, 1>(dgR, dgC, br, cdg, cfo, okv, lane, w_dg, w_o, w_o, dmy, sg, vd, td);
     S3T(5, 21 + 2 * (k0 >> 4));
     if (lane < 16) { sgn[k0 + lane] = sg; vdl[k0 + lane] = vd; tdiag[k0 + lane] = td; }
+    // Skipped steps (ok = 0: a zero or dependent column, H_k = I): row k of R is row k of B AS IT STANDS -- the later steps of the block never
+    // touch it -- not -sgn(u0) c_k (store_r, which leaves such rows alone).  It lives in this wave's registers; rare, so the stores sit here.
+    const unsigned skipped = (unsigned)(__ballot(okv == 0 && lane < 16 && k0 + li < w) & 0xffffu);
+    if (skipped) {
+        static_for16<0>([&](auto KK) {
+            constexpr int kk = decltype(KK)::value;
+            if ((skipped >> kk) & 1u) {
+                float* rowp = a.A + (long)(a.c0 + k0 + kk) * a.lda + a.c0;
+                float r2 = 0.f;                              // largest squared entry of the dead row right of the diagonal
+                if (lane < 16 && li >= kk && k0 + li < w) { rowp[k0 + li] = dgR[kk]; if (li > kk) r2 = dgR[kk] * dgR[kk]; }
+#pragma unroll
+                for (int s = 0; s < NS; s++) { const int col = k0 + 16 + lane + 64 * s; if (lane + 64 * s < nrest && col < w) { rowp[col] = br[kk][s]; r2 = fmaxf(r2, br[kk][s] * br[kk][s]); } }
+                // The skipped step does not take its dead row out of the Gram matrix N (the Cholesky chain ran ahead and never sees B's rows):
+                // the later columns of the leaf keep B[k][j]^2 too much norm, a relative B[k][j]^2 / ||u_j||^2 on their reflectors.  Measured
+                // (tools/defl_rows.py): backward-error excess ~ 2.7 x that ratio per skipped column -- fine for sparse Jacobians and for leaves of
+                // >= ~6000 rows, 1.3e-3 ... 4.6e-3 in all for dense leaves of 1500 - 4000 rows.  So the skip is kept only while the row is small
+                // against the leaf (GH_SKIP_ROW_MAX x max_j ||a_j||^2); otherwise the leaf is flagged and redone on the column-by-column kernels
+                // as before round 5.  (r2 is the row's LARGEST squared entry, ~6 x a typical one over 120 columns: excess ~ 0.4 r2 / max ||a_j||^2.)
+#pragma unroll
+                for (int o = 32; o >= 1; o >>= 1) r2 = fmaxf(r2, __shfl_xor(r2, o));
+                if (lane == 0 && r2 > skip_row_max2) *lflag = 1;
+            }
+        });
+    }
 }
 template <int NS>
 __device__ __forceinline__ void s3_hhc_round(int b, int k0, int nrest, int lane, const int* cmask) {
@@ -378,6 +412,7 @@ __global__ __launch_bounds__(S3_THREADS) void gh_solve3_kernel(LeafArgs a, const
     float* Ts = (float*)(gh_smem + S3_OFF_BUF);           // [TP][TPS] after the loop: the inverse
     __shared__ float vdl[GW], tdiag[GW], sgn[GW];
     __shared__ int cmask[GW], lflag;
+    __shared__ float skip_row_max2;                        // a skipped step's dead row may hold entries up to sqrt of this (GH_SKIP_ROW_MAX x the leaf's largest ||a_j||^2)
     __shared__ double thr[GW];                            // rho thresholds GH_RHO_MIN ||a_j||^2
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -409,7 +444,7 @@ __global__ __launch_bounds__(S3_THREADS) void gh_solve3_kernel(LeafArgs a, const
 #pragma unroll
         for (int j = 0; j < 2; j++) {
             const int k = kb + j;
-            if (k < w) {
+            if (k < w && cmask[k]) {                         // (a skipped step's row was stored by the Householder wave: s3_hhr_round)
                 const float ns = -sgn[k];
                 float* rowp = a.A + (long)(a.c0 + k) * a.lda + a.c0;
 #pragma unroll
@@ -461,7 +496,7 @@ __global__ __launch_bounds__(S3_THREADS) void gh_solve3_kernel(LeafArgs a, const
     if (wave < 3) __builtin_amdgcn_s_setprio(3);           // the chains first: their panel loads compete with the update waves' operand reads
     if (wave == 0) {
         // ================================================= Cholesky chain
-        int bad = 0;
+        int bad = 0, ndefl = 0;
         {   // all 34 loads of a lane first, then the LDS stores: written as load -> store pairs the compiler kept them in program order and
             // the wave paid one memory latency per load (G was just written by gh_reduce on other CUs: misses) -- 21 k of the kernel's
             // ~155 k cycles before the first round could start (in-kernel stamps, tools/ktrace_solve.sh)
@@ -474,10 +509,16 @@ __global__ __launch_bounds__(S3_THREADS) void gh_solve3_kernel(LeafArgs a, const
                 for (int rr = 0; rr < 16; rr++) gv[s][rr] = Gw(rr, col);
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            double gmax = fmax(lane < ncol ? gv[0][16] : 0.0, lane + 64 < ncol ? gv[1][16] : 0.0);      // max_j ||a_j||^2 over the leaf's columns
+#pragma unroll
+            for (int o = 32; o >= 1; o >>= 1) gmax = fmax(gmax, __shfl_xor(gmax, o));
+            if (lane == 0) skip_row_max2 = (float)(GH_SKIP_ROW_MAX * gmax);
 #pragma unroll
             for (int s = 0; s < 2; s++) {
                 const int col = lane + 64 * s;
-                thr[col] = GH_RHO_MIN * gv[s][16];            // rho threshold: ||a_j||^2 over all leaf rows
+                // pivot floor of column j: rho threshold x ||a_j||^2 (all leaf rows), never below 1e-6 of the leaf's largest column; an
+                // EXACTLY zero column keeps floor 0: its pivot is 0, the step is skipped in line (v = 0, R_kk = 0) as the reference does (qr.cu:242-244)
+                thr[col] = gv[s][16] == 0.0 ? 1e-30 : fmax(GH_RHO_MIN * fmax(gv[s][16], 1e-6 * gmax), 1e-30);
 #pragma unroll
                 for (int rr = 0; rr < 16; rr++) buf[rr * S3_BS + col] = gv[s][rr];   // row panel 0
             }
@@ -491,15 +532,20 @@ __global__ __launch_bounds__(S3_THREADS) void gh_solve3_kernel(LeafArgs a, const
                 const int k0 = 16 * r;
                 const int nrest = ncol - (k0 + 16);           // columns right of the block: 0, 1 or 2 slots of 64
                 const unsigned pb = S3_OFF_BUF + (r & 1) * (16 * S3_BS * 8);
-                if (nrest > 64) s3_ch_round<2>(pb, k0, nrest, lane, thr, cmask, bad);
-                else if (nrest > 0) s3_ch_round<1>(pb, k0, nrest, lane, thr, cmask, bad);
-                else s3_ch_round<0>(pb, k0, nrest, lane, thr, cmask, bad);
+                if (nrest > 64) s3_ch_round<2>(pb, k0, nrest, lane, thr, cmask, bad, ndefl);
+                else if (nrest > 0) s3_ch_round<1>(pb, k0, nrest, lane, thr, cmask, bad, ndefl);
+                else s3_ch_round<0>(pb, k0, nrest, lane, thr, cmask, bad, ndefl);
                 if (bad) lflag = 1;
             }
             S3T(0, 2 * r + 1);
             s3_barrier();
             s3_barrier();
         }
+        // columns deflated by the pivot clamp (s3_piv_link): counted in mapped host memory -- nothing is written on the normal path
+        int tot = (lane < 16 && w > 0) ? ndefl : 0;
+#pragma unroll
+        for (int o = 8; o >= 1; o >>= 1) tot += __shfl_xor(tot, o);
+        if (lane == 0 && tot > 0 && a.deflword) __hip_atomic_fetch_add(a.deflword, tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     } else if (wave == 1) {
         // ================================================= Householder chain, one block behind: wave 1 the row panel (w), wave 2
         // the column panel (v); both carry the diagonal block
@@ -509,9 +555,9 @@ __global__ __launch_bounds__(S3_THREADS) void gh_solve3_kernel(LeafArgs a, const
             if (r >= 1) {
                 const int b = r - 1, k0 = 16 * b;
                 const int nrest = ncol - (k0 + 16);
-                if (nrest > 64) s3_hhr_round<2>(b, k0, nrest, lane, w, a, cmask, sgn, vdl, tdiag);
-                else if (nrest > 0) s3_hhr_round<1>(b, k0, nrest, lane, w, a, cmask, sgn, vdl, tdiag);
-                else s3_hhr_round<0>(b, k0, nrest, lane, w, a, cmask, sgn, vdl, tdiag);
+                if (nrest > 64) s3_hhr_round<2>(b, k0, nrest, lane, w, a, cmask, sgn, vdl, tdiag, skip_row_max2, &lflag);
+                else if (nrest > 0) s3_hhr_round<1>(b, k0, nrest, lane, w, a, cmask, sgn, vdl, tdiag, skip_row_max2, &lflag);
+                else s3_hhr_round<0>(b, k0, nrest, lane, w, a, cmask, sgn, vdl, tdiag, skip_row_max2, &lflag);
             }
             S3T(1, 2 * r + 1);
             s3_barrier();

@@ -119,6 +119,7 @@ struct LeafArgs {
     float* P;                   // partial dot products, 2 x maxwg x 32
     int maxwg;
     int* hostflag;              // Gram-Householder leaves: word in mapped host memory that a flagged leaf also raises (or nullptr)
+    int* deflword;              // ... and the word that counts the columns gh_solve deflated (pivot clamp; or nullptr)
 };
 void launch_leaf_factor(const LeafArgs& a, hipStream_t s);   // robust path: one workgroup (<=2048 rows) or one launch per column
 // the last leaf of a (nearly) square matrix: at most 128 rows from row c0 down, up to 128 columns inside the 128-aligned window a.cb; one

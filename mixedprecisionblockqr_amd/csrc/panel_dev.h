@@ -21,6 +21,7 @@ static __device__ int g_ktrace_left[8] = {3, 3, 3, 3, 3, 3, 3, 3};
 #define KT_DUMP(id, name) do {} while (0)
 #endif
 constexpr double GH_RHO_MIN = 1e-8;
+constexpr double GH_SKIP_ROW_MAX = 6e-4;   // in-line deflation (kernels_solve.hip): largest B[k][j]^2 of a skipped step's dead row, relative to max_j ||a_j||^2 of the leaf
 constexpr int GW = 128;          // window width
 
 __device__ __forceinline__ double bcast_lane_d(double v, int srclane) {
