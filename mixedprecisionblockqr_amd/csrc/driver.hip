@@ -1796,7 +1796,8 @@ static int run_block_loop(mpqr_handle_t h, int start = 0) {
         for (size_t t = 0; t < nt; t++) {
             std::vector<int> leaves_t;
             collect_leaves(h, h->tops[t], leaves_t);
-            npre[t] = (t > 0 && ext[t - 1] && flat[t]) ? std::min<int>(ext_leaves, (int)leaves_t.size()) : 1;
+            // (at most half of the block's leaves: a 512-column block keeps the two leaves of rounds 3 - 4)
+            npre[t] = (t > 0 && ext[t - 1] && flat[t]) ? std::min<int>(ext_leaves, std::max<int>(ext_env ? (int)leaves_t.size() : (int)leaves_t.size() / 2, 1)) : 1;
             cfirst[t] = h->nodes[leaves_t[npre[t] - 1]].c1;
         }
     }
