@@ -959,7 +959,9 @@ int factor_block_flat(mpqr_handle_t h, int top, const std::vector<int>& leaves) 
         // Fused leaf (round 5): the chain works on the NEXT 128 columns only, in three launches (leaf_a: gh_apply + partial X; leaf_m: T and Y;
         // leaf_b: the update + the next leaf's partial Gram matrices), the rest of the block follows on the T stream as under leaf-level look-ahead.
         // Needs a full 128-column leaf, 128 further columns inside the update range, and the polling T stream (leaf_b publishes the word).
-        const bool fl = h->fused_leaf && gh_leaf && tq && lane2_ok && h->Xp && h->tpoll && h->tflag && h->hflag_dev && h->flag_words > 0 &&
+        // (not for leaves of >= 49152 rows, where a workgroup of leaf_a / leaf_b takes four row blocks: 65536 x 8192 factors in 38.8 ms on the
+        //  round-4 launches with leaf-level look-ahead, 39.3 fused)
+        const bool fl = h->fused_leaf && gh_leaf && tq && lane2_ok && h->Xp && h->tpoll && h->tflag && h->hflag_dev && h->flag_words > 0 && h->m - lf.c1 < 49152 &&
                         lf.ldt == 128 && lf.a0 == lf.c0 && lf.c1 - lf.c0 == 128 && (lf.c0 % 128) == 0 && lf.c1 + 128 <= upd_end && lf.c1 + 128 <= h->n &&
                         !h->shadow && !h->Vf && h->opts.precision != MPQR_PREC_FP32;
         const bool la_split = fl || (tq && lane2_ok && leaf_la && lf.c1 < upd_end && std::min(next_c1, upd_end) < upd_end);
@@ -1788,7 +1790,7 @@ static int run_block_loop(mpqr_handle_t h, int start = 0) {
         //  range only costs the T stream's deferred updates a few columns, and the wait for part (a) moves from the block's second leaf,
         //  where gh_solve's final poll sat 100 - 250 us in every block (MPQR_DBG_STAMPS), to its fourth: 33.45 -> 33.03 ms; 5 / 6 / 8: 33.4 / 34.0 / 35.2)
         static const int ext_env = []() { const char* e = getenv("MPQR_EXT_LEAVES"); return e ? std::max(1, atoi(e)) : 0; }();
-        const int ext_leaves = ext_env ? ext_env : ((h->fused_leaf && h->Xp) ? 4 : 2);
+        const int ext_short = ext_env ? ext_env : ((h->fused_leaf && h->Xp) ? 4 : 2);
         for (size_t t = 0; t < nt; t++) {
             flat[t] = flat_block_ok(h, h->tops[t], lv);
             ext[t] = la && ext_on && h->tq_on && t + 1 < nt && flat[t];
@@ -1797,6 +1799,8 @@ static int run_block_loop(mpqr_handle_t h, int start = 0) {
             std::vector<int> leaves_t;
             collect_leaves(h, h->tops[t], leaves_t);
             // (at most half of the block's leaves: a 512-column block keeps the two leaves of rounds 3 - 4)
+            // (tall leaves -- >= 20480 rows, where the deferred updates are large -- keep two: 65536 x 8192 factors in 39.3 ms with two, 41.5 with four)
+            const int ext_leaves = ext_env ? ext_env : (h->m - h->nodes[h->tops[t]].c0 >= 20480 ? 2 : ext_short);
             npre[t] = (t > 0 && ext[t - 1] && flat[t]) ? std::min<int>(ext_leaves, std::max<int>(ext_env ? (int)leaves_t.size() : (int)leaves_t.size() / 2, 1)) : 1;
             cfirst[t] = h->nodes[leaves_t[npre[t] - 1]].c1;
         }
