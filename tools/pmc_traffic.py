@@ -77,8 +77,8 @@ def match(fetch_rows, write_rows, recs, name):
 
     def grid_ok(row, rec):       # the launch's grid against the record's shape: 256 x 256 tiles of 512 threads, or 128 x 128 tiles of 256
         g, M, N = int(row["Grid_Size"]), rec["M"], rec["N"]
-        if "gemm6" in row["Kernel_Name"]:
-            return g == -(-M // 256) * -(-N // 256) * 512
+        if "gemm6" in row["Kernel_Name"]:                    # whole 4 x 8 groups of 256 x 256 tiles, 512 threads each
+            return g == -(-(-(-M // 256)) // 4) * -(-(-(-N // 256)) // 8) * 32 * 512
         return g == -(-M // 128) * -(-N // 128) * 256
     bad = [fetch_rows[i]["_id"] for i in range(n) if not grid_ok(fetch_rows[i], recs[i])]
     out = {"set": name, "launches": n, "records": len(recs), "pmc_rows_fetch": len(fetch_rows), "pmc_rows_write": len(write_rows),

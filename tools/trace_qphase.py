@@ -11,7 +11,7 @@ ab = [i for i, r in enumerate(rows) if 'absmax' in r['Kernel_Name']]          # 
 bounds = ab + [len(rows)]
 run = None
 for a, b in reversed(list(zip(bounds, bounds[1:]))):
-    if sum(1 for r in rows[a:b] if 'gh_apply' in r['Kernel_Name']) >= 8:
+    if sum(1 for r in rows[a:b] if 'gh_apply' in r['Kernel_Name'] or 'leaf_a_kernel' in r['Kernel_Name']) >= 8:
         hi = next((i for i in range(a, b) if 'lower_norm' in rows[i]['Kernel_Name'] or 'strip_r' in rows[i]['Kernel_Name']), b)
         run = rows[a:hi]
         break
@@ -19,7 +19,7 @@ if run is None:
     sys.exit("no factorisation found in the trace")
 # Q formation = everything behind the last gh_apply of the run (round 4: Q = I is set up at the START of the factorisation, the identity
 # kernels no longer mark the phase)
-last_apply = max(i for i, r in enumerate(run) if 'gh_apply' in r['Kernel_Name'])
+last_apply = max(i for i, r in enumerate(run) if 'gh_apply' in r['Kernel_Name'] or 'leaf_a_kernel' in r['Kernel_Name'] or 'leaf_tail' in r['Kernel_Name'])
 q = run[last_apply + 1:]
 first = next((i for i, r in enumerate(q) if 'gemm6_f16_kernel<1, 0' in r['Kernel_Name'] or 'gemm2_f16_kernel' in r['Kernel_Name']), 0)   # first X = Q2^T V
 q = q[max(first - 2, 0):]
