@@ -103,3 +103,20 @@ def test_rmw_epilogue_precondition_is_checked():
     A = np.ones((300, 64), np.float32); B = np.ones((64, 64), np.float32); C = np.zeros((300, 64), np.float32)
     with pytest.raises(mp.MpqrError):
         mp.gemm_test(A, B, C, 1, 2)
+
+
+@pytest.mark.parametrize("kernel", sorted(KERNELS))
+def test_device_cast_round_trip(kernel):
+    """The reference's cast check (Cuda/mmult.cuh:482-555 test_dev_cpy_and_cast_array: fp32 -> fp16 -> fp32 through its copy-and-cast
+    kernel, |x - roundtrip(x)| <= 4e-4 for U[0,1) data, mmult.cuh:541).  Here the casts are fused into the GEMM kernels' operand staging
+    (no cast kernel exists), so the DEVICE-side conversion is driven through each kernel's staging path with B = I: C = A I has exactly one
+    non-zero product per entry, i.e. C[i][j] = fp16(A[i][j]) as the staging rounded it -- bit for bit the host's round-to-nearest-even
+    conversion, and within the reference's 4e-4 of the fp32 input.  Odd shapes: masked rows / columns and a K that is padded to the k step."""
+    import mixedprecisionblockqr_amd as mp
+    rng = np.random.default_rng(7)
+    for (m, k) in ((97, 90), (256, 256), (129, 80), (600, 400)):
+        A = rng.random((m, k), dtype=np.float32)
+        C = np.zeros((m, k), np.float32)
+        mp.gemm_test(A, np.eye(k, dtype=np.float32), C, kernel, 0)
+        assert np.array_equal(C, _h16(A)), (KERNELS[kernel], m, k, float(np.abs(C - _h16(A)).max()))
+        assert float(np.abs(C - A).max()) <= 4e-4, (KERNELS[kernel], m, k)
