@@ -261,9 +261,9 @@ void free_plan(mpqr_handle_t h) {
                     h->Tf, h->Th, h->Tth, h->dstage, h->Gp, h->Gs, h->Cv, h->dflag, h->Vf, h->Yf, h->Xt1, h->Yt1, h->Sp,
                     h->rbTf, h->rbTh, h->rbTth, h->Sleaf, h->mid_counter, h->tflag, h->V8n, h->V8t, h->A8t, h->Y8, h->Xt2, h->Yt2, h->Xp, h->Xs, h->Yfl,
                     h->S2, h->tmp1b, h->tmp2b, h->Qt, h->At, h->Xh, h->Wh, h->Xl, h->Xh1, h->Xl1};
-    for (void* p : ptrs) if (p) (void)hipFree(p);
-    if (h->hflag_host) (void)hipHostFree(h->hflag_host);
-    if (h->dbg_stamps) { (void)hipHostFree(h->dbg_stamps); h->dbg_stamps = nullptr; h->dbg_stamps_n = 0; }
+    for (void* p : ptrs) if (p) MPQR_IGNORE(hipFree(p));
+    if (h->hflag_host) MPQR_IGNORE(hipHostFree(h->hflag_host));
+    if (h->dbg_stamps) { MPQR_IGNORE(hipHostFree(h->dbg_stamps)); h->dbg_stamps = nullptr; h->dbg_stamps_n = 0; }
     h->hflag_host = h->hflag_dev = nullptr; h->flag_words = 0; h->cur_block = 0;
     h->S2 = h->tmp1b = h->tmp2b = nullptr; h->s2_elems = 0; h->Qt = nullptr; h->shadow = nullptr; h->At = nullptr; h->at_read = false; h->Xh = nullptr; h->Xl = h->Xh1 = h->Xl1 = nullptr; h->Wh = nullptr; h->qroot = -1; h->qmerge_after.clear(); h->qpair.clear(); h->pairs_ready = false;
     h->dA = h->dA0 = h->dQ = nullptr; h->Vh = h->Vt = nullptr; h->vdiag = nullptr; h->Xt = nullptr; h->Yt = nullptr;
@@ -273,13 +273,13 @@ void free_plan(mpqr_handle_t h) {
     h->Xt1 = nullptr; h->Yt1 = nullptr; h->Sp = nullptr; h->Xt2 = nullptr; h->Yt2 = nullptr; h->xt2_elems = 0;
     h->rbTf = nullptr; h->rbTh = h->rbTth = nullptr; h->rb_elems = 0; h->nflag = 0; h->leaf_robust.clear(); h->Sleaf = nullptr; h->mid_counter = nullptr; h->tflag = nullptr; h->Xp = nullptr; h->Xs = nullptr; h->Yfl = nullptr; h->gram_ready_c0 = -1;
     h->V8n = h->V8t = h->A8t = h->Y8 = nullptr; h->v8_node = -1;
-    for (hipEvent_t e : h->chain_ev) (void)hipEventDestroy(e);
+    for (hipEvent_t e : h->chain_ev) MPQR_IGNORE(hipEventDestroy(e));
     h->chain_ev.clear(); h->chain_used = 0; h->far_used = 0;
-    for (hipEvent_t e : h->ev_node) (void)hipEventDestroy(e);
-    for (hipEvent_t e : h->ev_cols) (void)hipEventDestroy(e);
-    for (hipEvent_t e : h->ev_cols2) (void)hipEventDestroy(e);
+    for (hipEvent_t e : h->ev_node) MPQR_IGNORE(hipEventDestroy(e));
+    for (hipEvent_t e : h->ev_cols) MPQR_IGNORE(hipEventDestroy(e));
+    for (hipEvent_t e : h->ev_cols2) MPQR_IGNORE(hipEventDestroy(e));
     h->ev_node.clear(); h->ev_cols.clear(); h->ev_cols2.clear();
-    for (hipEvent_t e : h->far_ev) (void)hipEventDestroy(e);
+    for (hipEvent_t e : h->far_ev) MPQR_IGNORE(hipEventDestroy(e));
     h->far_ev.clear();
     h->nodes.clear(); h->tops.clear();
     h->planned = false; h->have_input = false; h->factored = false; h->q_formed = false; h->q_inited = false;
@@ -1353,7 +1353,7 @@ int mpqr_create(mpqr_handle_t* out, int device) {
     mpqr_default_opts(&h->opts);
     memset(&h->last_t, 0, sizeof h->last_t);
     int prio_lo = 0, prio_hi = 0;
-    (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
+    MPQR_IGNORE(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
     if (hipSetDevice(device) != hipSuccess ||
         hipStreamCreateWithPriority(&h->s0, hipStreamNonBlocking, prio_hi) != hipSuccess ||
         create_update_stream(&h->s1, prio_lo) != hipSuccess ||
@@ -1369,7 +1369,7 @@ int mpqr_create(mpqr_handle_t* out, int device) {
         delete h;
         return MPQR_ERR_HIP;
     }
-    for (int i = 0; i < 4; i++) (void)hipEventCreate(&h->ev[i]);
+    for (int i = 0; i < 4; i++) MPQR_IGNORE(hipEventCreate(&h->ev[i]));
     if (hipMalloc((void**)&h->dmetric, 8 * sizeof(double)) != hipSuccess ||
         hipMalloc((void**)&h->dscalar, 4 * sizeof(float)) != hipSuccess) {
         g_create_err = "hipMalloc failed";
@@ -1382,26 +1382,26 @@ int mpqr_create(mpqr_handle_t* out, int device) {
 
 int mpqr_destroy(mpqr_handle_t h) {
     if (!h) return MPQR_ERR_INVALID;
-    (void)hipSetDevice(h->device);
-    (void)hipStreamSynchronize(h->s0);
-    if (h->s1) (void)hipStreamSynchronize(h->s1);
-    if (h->sT) (void)hipStreamSynchronize(h->sT);
+    MPQR_IGNORE(hipSetDevice(h->device));
+    MPQR_IGNORE(hipStreamSynchronize(h->s0));
+    if (h->s1) MPQR_IGNORE(hipStreamSynchronize(h->s1));
+    if (h->sT) MPQR_IGNORE(hipStreamSynchronize(h->sT));
     free_plan(h);
-    if (h->dmetric) (void)hipFree(h->dmetric);
-    if (h->dscalar) (void)hipFree(h->dscalar);
-    for (int i = 0; i < 4; i++) if (h->ev[i]) (void)hipEventDestroy(h->ev[i]);
-    for (hipEvent_t e : h->ev_T) (void)hipEventDestroy(e);
-    if (h->ev_v) (void)hipEventDestroy(h->ev_v);
-    if (h->ev_join) (void)hipEventDestroy(h->ev_join);
-    if (h->sD) (void)hipStreamDestroy(h->sD);
-    if (h->ev_x) (void)hipEventDestroy(h->ev_x);
-    if (h->ev_def) (void)hipEventDestroy(h->ev_def);
-    if (h->ev_rest) (void)hipEventDestroy(h->ev_rest);
-    if (h->ev_dist_chain) (void)hipEventDestroy(h->ev_dist_chain);
-    if (h->ev_dist_far) (void)hipEventDestroy(h->ev_dist_far);
-    (void)hipStreamDestroy(h->s0);
-    if (h->s1) (void)hipStreamDestroy(h->s1);
-    if (h->sT) (void)hipStreamDestroy(h->sT);
+    if (h->dmetric) MPQR_IGNORE(hipFree(h->dmetric));
+    if (h->dscalar) MPQR_IGNORE(hipFree(h->dscalar));
+    for (int i = 0; i < 4; i++) if (h->ev[i]) MPQR_IGNORE(hipEventDestroy(h->ev[i]));
+    for (hipEvent_t e : h->ev_T) MPQR_IGNORE(hipEventDestroy(e));
+    if (h->ev_v) MPQR_IGNORE(hipEventDestroy(h->ev_v));
+    if (h->ev_join) MPQR_IGNORE(hipEventDestroy(h->ev_join));
+    if (h->sD) MPQR_IGNORE(hipStreamDestroy(h->sD));
+    if (h->ev_x) MPQR_IGNORE(hipEventDestroy(h->ev_x));
+    if (h->ev_def) MPQR_IGNORE(hipEventDestroy(h->ev_def));
+    if (h->ev_rest) MPQR_IGNORE(hipEventDestroy(h->ev_rest));
+    if (h->ev_dist_chain) MPQR_IGNORE(hipEventDestroy(h->ev_dist_chain));
+    if (h->ev_dist_far) MPQR_IGNORE(hipEventDestroy(h->ev_dist_far));
+    MPQR_IGNORE(hipStreamDestroy(h->s0));
+    if (h->s1) MPQR_IGNORE(hipStreamDestroy(h->s1));
+    if (h->sT) MPQR_IGNORE(hipStreamDestroy(h->sT));
     delete h;
     return MPQR_OK;
 }
@@ -2054,7 +2054,7 @@ int mpqr_get_timings(mpqr_handle_t h, mpqr_timings* t) {
         static const int dbg_blocks = []() { const char* e = getenv("MPQR_DBG_BLOCKS"); return e ? atoi(e) : 0; }();
         if (dbg_blocks) {                                  // measurement aid: chain time of every top-level block + the gap before the next one
             float gap = 0;
-            if (i + 2 < h->chain_used) (void)hipEventElapsedTime(&gap, h->chain_ev[i + 1], h->chain_ev[i + 2]);
+            if (i + 2 < h->chain_used) MPQR_IGNORE(hipEventElapsedTime(&gap, h->chain_ev[i + 1], h->chain_ev[i + 2]));
             fprintf(stderr, "mpqr: block %2zu chain %8.1f us, then %6.1f us before the next block\n", i / 2, x * 1e3f, gap * 1e3f);
         }
     }
@@ -2129,9 +2129,9 @@ int mpqr_bench_leaf_solve(mpqr_handle_t h, int w, int iters, float* us_per_launc
         }
         if (rc == MPQR_OK) { h->us_gh_solve = ms * 1000.f / iters; *us_per_launch = h->us_gh_solve; }
     }
-    if (e0) (void)hipEventDestroy(e0);
-    if (e1) (void)hipEventDestroy(e1);
-    (void)hipFree(dG); (void)hipFree(dA); (void)hipFree(dCv); (void)hipFree(dvd); (void)hipFree(dVh); (void)hipFree(dVt); (void)hipFree(dfl);
+    if (e0) MPQR_IGNORE(hipEventDestroy(e0));
+    if (e1) MPQR_IGNORE(hipEventDestroy(e1));
+    MPQR_IGNORE(hipFree(dG)); MPQR_IGNORE(hipFree(dA)); MPQR_IGNORE(hipFree(dCv)); MPQR_IGNORE(hipFree(dvd)); MPQR_IGNORE(hipFree(dVh)); MPQR_IGNORE(hipFree(dVt)); MPQR_IGNORE(hipFree(dfl));
     return rc;
 }
 
@@ -2183,7 +2183,7 @@ int mpqr_gemm_test_f32(mpqr_handle_t h, const float* A, const float* B, float* C
         if (bad(hipMemcpy(Cp.data(), dC, Cp.size() * 4, hipMemcpyDeviceToHost))) break;
         for (int i = 0; i < M; i++) for (int j = 0; j < N; j++) C[(size_t)i * N + j] = Cp[(size_t)i * Np + j];
     } while (0);
-    (void)hipFree(dA); (void)hipFree(dB); (void)hipFree(dC); (void)hipFree(dAf); (void)hipFree(dA8); (void)hipFree(dB8);
+    MPQR_IGNORE(hipFree(dA)); MPQR_IGNORE(hipFree(dB)); MPQR_IGNORE(hipFree(dC)); MPQR_IGNORE(hipFree(dAf)); MPQR_IGNORE(hipFree(dA8)); MPQR_IGNORE(hipFree(dB8));
     return rc;
 }
 
@@ -2216,9 +2216,9 @@ int mpqr_bench_mfma_peak(mpqr_handle_t h, int shape, float* tflops, float* ghz) 
         *ghz = (float)(g / nwg);
         *tflops = (float)((double)reps * nwg * 8 * (double)iters * 2.0 * 128 * 64 * 32 / (ms * 1e-3) / 1e12);
     } while (0);
-    if (e0) (void)hipEventDestroy(e0);
-    if (e1) (void)hipEventDestroy(e1);
-    (void)hipFree(dsrc); (void)hipFree(dout); (void)hipFree(dclk);
+    if (e0) MPQR_IGNORE(hipEventDestroy(e0));
+    if (e1) MPQR_IGNORE(hipEventDestroy(e1));
+    MPQR_IGNORE(hipFree(dsrc)); MPQR_IGNORE(hipFree(dout)); MPQR_IGNORE(hipFree(dclk));
     return rc;
 }
 
@@ -2268,9 +2268,9 @@ int mpqr_bench_gemm(mpqr_handle_t h, int kernel, int mode, int M, int N, int K, 
         if (bad(hipEventRecord(e1, h->s0)) || bad(hipStreamSynchronize(h->s0)) || bad(hipGetLastError()) || bad(hipEventElapsedTime(&ms, e0, e1))) break;
         *ms_per_launch = ms / iters;
     } while (0);
-    if (e0) (void)hipEventDestroy(e0);
-    if (e1) (void)hipEventDestroy(e1);
-    (void)hipFree(dA); (void)hipFree(dB); (void)hipFree(dC); (void)hipFree(dCt);
+    if (e0) MPQR_IGNORE(hipEventDestroy(e0));
+    if (e1) MPQR_IGNORE(hipEventDestroy(e1));
+    MPQR_IGNORE(hipFree(dA)); MPQR_IGNORE(hipFree(dB)); MPQR_IGNORE(hipFree(dC)); MPQR_IGNORE(hipFree(dCt));
     return rc;
 }
 
@@ -2290,7 +2290,7 @@ static int clear_leaf_flags(mpqr_handle_t h) {
 
 static int ensure_stage(mpqr_handle_t h, size_t elems) {
     if (h->stage_elems >= elems) return MPQR_OK;
-    if (h->dstage) (void)hipFree(h->dstage);
+    if (h->dstage) MPQR_IGNORE(hipFree(h->dstage));
     h->dstage = nullptr; h->stage_elems = 0;
     int rc = dalloc(h, &h->dstage, elems);
     if (rc) return rc;
@@ -2371,10 +2371,10 @@ int mpqr_metrics_device(mpqr_handle_t h, mpqr_metrics* out) {
     const int m = h->m, n = h->n;
     float* R = nullptr; float* work = nullptr;
     if ((rc = dalloc(h, &R, (size_t)m * n))) return rc;
-    if ((rc = dalloc(h, &work, (size_t)m * std::max(m, n)))) { (void)hipFree(R); return rc; }
+    if ((rc = dalloc(h, &work, (size_t)m * std::max(m, n)))) { MPQR_IGNORE(hipFree(R)); return rc; }
     launch_strip_r(h->dA, h->lda, R, m, n, h->s0);
     rc = metrics_core(h, h->dA0, h->lda, R, n, h->dQ, h->ldq, m, n, work, out);
-    (void)hipFree(R); (void)hipFree(work);
+    MPQR_IGNORE(hipFree(R)); MPQR_IGNORE(hipFree(work));
     return rc;
 }
 
@@ -2385,7 +2385,7 @@ int mpqr_metrics_f32(mpqr_handle_t h, const float* A, const float* R, const floa
     int rc;
     if ((rc = dalloc(h, &dA, (size_t)m * n)) || (rc = dalloc(h, &dR, (size_t)m * n)) ||
         (rc = dalloc(h, &dQ, (size_t)m * m)) || (rc = dalloc(h, &work, (size_t)m * std::max(m, n)))) {
-        if (dA) (void)hipFree(dA); if (dR) (void)hipFree(dR); if (dQ) (void)hipFree(dQ);
+        if (dA) MPQR_IGNORE(hipFree(dA)); if (dR) MPQR_IGNORE(hipFree(dR)); if (dQ) MPQR_IGNORE(hipFree(dQ));
         return rc;
     }
     hipError_t e1 = hipMemcpyAsync(dA, A, (size_t)m * n * 4, hipMemcpyHostToDevice, h->s0);
@@ -2393,7 +2393,7 @@ int mpqr_metrics_f32(mpqr_handle_t h, const float* A, const float* R, const floa
     hipError_t e3 = hipMemcpyAsync(dQ, Q, (size_t)m * m * 4, hipMemcpyHostToDevice, h->s0);
     if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess) rc = fail(h, MPQR_ERR_HIP, "H2D copy failed");
     else rc = metrics_core(h, dA, n, dR, n, dQ, m, m, n, work, out);
-    (void)hipFree(dA); (void)hipFree(dR); (void)hipFree(dQ); (void)hipFree(work);
+    MPQR_IGNORE(hipFree(dA)); MPQR_IGNORE(hipFree(dR)); MPQR_IGNORE(hipFree(dQ)); MPQR_IGNORE(hipFree(work));
     return rc;
 }
 
@@ -2402,10 +2402,10 @@ int mpqr_q_error_f32(mpqr_handle_t h, const float* Q, int m, mpqr_metrics* out) 
     HIPCHK(h, hipSetDevice(h->device));
     float *dQ = nullptr, *work = nullptr;
     int rc;
-    if ((rc = dalloc(h, &dQ, (size_t)m * m)) || (rc = dalloc(h, &work, (size_t)m * m))) { if (dQ) (void)hipFree(dQ); return rc; }
+    if ((rc = dalloc(h, &dQ, (size_t)m * m)) || (rc = dalloc(h, &work, (size_t)m * m))) { if (dQ) MPQR_IGNORE(hipFree(dQ)); return rc; }
     if (hipMemcpyAsync(dQ, Q, (size_t)m * m * 4, hipMemcpyHostToDevice, h->s0) != hipSuccess) rc = fail(h, MPQR_ERR_HIP, "H2D copy failed");
     else rc = metrics_core(h, nullptr, 0, nullptr, 0, dQ, m, m, m, work, out);
-    (void)hipFree(dQ); (void)hipFree(work);
+    MPQR_IGNORE(hipFree(dQ)); MPQR_IGNORE(hipFree(work));
     return rc;
 }
 
@@ -2504,8 +2504,8 @@ static int stage_tree_begin(mpqr_handle_t h, StageTree& st, int c0, int c1, int 
     return MPQR_OK;
 }
 static void stage_tree_end(mpqr_handle_t h, StageTree& st) {
-    (void)hipStreamSynchronize(h->s0);
-    if (st.Tf) (void)hipFree(st.Tf); if (st.Th) (void)hipFree(st.Th); if (st.Tth) (void)hipFree(st.Tth);
+    MPQR_IGNORE(hipStreamSynchronize(h->s0));
+    if (st.Tf) MPQR_IGNORE(hipFree(st.Tf)); if (st.Th) MPQR_IGNORE(hipFree(st.Th)); if (st.Tth) MPQR_IGNORE(hipFree(st.Tth));
     h->Tf = st.oTf; h->Th = st.oTh; h->Tth = st.oTth;
     h->nodes = st.saved_nodes; h->tops = st.saved_tops; h->leaf_robust = st.saved_robust;
 }
@@ -2569,7 +2569,7 @@ int mpqr_wy_transform_f32(mpqr_handle_t h, const float* A, int m, int n, int go,
         for (int i = 0; i < W; i++) for (int j = 0; j < pw && j <= i; j++) V[(size_t)i * pw + j] = A[(size_t)(go + i + 1) * n + go + j];
         float *dV = nullptr, *dT = nullptr, *dW = nullptr, *dQp = nullptr;
         if ((rc = dalloc(h, &dV, V.size())) || (rc = dalloc(h, &dT, Tl.size())) || (rc = dalloc(h, &dW, V.size())) ||
-            (rc = dalloc(h, &dQp, (size_t)W * W))) { if (dV) (void)hipFree(dV); if (dT) (void)hipFree(dT); if (dW) (void)hipFree(dW); return rc; }
+            (rc = dalloc(h, &dQp, (size_t)W * W))) { if (dV) MPQR_IGNORE(hipFree(dV)); if (dT) MPQR_IGNORE(hipFree(dT)); if (dW) MPQR_IGNORE(hipFree(dW)); return rc; }
         HIPQ(h, hipMemcpyAsync(dV, V.data(), V.size() * 4, hipMemcpyHostToDevice, h->s0));
         HIPQ(h, hipMemcpyAsync(dT, Tl.data(), Tl.size() * 4, hipMemcpyHostToDevice, h->s0));
         HIPQ(h, hipMemsetAsync(dQp, 0, (size_t)W * W * 4, h->s0));
@@ -2581,8 +2581,8 @@ int mpqr_wy_transform_f32(mpqr_handle_t h, const float* A, int m, int n, int go,
         b.alpha = -1.f; b.beta = 1.f; b.nslab_a = 1;
         launch_sgemm(b, h->s0);
         hipError_t e2 = hipMemcpyAsync(Qpanel, dQp, (size_t)W * W * 4, hipMemcpyDeviceToHost, h->s0);
-        (void)hipStreamSynchronize(h->s0);
-        (void)hipFree(dV); (void)hipFree(dT); (void)hipFree(dW); (void)hipFree(dQp);
+        MPQR_IGNORE(hipStreamSynchronize(h->s0));
+        MPQR_IGNORE(hipFree(dV)); MPQR_IGNORE(hipFree(dT)); MPQR_IGNORE(hipFree(dW)); MPQR_IGNORE(hipFree(dQp));
         if (e2 != hipSuccess) return fail(h, MPQR_ERR_HIP, "D2H of Q_panel failed");
     }
     return MPQR_OK;
@@ -2666,7 +2666,7 @@ int ls_core(mpqr_handle_t h, const float* B, int nrhs, float* out, bool solve) {
     hipError_t e0 = hipMemsetAsync(dB, 0, (size_t)(h->m_pad + 256) * ldb * sizeof(float), h->s0);
     hipError_t e1 = hipMemcpy2DAsync(dB, ldb * sizeof(float), B, (size_t)nrhs * sizeof(float), (size_t)nrhs * sizeof(float),
                                      h->m, hipMemcpyHostToDevice, h->s0);
-    if (e0 != hipSuccess || e1 != hipSuccess) { (void)hipFree(dB); return fail(h, MPQR_ERR_HIP, "copy-in failed"); }
+    if (e0 != hipSuccess || e1 != hipSuccess) { MPQR_IGNORE(hipFree(dB)); return fail(h, MPQR_ERR_HIP, "copy-in failed"); }
     rc = apply_qt_device(h, dB, ldb, nrhs);
     if (!rc && solve) rc = back_substitute_device(h, dB, ldb, nrhs);
     if (!rc) {
@@ -2676,8 +2676,8 @@ int ls_core(mpqr_handle_t h, const float* B, int nrhs, float* out, bool solve) {
         hipError_t e3 = hipStreamSynchronize(h->s0);
         if (e2 != hipSuccess || e3 != hipSuccess) rc = fail(h, MPQR_ERR_HIP, "copy-out failed");
     }
-    (void)hipStreamSynchronize(h->s0);
-    (void)hipFree(dB);
+    MPQR_IGNORE(hipStreamSynchronize(h->s0));
+    MPQR_IGNORE(hipFree(dB));
     return rc;
 }
 }  // namespace
@@ -2708,7 +2708,7 @@ int mpqr_qr_factorization_f64(mpqr_handle_t h, double* A, double* Q, int m, int 
     HIPCHK(h, hipSetDevice(h->device));
     double *dA = nullptr, *dQ = nullptr, *dw = nullptr;
     if ((rc = dalloc(h, &dA, (size_t)m * n)) || (rc = dalloc(h, &dQ, (size_t)m * m)) || (rc = dalloc(h, &dw, (size_t)m))) {
-        if (dA) (void)hipFree(dA); if (dQ) (void)hipFree(dQ);
+        if (dA) MPQR_IGNORE(hipFree(dA)); if (dQ) MPQR_IGNORE(hipFree(dQ));
         return rc;
     }
     std::vector<double> I((size_t)m * m, 0.0);
@@ -2719,7 +2719,7 @@ int mpqr_qr_factorization_f64(mpqr_handle_t h, double* A, double* Q, int m, int 
     hipError_t e3 = hipMemcpyAsync(A, dA, (size_t)m * n * 8, hipMemcpyDeviceToHost, h->s0);
     hipError_t e4 = hipMemcpyAsync(Q, dQ, (size_t)m * m * 8, hipMemcpyDeviceToHost, h->s0);
     hipError_t e5 = hipStreamSynchronize(h->s0);
-    (void)hipFree(dA); (void)hipFree(dQ); (void)hipFree(dw);
+    MPQR_IGNORE(hipFree(dA)); MPQR_IGNORE(hipFree(dQ)); MPQR_IGNORE(hipFree(dw));
     if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess || e4 != hipSuccess || e5 != hipSuccess)
         return fail(h, MPQR_ERR_HIP, "fp64 path: HIP call failed");
     return MPQR_OK;

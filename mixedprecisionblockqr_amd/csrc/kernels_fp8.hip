@@ -249,7 +249,7 @@ __global__ __launch_bounds__(512) void gemm8_fp8_kernel(GemmArgs g, int tilesM, 
 template <int EM>
 static void launch8(const GemmArgs& g, hipStream_t s) {
     constexpr int LDS = 2 * 2 * 256 * 128;
-    MPQR_ONCE_PER_DEVICE((void)hipFuncSetAttribute((const void*)gemm8_fp8_kernel<EM, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+    MPQR_ONCE_PER_DEVICE(MPQR_IGNORE(hipFuncSetAttribute((const void*)gemm8_fp8_kernel<EM, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS)));
     const int tilesM = (g.M + 255) / 256, tilesN = (g.N + 255) / 256;
     const int groups = ((tilesM + 3) / 4) * ((tilesN + 7) / 8);
     GemmArgs a = g;

@@ -309,7 +309,7 @@ template <int AM, int EM, int WM, int WN, int BK>
 static void launch2(const GemmArgs& g, hipStream_t s) {
     constexpr int BM = 128 * WM, BN = 64 * WN, NT = 64 * WM * WN;
     constexpr int LDS = 2 * ((AM == A_F32S ? 2 : 1) * BM + BN) * BK * 2;
-    MPQR_ONCE_PER_DEVICE((void)hipFuncSetAttribute((const void*)gemm2_f16_kernel<AM, EM, WM, WN, BK>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+    MPQR_ONCE_PER_DEVICE(MPQR_IGNORE(hipFuncSetAttribute((const void*)gemm2_f16_kernel<AM, EM, WM, WN, BK>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS)));
     const int tilesM = (g.M + BM - 1) / BM, tilesN = (g.N + BN - 1) / BN;
     const int groups = ((tilesM + 3) / 4) * ((tilesN + 7) / 8);
     GemmArgs a = g;
@@ -754,7 +754,7 @@ static void launch6(const GemmArgs& g, hipStream_t s) {
         static const int dr = []() { const char* e = getenv("MPQR_G6_DR"); return e ? atoi(e) : 0; }();
         if (dr) { launch6<EM, DMA_EPI, MF, 1>(g, s); return; }
     }
-    MPQR_ONCE_PER_DEVICE((void)hipFuncSetAttribute((const void*)gemm6_f16_kernel<EM, DMA_EPI, MF, DR>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+    MPQR_ONCE_PER_DEVICE(MPQR_IGNORE(hipFuncSetAttribute((const void*)gemm6_f16_kernel<EM, DMA_EPI, MF, DR>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS)));
     const int tilesM = (g.M + 255) / 256, tilesN = (g.N + 255) / 256;
     const int groups = ((tilesM + 3) / 4) * ((tilesN + 7) / 8);
     hipLaunchKernelGGL((gemm6_f16_kernel<EM, DMA_EPI, MF, DR>), dim3(groups * 32), dim3(512), LDS, s, g, tilesM, tilesN);

@@ -231,7 +231,7 @@ __global__ void absmax_kernel(const float* A, long lda, int m, int n, float* out
     if ((threadIdx.x & 63) == 0) atomicMax((unsigned int*)out, __float_as_uint(mx));
 }
 void launch_absmax(const float* A, long lda, int m, int n, float* out, hipStream_t s) {
-    (void)hipMemsetAsync(out, 0, sizeof(float), s);
+    MPQR_IGNORE(hipMemsetAsync(out, 0, sizeof(float), s));
     hipLaunchKernelGGL(absmax_kernel, dim3(2048), dim3(256), 0, s, A, lda, m, n, out);
 }
 
@@ -260,7 +260,7 @@ __global__ __launch_bounds__(256) void copy_absmax_kernel(const float* __restric
     if ((threadIdx.x & 63) == 0) atomicMax((unsigned int*)out, __float_as_uint(mx));
 }
 void launch_copy_absmax(const float* src, float* dst, long ld, int rows, int m, int n, float* out, hipStream_t s) {
-    (void)hipMemsetAsync(out, 0, sizeof(float), s);
+    MPQR_IGNORE(hipMemsetAsync(out, 0, sizeof(float), s));
     hipLaunchKernelGGL(copy_absmax_kernel, dim3(std::min(rows, 4096)), dim3(256), 0, s, src, dst, ld, rows, m, n, out);
 }
 

@@ -592,6 +592,8 @@ __global__ __launch_bounds__(256) void gh_reduce_f32_kernel(const float* __restr
 // blocks of 64 rows per gh_apply workgroup: tall leaves take 2 / 4, which still leaves >= 256 workgroups
 static int gh_apply_iters(const LeafArgs& a) {
     const int rows = a.mrows - a.c1;
+    static const int it_env = []() { const char* e = getenv("MPQR_APPLY_ITERS"); return e ? atoi(e) : 0; }();   // A/B hook (row blocks per workgroup of gh_apply / leaf_a)
+    if (it_env > 0 && rows >= 64 * it_env * 8) return it_env;
     return rows >= 49152 ? 4 : rows >= 24576 ? 2 : 1;
 }
 int gh_num_partials(const LeafArgs& a) {
@@ -602,8 +604,8 @@ void launch_gh_reduce_f32(const float* Sp, int nslab, float* S, hipStream_t s) {
     hipLaunchKernelGGL(gh_reduce_f32_kernel, dim3(256), dim3(256), 0, s, Sp, nslab, S);
 }
 static void gh_set_attrs() {
-    MPQR_ONCE_PER_DEVICE((void)hipFuncSetAttribute((const void*)gh_gram_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, GH_ROWS * GH_TD * 8);
-                         (void)hipFuncSetAttribute((const void*)gh_apply_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (8256 + GW * GH_TS) * 4));
+    MPQR_ONCE_PER_DEVICE(MPQR_IGNORE(hipFuncSetAttribute((const void*)gh_gram_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, GH_ROWS * GH_TD * 8));
+                         MPQR_IGNORE(hipFuncSetAttribute((const void*)gh_apply_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (8256 + GW * GH_TS) * 4)));
 }
 // the four steps of a Gram-Householder leaf, separately launchable (the look-ahead schedule puts them on different streams)
 void launch_gh_gram(const LeafArgs& a, double* Gp, double* G, hipStream_t s) {
@@ -775,7 +777,7 @@ __global__ __launch_bounds__(1024) void leaf_tail_kernel(LeafArgs a, float* __re
 }
 
 void launch_leaf_tail(const LeafArgs& a, float* S, hipStream_t s) {
-    MPQR_ONCE_PER_DEVICE((void)hipFuncSetAttribute((const void*)leaf_tail_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, TP * TPS * 4));
+    MPQR_ONCE_PER_DEVICE(MPQR_IGNORE(hipFuncSetAttribute((const void*)leaf_tail_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, TP * TPS * 4)));
     hipLaunchKernelGGL(leaf_tail_kernel, dim3(1), dim3(1024), TP * TPS * 4, s, a, S);
 }
 
@@ -1068,7 +1070,7 @@ __global__ __launch_bounds__(1024) void t_merge_kernel(const float* __restrict__
 }
 
 void launch_t_merge(const float* S, int ldl, int ldr, const float* TL, const float* TR, float* TLR, hipStream_t s) {
-    MPQR_ONCE_PER_DEVICE((void)hipFuncSetAttribute((const void*)t_merge_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * TP * TPS * 4));
+    MPQR_ONCE_PER_DEVICE(MPQR_IGNORE(hipFuncSetAttribute((const void*)t_merge_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * TP * TPS * 4)));
     hipLaunchKernelGGL(t_merge_kernel, dim3(1), dim3(1024), 2 * TP * TPS * 4, s, S, ldl, ldr, TL, TR, TLR);
 }
 
@@ -1107,14 +1109,14 @@ __global__ __launch_bounds__(1024) void trsm_diag_kernel(const float* __restrict
     }
 }
 void launch_trsm_diag(const float* R, long ldr, int k0, int kb, float* Y, long ldy, int nrhs, hipStream_t s) {
-    MPQR_ONCE_PER_DEVICE((void)hipFuncSetAttribute((const void*)trsm_diag_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * TP * TPS * 4));
+    MPQR_ONCE_PER_DEVICE(MPQR_IGNORE(hipFuncSetAttribute((const void*)trsm_diag_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * TP * TPS * 4)));
     hipLaunchKernelGGL(trsm_diag_kernel, dim3(1), dim3(1024), 2 * TP * TPS * 4, s, R, ldr, k0, kb, Y, ldy, nrhs);
 }
 
 void launch_t_leaf(const float* S, int nslab, long slab_stride, int lds_, int a0, int c0, int c1, float* T, half_t* Th,
                    half_t* Tth, int ldt, hipStream_t s, int ld) {
     if (ld <= 0) ld = ldt;
-    MPQR_ONCE_PER_DEVICE((void)hipFuncSetAttribute((const void*)t_panel_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * TP * TPS * 4));
+    MPQR_ONCE_PER_DEVICE(MPQR_IGNORE(hipFuncSetAttribute((const void*)t_panel_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * TP * TPS * 4)));
     hipLaunchKernelGGL(t_panel_kernel, dim3(1), dim3(1024), 2 * TP * TPS * 4, s, S, nslab, slab_stride, lds_, a0, c0, c1, T, Th,
                        Tth, ldt, ld);
 }
@@ -1197,7 +1199,7 @@ void launch_leaf_mid(const GemmArgs& g1, const float* Sp, int nslab, float* S, i
                      float* T, half_t* Th, half_t* Tth, int ldt, int ld, hipStream_t s) {
     constexpr int LDS = 2 * TP * TPS * 4;
     static_assert(LDS >= (gemm128::BM + gemm128::BN) * gemm128::LDSP * 2, "the GEMM tile's LDS image fits in the T body's");
-    MPQR_ONCE_PER_DEVICE((void)hipFuncSetAttribute((const void*)leaf_mid_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+    MPQR_ONCE_PER_DEVICE(MPQR_IGNORE(hipFuncSetAttribute((const void*)leaf_mid_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS)));
     LeafMidArgs m{};
     m.g = g1;
     if (m.g.nsplit < 1) m.g.nsplit = 1;
@@ -1709,7 +1711,7 @@ int fl_gram_partials(const LeafArgs& a) {                   // partial Gram matr
     return ((rows + FL_B_ROWS - 1) / FL_B_ROWS + it - 1) / it;
 }
 void launch_leaf_a(const LeafArgs& a, const float* Cv, float* Sp, float* Xp, int nb, float in_scale, hipStream_t s) {
-    MPQR_ONCE_PER_DEVICE((void)hipFuncSetAttribute((const void*)leaf_a_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, FL_A_LDS));
+    MPQR_ONCE_PER_DEVICE(MPQR_IGNORE(hipFuncSetAttribute((const void*)leaf_a_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, FL_A_LDS)));
     const int it = gh_apply_iters(a);
     const int nlow = ((a.mrows - a.c1 + 63) / 64 + it - 1) / it;
     const int ntop = (a.c1 - a.c0 + 63) / 64;
@@ -1718,7 +1720,7 @@ void launch_leaf_a(const LeafArgs& a, const float* Cv, float* Sp, float* Xp, int
 void launch_leaf_m(const float* Sp, const float* Xp, int nslab, float* S, float* Xs, int* counter, int sh, int a0, int c0, int c1,
                    float* T, half_t* Th, half_t* Tth, int ldt, int ld, half_t* Y, hipStream_t s, int* pub_flag, int pub_value) {
     constexpr int LDS = 2 * TP * TPS * 4;
-    MPQR_ONCE_PER_DEVICE((void)hipFuncSetAttribute((const void*)leaf_m_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+    MPQR_ONCE_PER_DEVICE(MPQR_IGNORE(hipFuncSetAttribute((const void*)leaf_m_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS)));
     LeafM2Args m{};
     m.Sp = Sp; m.Xp = Xp; m.nslab = nslab; m.S = S; m.Xs = Xs; m.counter = counter;
     m.ngrp = std::max(1, std::min(LEAF_MID_MAX_GROUPS, nslab / 256));
@@ -1728,7 +1730,7 @@ void launch_leaf_m(const float* Sp, const float* Xp, int nslab, float* S, float*
 }
 void launch_leaf_b(const LeafArgs& a, int nb, const half_t* Y, float alpha, double* Gp, bool do_gram, int* pub_flag, int pub_value, hipStream_t s) {
     constexpr int LDS = FL_B_ROWS * GH_TD * 8;
-    MPQR_ONCE_PER_DEVICE((void)hipFuncSetAttribute((const void*)leaf_b_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+    MPQR_ONCE_PER_DEVICE(MPQR_IGNORE(hipFuncSetAttribute((const void*)leaf_b_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS)));
     const int rows = a.mrows - a.c1;
     const int it = rows >= 49152 ? 4 : rows >= 24576 ? 2 : 1;
     const int ng = rows > 0 ? ((rows + FL_B_ROWS - 1) / FL_B_ROWS + it - 1) / it : 0;

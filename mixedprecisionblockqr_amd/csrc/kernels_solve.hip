@@ -786,7 +786,7 @@ __global__ __launch_bounds__(S3_THREADS) void gh_solve3_kernel(LeafArgs a, const
 }
 
 void launch_gh_solve3(const LeafArgs& a, const double* G, float* Cv, int* flag, hipStream_t s, const SolveWait* ws) {
-    MPQR_ONCE_PER_DEVICE((void)hipFuncSetAttribute((const void*)gh_solve3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, S3_LDS_BYTES));
+    MPQR_ONCE_PER_DEVICE(MPQR_IGNORE(hipFuncSetAttribute((const void*)gh_solve3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, S3_LDS_BYTES)));
     SolveWait w{}; if (ws) w = *ws;
     hipLaunchKernelGGL(gh_solve3_kernel, dim3(1), dim3(S3_THREADS), S3_LDS_BYTES, s, a, G, Cv, flag, w);
 }

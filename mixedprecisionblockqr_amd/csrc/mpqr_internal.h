@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdio.h>
 #include <atomic>
 #include <mutex>
 #include <string>
@@ -27,6 +28,13 @@ inline void once_per_device(std::atomic<unsigned long long>& done, std::mutex& m
     set();
     done.fetch_or(bit, std::memory_order_release);
 }
+// A HIP call whose failure does not change what the caller can do (teardown, attribute set-up, best-effort hints): the result is still
+// LOOKED AT -- a failure is reported on stderr with its call site -- instead of being cast to void (hygiene).
+#define MPQR_IGNORE(call)                                                                                          \
+    do {                                                                                                           \
+        hipError_t ie_ = (call);                                                                                   \
+        if (ie_ != hipSuccess) fprintf(stderr, "mpqr: %s failed: %s (%s:%d)\n", #call, hipGetErrorString(ie_), __FILE__, __LINE__); \
+    } while (0)
 #define MPQR_ONCE_PER_DEVICE(stmt)                                                   \
     do {                                                                             \
         static std::atomic<unsigned long long> once_done_{0};                        \
