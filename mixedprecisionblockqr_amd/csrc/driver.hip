@@ -1613,7 +1613,7 @@ static int plan_common(mpqr_handle_t h, int m, int n, int r, const mpqr_opts* op
     HIPCHK(h, hipMemsetAsync(h->rbTh, 0, (h->rb_elems + (size_t)256 * 256) * sizeof(half_t), h->s0));
     HIPCHK(h, hipMemsetAsync(h->rbTth, 0, (h->rb_elems + (size_t)256 * 256) * sizeof(half_t), h->s0));
     // event pools (nothing is created inside the timed region): 2 recorded far updates per block, 2 chain events per block
-    for (size_t i = 0; i < 12 * h->tops.size() + 8; i++) { hipEvent_t e; HIPCHK(h, hipEventCreate(&e)); h->far_ev.push_back(e); }   // + 1 per block for Q formation
+    for (size_t i = 0; i < 16 * h->tops.size() + 8; i++) { hipEvent_t e; HIPCHK(h, hipEventCreate(&e)); h->far_ev.push_back(e); }   // + 1 per block for Q formation
     for (size_t i = 0; i < 2 * h->tops.size() + 2; i++) { hipEvent_t e; HIPCHK(h, hipEventCreate(&e)); h->chain_ev.push_back(e); }
     if ((rc = dalloc(h, &h->dA0, (size_t)h->m_pad * h->lda + 1024))) return rc;
     if ((rc = dalloc(h, &h->tmp1, h->tmp_elems))) return rc;
@@ -1813,6 +1813,19 @@ static int run_block_loop(mpqr_handle_t h, int start = 0) {
     const bool far_pair = la && fp_env && h->opts.precision == MPQR_PREC_FP16 && h->opts.form_q && h->S2 && h->qroot < 0;
     bool deferred = false, pair_merged = false;
     int pending_far = -1;                                   // block whose far update waits for the next block's first leaf
+    // A large pair update is enqueued in two column halves, the second one a block later BEHIND that block's urgent updates (its part (a),
+    // the even block's extra columns).  The far stream works in order: the pair (0, 1) at 16384^2 takes 2.7 ms, longer than block 2's chain
+    // beside it, and block 3 sat ~0.5 ms at its third leaf waiting for a 0.25 ms part (a) queued behind it (MPQR_DBG_STAMPS / MPQR_DBG_BLOCKS).
+    // Only where the update is that long (>= 12000 columns: the first pair of 16384^2; 33.0 -> 32.6 ms): the X GEMM of a half has half the
+    // tiles, and from the second pair on that costs more than the queueing did (8192: 33.4 ms; halves of 33 / 66 / 10 %: 33.0).
+    struct HalfB { int node = -1, lo = 0, hi = 0; bool at_read = false; } half_b;
+    static const int split_min = []() { const char* e = getenv("MPQR_PAIR_SPLIT_MIN"); return e ? atoi(e) : 12000; }();
+    auto flush_half_b = [&]() {
+        if (half_b.node < 0) return;
+        h->at_read = half_b.at_read;
+        apply_node(h, h->nodes[half_b.node], h->dA, h->lda, half_b.lo, half_b.hi, true, h->a_scale, true, 1, true);
+        half_b.node = -1;
+    };
     auto far_update = [&](size_t t) -> int {
         const Node nd = h->nodes[h->tops[t]];
         Range rg("mpqr:far_update");
@@ -1835,15 +1848,26 @@ static int run_block_loop(mpqr_handle_t h, int start = 0) {
                 const int e_next = (t + 2 < nt) ? (ext[t + 2] ? cfirst[t + 3] : h->nodes[h->tops[t + 2]].c1) : h->n;
                 apply_node(h, nd, h->dA, h->lda, a_end, std::min(e_next, h->n), true, h->a_scale, true, 1, true);
                 deferred = e_next < h->n;
+                flush_half_b();                             // the previous pair's second half, behind this block's urgent columns
             } else if (deferred) {
                 // odd block: the pair (t-1, t) onto everything neither of them has reached yet
+                flush_half_b();                             // (cannot be pending here: the even block between took it)
                 merge_pair(h, h->qpair[t], h->s1); pair_merged = true;
                 h->at_read = t >= 3;                        // the first pair's columns have not been written by a far update yet
-                apply_node(h, h->nodes[h->qpair[t]], h->dA, h->lda, a_end, h->n, true, h->a_scale, true, 1, true);
+                // first half: at least everything the next block's far update touches (its part (a) and extra columns end at cfirst[t + 4])
+                int mid = h->n;
+                if (split_min > 0 && t + 2 < nt && h->n - a_end >= split_min) {
+                    const int need = cfirst[std::min(t + 4, nt + 1)];
+                    mid = std::max(need, a_end + rup((h->n - a_end) / 2, 256));
+                    if (h->n - mid < 256) mid = h->n;
+                }
+                apply_node(h, h->nodes[h->qpair[t]], h->dA, h->lda, a_end, mid, true, h->a_scale, true, 1, true);
+                if (mid < h->n) { half_b.node = h->qpair[t]; half_b.lo = mid; half_b.hi = h->n; half_b.at_read = t >= 3; }
                 deferred = false;
             } else
             apply_node(h, nd, h->dA, h->lda, a_end, h->n, true, h->a_scale, true, 1, true);       // ... the rest overlaps its panels
         }
+        if ((t % 2) == 0 || t + 1 >= nt) flush_half_b();       // (an even block that took another branch; the last block)
         // Q formation works on pairs of blocks: the pair's T behind this block's far update, beside the next panels
         if (h->opts.form_q && h->qpair[t] >= 0 && h->S2 && !pair_merged) merge_pair(h, h->qpair[t], h->s1);
         pair_merged = false;
@@ -1894,6 +1918,7 @@ static int run_block_loop(mpqr_handle_t h, int start = 0) {
         if (defer_env && ext[t] && t + 1 < nt && flat[t + 1]) { pending_far = (int)t; continue; }   // (a flat block takes the hook in its first leaf)
         if ((rc = far_update(t))) { h->defer_join = false; h->watch_flags = false; return rc; }
     }
+    if (!aborted) flush_half_b();                           // (every far_update has run; nothing can be pending)
     h->watch_flags = false; h->pass_aborted = aborted; h->pre_leaves = 0; h->cur_block = 0;
     h->pairs_ready = !aborted && h->opts.form_q && h->S2 != nullptr;     // (pairs or the whole tree)
     if (h->defer_join) {                                    // the T stream's work of every block, once

@@ -1003,6 +1003,30 @@ def test_opt_in_schedules_and_kernels():
 
 
 @pytest.mark.gpu
+def test_large_pair_update_in_two_halves_gives_the_same_factorisation():
+    """A long pairwise far update is enqueued in two column halves, the second one a block later behind that block's urgent updates
+    (driver.hip run_block_loop, `half_b`; by default only from 12000 columns on).  A child process lowers the threshold so that a
+    seven-block case takes it: one more far launch and the same factorisation up to the summation order of X = A2^T V (a half has its
+    own split of the K range)."""
+    import json, os, subprocess, sys
+    child = os.path.join(os.path.dirname(os.path.abspath(__file__)), "optin_child.py")
+    outs = []
+    for k, extra in enumerate(({"MPQR_PAIR_SPLIT_MIN": "0"}, {"MPQR_PAIR_SPLIT_MIN": "512"})):
+        env = dict(os.environ); env.update(extra)
+        p = subprocess.run([sys.executable, child, "3584", "3584", "128", "512"], env=env, capture_output=True, text=True, timeout=600)
+        assert p.returncode == 0, (extra, p.stderr[-2000:])
+        outs.append(json.loads(p.stdout.strip().splitlines()[-1]))
+    o0, o1 = outs
+    assert o1["n_far_launches"] == o0["n_far_launches"] + 1, (o0["n_far_launches"], o1["n_far_launches"])
+    for o in outs:
+        assert o["backward_error"] <= 1e-3 and o["orth_max"] <= 2e-3, o          # north_star tolerance
+    d0, d1 = np.array(o0["absdiag"]), np.array(o1["absdiag"])
+    # (a square random matrix: the last |R_kk| are ~1e-3 of the first and of the size of the fp16 update's rounding, so the comparison is absolute)
+    assert np.max(np.abs(d1 - d0)) <= 1.5e-3 * d0.max(), float(np.max(np.abs(d1 - d0)) / d0.max())
+    assert abs(o1["backward_error"] - o0["backward_error"]) <= 0.05 * o0["backward_error"], (o0["backward_error"], o1["backward_error"])
+
+
+@pytest.mark.gpu
 def test_q_identity_columns_fast_path_matches_oracle(po, tmp_path):
     """Q formation copies the rows of X = Q2^T V that belong to columns of Q which are still identity columns (driver.hip apply_node,
     `idc`).  At the library's default thresholds only 16384^2-sized runs reach that branch; a child process lowers them
