@@ -1423,12 +1423,10 @@ static int plan_common(mpqr_handle_t h, int m, int n, int r, const mpqr_opts* op
     HIPCHK(h, hipStreamSynchronize(h->s0));
     free_plan(h);
     h->m = m; h->n = n; h->r = r; h->opts = o; h->world = world; h->rank = rank;
-    {   // The compact-WY T's are built on a third stream beside the chain's next V-only GEMM (MPQR_TSTREAM=0: on the chain
-        // stream).  With the tree schedule alone this did not pay (the serial leaf T -> merge -> merge chain at the end of a
+    {   // The compact-WY T's are built on a third stream beside the chain's next V-only GEMM.  With the tree schedule alone this did not pay (the serial leaf T -> merge -> merge chain at the end of a
         // sub-tree is longer than the GEMM it hides behind: 60.9 vs 59.0 ms at 16384^2); the flat block schedule
         // (factor_block_flat) needs only the leaf's own T on the chain and is what the T stream is for (53.0 ms).
-        const char* e = getenv("MPQR_TSTREAM");
-        h->tq_on = h->sT != nullptr && o.precision != MPQR_PREC_FP32 && !(e && atoi(e) == 0);
+        h->tq_on = h->sT != nullptr && o.precision != MPQR_PREC_FP32;
     }
     if (const char* e = getenv("MPQR_GH_MIN_ROWS")) h->gh_min_rows = atoi(e);      // tuning hook
     if (const char* e = getenv("MPQR_TAIL_LEAF")) h->tail_leaf = atoi(e) != 0;       // A/B hook
@@ -1453,7 +1451,6 @@ static int plan_common(mpqr_handle_t h, int m, int n, int r, const mpqr_opts* op
     size_t q_half = 0;                                    // largest L.ldt x R.ldt of a tree merge (scratch of merge_pair)
     h->qroot = -1;
     {
-        static const int qp_on = []() { const char* e = getenv("MPQR_QPAIR"); return e ? atoi(e) : 1; }();
         static const int one_on = []() { const char* e = getenv("MPQR_QONESHOT"); return e ? atoi(e) : 1; }();
         bool aligned = h->tops.size() >= 2;
         for (size_t p = 0; p + 1 < h->tops.size() && aligned; p++) {
@@ -1461,9 +1458,7 @@ static int plan_common(mpqr_handle_t h, int m, int n, int r, const mpqr_opts* op
             aligned = L.a0 == L.c0 && R.a0 == R.c0 && L.a1 == R.a0;
         }
         h->qmerge_after.assign(h->tops.size(), std::vector<int>());
-        const char* g6 = getenv("MPQR_GEMM6");             // the I - W V^T epilogue lives in the ping-pong kernel only
-        if (one_on && aligned && o.form_q && o.precision != MPQR_PREC_FP32 && (long)m >= 3L * n && m >= 2048 &&
-            !(g6 && atoi(g6) == 0)) {
+        if (one_on && aligned && o.form_q && o.precision != MPQR_PREC_FP32 && (long)m >= 3L * n && m >= 2048) {
             // prefix nodes P_k = blocks 0..k, all in ONE arena of the full width (P_k's T is the leading principal block of
             // the root's): step k adds the column block  T[0:o, o:o+w] = -T_{P_{k-1}} (V_P^T V_k) T_k  (LAPACK larft order, as
             // the flat block schedule does for the leaves of a block).  One arena instead of a tree of them; measured the same
@@ -1486,7 +1481,7 @@ static int plan_common(mpqr_handle_t h, int m, int n, int r, const mpqr_opts* op
             }
             h->qroot = prev;
         } else
-        if (qp_on && o.form_q && o.precision != MPQR_PREC_FP32) {             // (every rank of a distributed plan builds the same pairs)
+        if (o.form_q && o.precision != MPQR_PREC_FP32) {             // (every rank of a distributed plan builds the same pairs)
             for (size_t p = 0; p + 1 < h->tops.size(); p += 2) {
                 const Node L = h->nodes[h->tops[p]], R = h->nodes[h->tops[p + 1]];
                 if (L.a0 != L.c0 || R.a0 != R.c0 || L.a1 != R.a0 || L.ldt < 256 || R.ldt < 256) continue;
@@ -1619,8 +1614,7 @@ static int plan_common(mpqr_handle_t h, int m, int n, int r, const mpqr_opts* op
     if ((rc = dalloc(h, &h->tmp1, h->tmp_elems))) return rc;
     if ((rc = dalloc(h, &h->tmp2, h->tmp_elems))) return rc;
     {
-        static const int sh_on = []() { const char* e = getenv("MPQR_QSHADOW"); return e ? atoi(e) : 1; }();
-        if (sh_on && o.form_q && o.precision != MPQR_PREC_FP32 && h->qroot < 0) {
+        if (o.form_q && o.precision != MPQR_PREC_FP32 && h->qroot < 0) {
             h->ldqt = h->m_pad;                             // one row per LOCAL column of Q (all of them on a single GPU)
             if ((rc = dalloc(h, &h->Qt, (size_t)(h->ldq + 256) * h->ldqt))) return rc;
 
@@ -1758,9 +1752,8 @@ static int run_block_loop(mpqr_handle_t h, int start = 0) {
         for (int s = 0; s < start; s++) apply_node(h, h->nodes[h->tops[s]], h->dA, h->lda, cs, h->n, true, h->a_scale, false, 0, true);
     }
     HIPCHK(h, hipMemsetAsync(h->dflag, 0, (size_t)h->nflag * sizeof(int), h->s0));
-    static const int watch_env = []() { const char* e = getenv("MPQR_WATCH_FLAGS"); return e ? atoi(e) : 1; }();   // 0: never stop a pass early (round 2)
     for (int b = 0; b < h->flag_words; b++) __atomic_store_n(h->hflag_host + b, 0, __ATOMIC_RELAXED);   // (no leaf of an earlier pass is still running: mpqr_factor waits for every pass's last leaf)
-    h->watch_flags = watch_env != 0;
+    h->watch_flags = true;
     bool aborted = false;
     const bool la = h->Xt1 != nullptr;                    // look-ahead: far updates on s1, panel chain on s0
     if (la) {
@@ -1808,9 +1801,8 @@ static int run_block_loop(mpqr_handle_t h, int start = 0) {
     std::vector<int> lvtmp;
     h->defer_join = la && h->tq_on;
     // far updates beyond the next two blocks are taken pairwise (K = 2 outer blocks: the GEMMs run ~25 % faster and there
-    // are half as many), with the pair T that Q formation needs anyway (MPQR_FAR_PAIR=0: every block on its own)
-    static const int fp_env = []() { const char* e = getenv("MPQR_FAR_PAIR"); return e ? atoi(e) : 1; }();
-    const bool far_pair = la && fp_env && h->opts.precision == MPQR_PREC_FP16 && h->opts.form_q && h->S2 && h->qroot < 0;
+    // are half as many), with the pair T that Q formation needs anyway
+    const bool far_pair = la && h->opts.precision == MPQR_PREC_FP16 && h->opts.form_q && h->S2 && h->qroot < 0;
     bool deferred = false, pair_merged = false;
     int pending_far = -1;                                   // block whose far update waits for the next block's first leaf
     // A large pair update is enqueued in two column halves, the second one a block later BEHIND that block's urgent updates (its part (a),
@@ -1914,8 +1906,7 @@ static int run_block_loop(mpqr_handle_t h, int start = 0) {
         // block's first leaf, behind its gh_gram (factor_block_flat, far_hook): ev_node[t] is then recorded on the chain stream
         // behind that launch, the far stream's first GEMMs start together with the leaf's gh_solve and fill the CUs the solve
         // leaves idle, instead of taking every CU while gh_gram (139 KB of LDS per workgroup: whole CUs) wants them.
-        static const int defer_env = []() { const char* e = getenv("MPQR_DEFER_FAR"); return e ? atoi(e) : 1; }();
-        if (defer_env && ext[t] && t + 1 < nt && flat[t + 1]) { pending_far = (int)t; continue; }   // (a flat block takes the hook in its first leaf)
+        if (ext[t] && t + 1 < nt && flat[t + 1]) { pending_far = (int)t; continue; }   // (a flat block takes the hook in its first leaf)
         if ((rc = far_update(t))) { h->defer_join = false; h->watch_flags = false; return rc; }
     }
     if (!aborted) flush_half_b();                           // (every far_update has run; nothing can be pending)
@@ -2008,8 +1999,7 @@ int mpqr_factor(mpqr_handle_t h) {
             if (h->nodes[bad].c0 >= tp.c0 && h->nodes[bad].c0 < tp.c1) { first = t; break; }
         }
         h->leaf_robust[bad] = 1;
-        static const int restart_env = []() { const char* e = getenv("MPQR_RESTART"); return e ? atoi(e) : 1; }();   // 0: every pass from block 0 (round 2)
-        start = restart_env ? first : 0;
+        start = first;
         if (pass >= 15) { h->robust = true; start = 0; }    // (16 repaired leaves: the matrix is better served by the robust kernels everywhere)
     }
     h->n_gh_leaves = gh_total;

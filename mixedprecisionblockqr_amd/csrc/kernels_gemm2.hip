@@ -772,8 +772,7 @@ bool launch_gemm2_f16(AMode am, EMode em, const GemmArgs& g, hipStream_t s, int 
         return false;
     }
     if (am == A_H16 && config != 2 && config != 1) {          // config 2 keeps the register-staged kernel (A/B comparison)
-        static const int use6 = []() { const char* e = getenv("MPQR_GEMM6"); return e ? atoi(e) : 1; }();
-        if (use6 && (g.K % 64) == 0) {
+        if ((g.K % 64) == 0) {
             if (em == E_SUB_F32) { launch6<E_SUB_F32, 1>(g, s); return true; }
             // store epilogues (X = Q2^T V, W = V T, Q = I - W V^T, Y = X T): v_mfma_f32_16x16x32_f16 -- on random operands the chip holds
             // 1.87 GHz on this shape against 1.60 on 32x32x16 (tools/ubench_mfma.hip: 1900 vs 1550 TFLOP/s from registers); in this
