@@ -132,6 +132,7 @@ struct mpqr_handle_s {
     bool rest_in_solve = false;   // ... and the gh_solve launched last polls it at its end (no event wait in front of the next launch)
     int rest_first_cols = 0;      // apply_node, lane 2: the update's first this-many columns as a launch of their own, ev_rest recorded behind it
     bool rest_recorded = false;   // ... done: the caller does not record ev_rest again
+    bool q_all_ident = false;     // apply_node, Q formation: the matrix the node is applied to is still the identity (the first apply)
     int lane2_twait = 0;          // apply_node, lane 2: wait for this value of the chain's T word in front of Y = X T (0: nothing to wait for)
     int* tflag = nullptr;         // device word the chain publishes its progress in (leaf_xt_kernel / leaf_b_kernel), polled by the T stream (wait_flag_kernel)
     int tseq = 0, xt_pub = 0;     // last published value; value the next leaf_xt launch of apply_node is to publish (0: none)
@@ -469,6 +470,10 @@ void apply_node(mpqr_handle_t h, const Node& nd, float* C, long ldc, int clo, in
     static const int qsplit = []() { const char* e = getenv("MPQR_QSPLIT"); return e ? atoi(e) : 0; }();
     const bool q_apply = h->shadow && lane == 0 && !far;
     half_t* const Xlo = (xsplit && (!q_apply || qsplit)) ? (lane == 1 ? h->Xl1 : lane == 2 ? nullptr : h->Xl) : nullptr;
+    // Q formation's first applies are small (2048^2, 4096^2 at 16384^2: 64 / 128 tiles of 256^2): split-K sent them to the 128-tile kernel
+    // with fp32 slabs and Y = X T' to the fp32-staging kernel -- 265 + 400 us for 40 + 160 us of GEMM work (tools/trace_q.sh).  One K range on
+    // the 256-tile kernels instead, even with half the CUs idle.
+    if (q_apply && Xhi && g1.nsplit > 1 && M1 >= 256 && Kr >= 256 && (Kr % 64) == 0 && (long)(M1 / 256) * (Kr / 256) >= gemm2_min_tiles()) g1.nsplit = 1;
     const bool x16 = x16_env && Xhi && (!xsplit || Xlo || q_apply) && !f8 && g1.nsplit == 1 && M1 >= 256 && Kr >= 256 && (Kr % 64) == 0 &&
                      (long)(M1 / 256) * (Kr / 256) >= gemm2_min_tiles() && h->opts.precision != MPQR_PREC_FP32;
     // one leaf (128 reflectors) onto a few columns: slab sum and Y = X T' in one small kernel (leaf_xt_kernel)
@@ -504,6 +509,15 @@ void apply_node(mpqr_handle_t h, const Node& nd, float* C, long ldc, int clo, in
             // X = Q2^T V are rows of V (exact in fp16): copied, and the GEMM starts behind them
             const int idc = (h->q_ident_cols > 0 && clo == clo_al && nd.a0 == nd.c0 && rlo == nd.c0 && clo == nd.c0) ?
                             std::min({h->q_ident_cols, M1 - 256, (nd.c1 - nd.c0) / 256 * 256}) : 0;
+            bool x_done = false;
+            if (h->q_all_ident && clo == clo_al && nd.a0 == nd.c0 && rlo == nd.c0 && clo == nd.c0) {
+                // the FIRST apply of Q formation: Q2 = I, so X = Q2^T V = V, exact in fp16 -- a copy, no GEMM
+                HIPQ(h, hipMemcpy2DAsync(Xhi, (size_t)Kr * sizeof(half_t), h->Vh + (long)nd.c0 * h->ldvh + nd.a0, h->ldvh * sizeof(half_t),
+                                       (size_t)Kr * sizeof(half_t), M1, hipMemcpyDeviceToDevice, st1));
+                if (Xlo) HIPQ(h, hipMemsetAsync(Xlo, 0, (size_t)M1 * Kr * sizeof(half_t), st1));
+                h->n_q_ident_rows += M1;
+                g1.M = 0; x_done = true;
+            } else
             if (idc >= 256 && (long)((M1 - idc) / 256) * (Kr / 256) >= gemm2_min_tiles()) {   // (the rest still goes to the 256-wide kernel)
                 HIPQ(h, hipMemcpy2DAsync(Xhi, (size_t)Kr * sizeof(half_t), h->Vh + (long)nd.c0 * h->ldvh + nd.a0, h->ldvh * sizeof(half_t),
                                        (size_t)Kr * sizeof(half_t), idc, hipMemcpyDeviceToDevice, st1));
@@ -518,7 +532,7 @@ void apply_node(mpqr_handle_t h, const Node& nd, float* C, long ldc, int clo, in
                     g1.A = (const half_t*)g1.A + idc; g1.Bt += idc; g1.K = Kw - idc;
                 }
             }
-            gemm_dispatch(A_H16, E_STORE_H16, g1, st1);
+            if (!x_done) gemm_dispatch(A_H16, E_STORE_H16, g1, st1);
         }
         else gemm_dispatch(A_H16, E_STORE_F32, g1, st1);
     } else if (x16) {
@@ -1267,21 +1281,24 @@ int form_q(mpqr_handle_t h) {
     const bool rec = h->world == 1 && h->factored;        // timed like the far updates (mpqr_get_timings: ms_q_*)
     h->n_q_ident_rows = 0;
     h->q_first = rec ? h->far_used : (size_t)-1;
+    bool first = h->shadow != nullptr;                    // (Q = I and, with the shadow, Qt = I: init_q)
     for (int t = (int)h->tops.size() - 1; t >= 0; t--) {
         if (h->pairs_ready && t < (int)h->qpair.size() && h->qpair[t] >= 0) {      // two blocks at once, K = 2 outer_block
             const Node& pr = h->nodes[h->qpair[t]];
             h->shadow_write = t - 1 > 0;                    // nobody reads the shadow after the last apply
             h->q_ident_cols = pr.c1 - pr.c0;
+            h->q_all_ident = first; first = false;
             apply_node(h, pr, h->dQ, h->ldq, pr.c0, h->m, false, 1.f, rec);
-            h->q_ident_cols = 0;
+            h->q_ident_cols = 0; h->q_all_ident = false;
             t--;
             continue;
         }
         const Node& nd = h->nodes[h->tops[t]];
         h->shadow_write = t > 0;
         h->q_ident_cols = nd.c1 - nd.c0;
+        h->q_all_ident = first; first = false;
         apply_node(h, nd, h->dQ, h->ldq, nd.c0, h->m, false, 1.f, rec);
-        h->q_ident_cols = 0;
+        h->q_ident_cols = 0; h->q_all_ident = false;
     }
     h->shadow = nullptr;
     h->q_formed = true;

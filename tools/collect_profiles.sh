@@ -35,6 +35,7 @@ python3 bench.py --config c5 --precision fp16 --no-cpu-baseline --steps 3 --warm
 MPQR_FORCE_DIST=1 python3 bench.py --no-cpu-baseline > $out/${tag}_c4_forced_dist_n1_bench.json 2> $out/bench_dist.err && echo "bench forced dist ok"
 python3 -m pytest tests/test_gpu_parity.py -q -m gpu -s -k "rank_deficient or flagged" 2>&1 | grep -E "ratio|passed|failed" > $out/${tag}_restart_cost.txt && echo "restart cost ok"
 MPQR_DBG_BLOCKS=1 python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-dropin --no-alone 2>&1 | grep "mpqr:" > $out/${tag}_c4_blocks_unprofiled.txt && echo "blocks ok"
+MPQR_DBG_STAMPS=1 python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-dropin --no-alone 2>&1 | grep "mpqr:" > $out/${tag}_c4_leaf_stamps.txt && echo "stamps ok"
 python3 tools/bench_gemm.py > $out/${tag}_gemm_alone.txt 2>&1 && echo "gemm alone ok"
 [ -x tools/ubench_mfma.bin ] && ./tools/ubench_mfma.bin > $out/${tag}_mfma_ubench.txt 2>&1 && echo "mfma ubench ok"
 python3 tools/precision_study.py $out/${tag}_precision_study.md > /dev/null 2>&1 && echo "precision study ok"

@@ -35,6 +35,12 @@ for r in q:
     d[n] += r['e'] - r['s']; c[n] += 1
 for k, v in d.most_common():
     print("  %-60s %4d %8.3f ms" % (k, c[k], v / 1e6))
+show_all = len(sys.argv) > 2 and sys.argv[2] == '--all'      # every dispatch with the idle time in front of it
+prev = t0
 for r in q:
+    if show_all:
+        print("   %+9.1f us %8.1f us  gap %6.1f  q%s %s" % ((r['s'] - t0) / 1e3, (r['e'] - r['s']) / 1e3, (r['s'] - prev) / 1e3, r['Queue_Id'], re.sub(r'^void ', '', r['Kernel_Name']).replace('mpqr::', '')[:70]))
+        prev = max(prev, r['e'])
+        continue
     if (r['e'] - r['s']) > 2e5:
         print("   %+9.1f us %8.1f us  %s" % ((r['s'] - t0) / 1e3, (r['e'] - r['s']) / 1e3, re.sub(r'^void ', '', r['Kernel_Name'])[:50]))
