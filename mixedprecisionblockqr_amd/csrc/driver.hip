@@ -132,6 +132,9 @@ struct mpqr_handle_s {
     bool rest_in_solve = false;   // ... and the gh_solve launched last polls it at its end (no event wait in front of the next launch)
     int rest_first_cols = 0;      // apply_node, lane 2: the update's first this-many columns as a launch of their own, ev_rest recorded behind it
     bool rest_recorded = false;   // ... done: the caller does not record ev_rest again
+    half_t* Wq = nullptr;         // Q formation: W = V T of every block pair ([rows from the pair's first 64-aligned row][K], fp16), left by merge_pair
+    std::vector<long> wq_off;     // ... offset by node id, -1: none
+    bool defer_pair_w = false;    // merge_pair leaves W = V T to its caller (run_block_loop: a block later, where the far stream has room)
     bool q_all_ident = false;     // apply_node, Q formation: the matrix the node is applied to is still the identity (the first apply)
     int lane2_twait = 0;          // apply_node, lane 2: wait for this value of the chain's T word in front of Y = X T (0: nothing to wait for)
     int* tflag = nullptr;         // device word the chain publishes its progress in (leaf_xt_kernel / leaf_b_kernel), polled by the T stream (wait_flag_kernel)
@@ -261,7 +264,7 @@ void free_plan(mpqr_handle_t h) {
     void* ptrs[] = {h->dA, h->dA0, h->dQ, h->Vh, h->Vt, h->vdiag, h->Xt, h->Yt, h->S, h->P, h->tmp1, h->tmp2,
                     h->Tf, h->Th, h->Tth, h->dstage, h->Gp, h->Gs, h->Cv, h->dflag, h->Vf, h->Yf, h->Xt1, h->Yt1, h->Sp,
                     h->rbTf, h->rbTh, h->rbTth, h->Sleaf, h->mid_counter, h->tflag, h->V8n, h->V8t, h->A8t, h->Y8, h->Xt2, h->Yt2, h->Xp, h->Xs, h->Yfl,
-                    h->S2, h->tmp1b, h->tmp2b, h->Qt, h->At, h->Xh, h->Wh, h->Xl, h->Xh1, h->Xl1};
+                    h->S2, h->tmp1b, h->tmp2b, h->Qt, h->At, h->Xh, h->Wh, h->Xl, h->Xh1, h->Xl1, h->Wq};
     for (void* p : ptrs) if (p) MPQR_IGNORE(hipFree(p));
     if (h->hflag_host) MPQR_IGNORE(hipHostFree(h->hflag_host));
     if (h->dbg_stamps) { MPQR_IGNORE(hipHostFree(h->dbg_stamps)); h->dbg_stamps = nullptr; h->dbg_stamps_n = 0; }
@@ -271,7 +274,7 @@ void free_plan(mpqr_handle_t h) {
     h->S = nullptr; h->P = nullptr; h->tmp1 = h->tmp2 = nullptr; h->Tf = nullptr; h->Th = h->Tth = nullptr;
     h->dstage = nullptr; h->stage_elems = 0;
     h->Gp = nullptr; h->Gs = nullptr; h->Cv = nullptr; h->dflag = nullptr; h->Vf = nullptr; h->Yf = nullptr;
-    h->Xt1 = nullptr; h->Yt1 = nullptr; h->Sp = nullptr; h->Xt2 = nullptr; h->Yt2 = nullptr; h->xt2_elems = 0;
+    h->Xt1 = nullptr; h->Yt1 = nullptr; h->Wq = nullptr; h->wq_off.clear(); h->Sp = nullptr; h->Xt2 = nullptr; h->Yt2 = nullptr; h->xt2_elems = 0;
     h->rbTf = nullptr; h->rbTh = h->rbTth = nullptr; h->rb_elems = 0; h->nflag = 0; h->leaf_robust.clear(); h->Sleaf = nullptr; h->mid_counter = nullptr; h->tflag = nullptr; h->Xp = nullptr; h->Xs = nullptr; h->Yfl = nullptr; h->gram_ready_c0 = -1;
     h->V8n = h->V8t = h->A8t = h->Y8 = nullptr; h->v8_node = -1;
     for (hipEvent_t e : h->chain_ev) MPQR_IGNORE(hipEventDestroy(e));
@@ -560,6 +563,8 @@ void apply_node(mpqr_handle_t h, const Node& nd, float* C, long ldc, int clo, in
         launch_wait_flag(h->tflag, h->lane2_twait, h->hflag_dev + h->flag_words - 1, h->tpoll_ticks, st, 0);
         h->lane2_twait = 0;
     }
+    const bool use_w = q_apply && x16 && !Xlo && !trans_t && h->Wq && nd.id >= 0 && nd.id < (int)h->wq_off.size() && h->wq_off[nd.id] >= 0 &&
+                       nd.a0 == nd.c0 && !fuse_xt;
     // op2: Yt[M1 x Kr] = fp16( Xt * T' ) -- the first use of T: it was built on the T stream beside op1
     if (st1 == st && h->tq_on && nd.id >= 0 && nd.id < (int)h->ev_T.size()) HIPQ(h, hipStreamWaitEvent(st, h->ev_T[nd.id], 0));
     GemmArgs g2{};
@@ -574,6 +579,7 @@ void apply_node(mpqr_handle_t h, const Node& nd, float* C, long ldc, int clo, in
         launch_leaf_xt(Xt, g1.nsplit, slab, M1, g2.Bt, g2.ldb, g2.tri, Yt, Kr, g2.cscale, g2.cscale_ld, st, h->xt_pub ? h->tflag : nullptr, h->xt_pub);
         h->xt_pub = 0;
     }
+    else if (use_w) { /* Q formation with W = V T at hand: Q2 -= W X^T below, no Y */ }
     else if (x16) { g2.A = Xhi; g2.A2 = Xlo; gemm_dispatch(A_H16, E_STORE_H16, g2, st); }
     else
     gemm_dispatch(A_F32S, E_STORE_H16, g2, st);
@@ -584,6 +590,7 @@ void apply_node(mpqr_handle_t h, const Node& nd, float* C, long ldc, int clo, in
     g3.C = C + (long)rlo * ldc + clo_al; g3.ldc = ldc;
     g3.M = Kw; g3.N = M1; g3.K = Kr;
     g3.col_lo = clo - clo_al; g3.alpha = 1.0f / in_scale; g3.in_scale = 1.f; g3.nsplit = 1;
+    if (use_w) { g3.A = h->Wq + h->wq_off[nd.id]; g3.lda = Kr; g3.Bt = Xhi; }
     if (a_shadow) { g3.Ct = h->At + (long)clo_al * h->ldat + rlo; g3.ldct = h->ldat; g3.ct_scale = in_scale; }
     {   // Far updates and Q formation stream their C tiles (and the fp16 shadow) once per launch, ~2 GB each: read and written with the
         // non-temporal cache policy they leave the chain's working set (panel columns, V, X, T) in the caches.  16384^2: far nn
@@ -1159,6 +1166,7 @@ int compute_scale(mpqr_handle_t h, const float* src, float* copy_to = nullptr) {
 }
 
 // T of a pair of top-level blocks from its children's: T_LR = -T_L (V_L^T V_R) T_R  (enqueued on `st`, own scratch)
+static void pair_w(mpqr_handle_t h, int pid, hipStream_t st);
 static void merge_pair(mpqr_handle_t h, int pid, hipStream_t st) {
     Range rg("mpqr:wy_T_pair");
     const Node nd = h->nodes[pid];
@@ -1189,6 +1197,22 @@ static void merge_pair(mpqr_handle_t h, int pid, hipStream_t st) {
     launch_t_assemble(h->Tf + nd.toff, h->Th + nd.toff, h->Tth + nd.toff, nd.ldt, nd.a0, h->Tf + L.toff, L.ldt, L.a0,
                       nd.c0, L.c1, h->Tf + R.toff, R.ldt, R.a0, nd.c1, h->tmp2b, R.ldt, st, nz, zs);
     if (h->tq_on && nd.id < (int)h->ev_T.size()) HIPQ(h, hipEventRecord(h->ev_T[nd.id], st));
+    if (!h->defer_pair_w) pair_w(h, pid, st);
+}
+
+// W[rows x K] = V T of a block pair for Q formation (T upper triangular, the fp16 T has a unit diagonal: column n of the product takes tau_n)
+static void pair_w(mpqr_handle_t h, int pid, hipStream_t st) {
+    const Node nd = h->nodes[pid];
+    if (h->Wq && pid < (int)h->wq_off.size() && h->wq_off[pid] >= 0 && nd.a0 == nd.c0) {
+        const int rlo = rdown(nd.c0, 64);
+        GemmArgs w{};
+        w.A = h->Vh + (long)rlo * h->ldvh + nd.a0; w.lda = h->ldvh;
+        w.Bt = h->Tth + nd.toff; w.ldb = nd.tld;
+        w.C = h->Wq + h->wq_off[pid]; w.ldc = nd.ldt;
+        w.M = h->m_pad - rlo; w.N = nd.ldt; w.K = nd.ldt; w.alpha = 1.f; w.in_scale = 1.f; w.nsplit = 1; w.tri = 2;
+        w.cscale = h->Tf + nd.toff; w.cscale_ld = (long)nd.tld + 1;
+        gemm_dispatch(A_H16, E_STORE_H16, w, st);
+    }
 }
 
 // prefix step: T of blocks 0..k from T of blocks 0..k-1 (in place, leading block of the same arena) and T of block k
@@ -1634,6 +1658,22 @@ static int plan_common(mpqr_handle_t h, int m, int n, int r, const mpqr_opts* op
         if (o.form_q && o.precision != MPQR_PREC_FP32 && h->qroot < 0) {
             h->ldqt = h->m_pad;                             // one row per LOCAL column of Q (all of them on a single GPU)
             if ((rc = dalloc(h, &h->Qt, (size_t)(h->ldq + 256) * h->ldqt))) return rc;
+            // W = V T of every block pair, formed behind the pair's T on the far stream (merge_pair): Q formation's apply is then
+            // X = Q2^T V and Q2 -= W X^T, without the Y = X T^T GEMM between them (0.8 ms of the 7.2 at 16384^2)
+            static const int wq_on = []() { const char* e = getenv("MPQR_QW"); return e ? atoi(e) : 1; }();
+            if (wq_on && world == 1) {
+                h->wq_off.assign(h->nodes.size(), -1);
+                size_t tot = 0;
+                for (int pid : h->qpair) if (pid >= 0) {
+                    const Node& pr = h->nodes[pid];
+                    h->wq_off[pid] = (long)tot;
+                    tot += (size_t)(h->m_pad - rdown(pr.c0, 64) + 256) * pr.ldt;
+                }
+                if (tot > 0) {
+                    if ((rc = dalloc(h, &h->Wq, tot))) return rc;
+                    HIPCHK(h, hipMemsetAsync(h->Wq, 0, tot * sizeof(half_t), h->s0));
+                } else h->wq_off.clear();
+            }
 
         }
     }
@@ -1835,6 +1875,11 @@ static int run_block_loop(mpqr_handle_t h, int start = 0) {
         apply_node(h, h->nodes[half_b.node], h->dA, h->lda, half_b.lo, half_b.hi, true, h->a_scale, true, 1, true);
         half_b.node = -1;
     };
+    // W = V T of a pair (Q formation) is not urgent: it goes out behind the NEXT block's far update, where the far stream has room -- in
+    // front of the pair's own update it pushed that update into the next block's part (a) (ms_panel + 0.7 ms)
+    int pending_w = -1;
+    h->defer_pair_w = la;
+    auto flush_w = [&]() { if (pending_w >= 0) { pair_w(h, pending_w, h->s1); pending_w = -1; } };
     auto far_update = [&](size_t t) -> int {
         const Node nd = h->nodes[h->tops[t]];
         Range rg("mpqr:far_update");
@@ -1862,6 +1907,7 @@ static int run_block_loop(mpqr_handle_t h, int start = 0) {
                 // odd block: the pair (t-1, t) onto everything neither of them has reached yet
                 flush_half_b();                             // (cannot be pending here: the even block between took it)
                 merge_pair(h, h->qpair[t], h->s1); pair_merged = true;
+                flush_w(); pending_w = h->qpair[t];
                 h->at_read = t >= 3;                        // the first pair's columns have not been written by a far update yet
                 // first half: at least everything the next block's far update touches (its part (a) and extra columns end at cfirst[t + 4])
                 int mid = h->n;
@@ -1877,8 +1923,9 @@ static int run_block_loop(mpqr_handle_t h, int start = 0) {
             apply_node(h, nd, h->dA, h->lda, a_end, h->n, true, h->a_scale, true, 1, true);       // ... the rest overlaps its panels
         }
         if ((t % 2) == 0 || t + 1 >= nt) flush_half_b();       // (an even block that took another branch; the last block)
+        if ((t % 2) == 0 || t + 1 >= nt) flush_w();
         // Q formation works on pairs of blocks: the pair's T behind this block's far update, beside the next panels
-        if (h->opts.form_q && h->qpair[t] >= 0 && h->S2 && !pair_merged) merge_pair(h, h->qpair[t], h->s1);
+        if (h->opts.form_q && h->qpair[t] >= 0 && h->S2 && !pair_merged) { merge_pair(h, h->qpair[t], h->s1); flush_w(); pending_w = h->qpair[t]; if (t + 1 >= nt) flush_w(); }
         pair_merged = false;
         if (h->opts.form_q && h->qroot >= 0) for (int id : h->qmerge_after[t]) merge_prefix(h, id, h->s1);   // ... or the T of all blocks so far
         return MPQR_OK;
@@ -1927,6 +1974,8 @@ static int run_block_loop(mpqr_handle_t h, int start = 0) {
         if ((rc = far_update(t))) { h->defer_join = false; h->watch_flags = false; return rc; }
     }
     if (!aborted) flush_half_b();                           // (every far_update has run; nothing can be pending)
+    flush_w();                                              // (also of an aborted pass: the pair's T stays valid when the restart begins behind it)
+    h->defer_pair_w = false;
     h->watch_flags = false; h->pass_aborted = aborted; h->pre_leaves = 0; h->cur_block = 0;
     h->pairs_ready = !aborted && h->opts.form_q && h->S2 != nullptr;     // (pairs or the whole tree)
     if (h->defer_join) {                                    // the T stream's work of every block, once

@@ -917,6 +917,7 @@ OPT_IN = [
     {"MPQR_MFMA16": "0"},                          # store-epilogue GEMMs on v_mfma_f32_32x32x16_f16 (round 3) instead of 16x16x32
     {"MPQR_EXT_LOOKAHEAD": "0"},                   # block boundary: first leaf of the next block through the far update
     {"MPQR_QSPLIT": "1"},                          # hi + lo parts of X in Q formation as well
+    {"MPQR_QW": "0"},                              # Q formation with Y = X T^T per apply instead of the pair's W = V T from the far stream
     {"MPQR_ASHADOW": "0"},                         # far X = A2^T V from the fp32 matrix (converted + transposed while staged: round 3 default)
     {"MPQR_EXT_LEAVES": "1"},                      # block boundary: the in-block updates reach ONE leaf of the next block (round 2)
     {"MPQR_TPOLL": "0"},                           # the T stream follows the chain through an event instead of polling the word leaf_xt publishes
