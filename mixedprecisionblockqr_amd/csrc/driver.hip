@@ -134,6 +134,7 @@ struct mpqr_handle_s {
     bool rest_recorded = false;   // ... done: the caller does not record ev_rest again
     half_t* Wq = nullptr;         // Q formation: W = V T of every block pair ([rows from the pair's first 64-aligned row][K], fp16), left by merge_pair
     std::vector<long> wq_off;     // ... offset by node id, -1: none
+    std::vector<char> wq_ready;   // ... W of this node matches its current T (set by pair_w, cleared by merge_pair)
     bool defer_pair_w = false;    // merge_pair leaves W = V T to its caller (run_block_loop: a block later, where the far stream has room)
     bool q_all_ident = false;     // apply_node, Q formation: the matrix the node is applied to is still the identity (the first apply)
     int lane2_twait = 0;          // apply_node, lane 2: wait for this value of the chain's T word in front of Y = X T (0: nothing to wait for)
@@ -274,7 +275,7 @@ void free_plan(mpqr_handle_t h) {
     h->S = nullptr; h->P = nullptr; h->tmp1 = h->tmp2 = nullptr; h->Tf = nullptr; h->Th = h->Tth = nullptr;
     h->dstage = nullptr; h->stage_elems = 0;
     h->Gp = nullptr; h->Gs = nullptr; h->Cv = nullptr; h->dflag = nullptr; h->Vf = nullptr; h->Yf = nullptr;
-    h->Xt1 = nullptr; h->Yt1 = nullptr; h->Wq = nullptr; h->wq_off.clear(); h->Sp = nullptr; h->Xt2 = nullptr; h->Yt2 = nullptr; h->xt2_elems = 0;
+    h->Xt1 = nullptr; h->Yt1 = nullptr; h->Wq = nullptr; h->wq_off.clear(); h->wq_ready.clear(); h->Sp = nullptr; h->Xt2 = nullptr; h->Yt2 = nullptr; h->xt2_elems = 0;
     h->rbTf = nullptr; h->rbTh = h->rbTth = nullptr; h->rb_elems = 0; h->nflag = 0; h->leaf_robust.clear(); h->Sleaf = nullptr; h->mid_counter = nullptr; h->tflag = nullptr; h->Xp = nullptr; h->Xs = nullptr; h->Yfl = nullptr; h->gram_ready_c0 = -1;
     h->V8n = h->V8t = h->A8t = h->Y8 = nullptr; h->v8_node = -1;
     for (hipEvent_t e : h->chain_ev) MPQR_IGNORE(hipEventDestroy(e));
@@ -564,7 +565,7 @@ void apply_node(mpqr_handle_t h, const Node& nd, float* C, long ldc, int clo, in
         h->lane2_twait = 0;
     }
     const bool use_w = q_apply && x16 && !Xlo && !trans_t && h->Wq && nd.id >= 0 && nd.id < (int)h->wq_off.size() && h->wq_off[nd.id] >= 0 &&
-                       nd.a0 == nd.c0 && !fuse_xt;
+                       h->wq_ready[nd.id] && nd.a0 == nd.c0 && !fuse_xt;
     // op2: Yt[M1 x Kr] = fp16( Xt * T' ) -- the first use of T: it was built on the T stream beside op1
     if (st1 == st && h->tq_on && nd.id >= 0 && nd.id < (int)h->ev_T.size()) HIPQ(h, hipStreamWaitEvent(st, h->ev_T[nd.id], 0));
     GemmArgs g2{};
@@ -1197,6 +1198,7 @@ static void merge_pair(mpqr_handle_t h, int pid, hipStream_t st) {
     launch_t_assemble(h->Tf + nd.toff, h->Th + nd.toff, h->Tth + nd.toff, nd.ldt, nd.a0, h->Tf + L.toff, L.ldt, L.a0,
                       nd.c0, L.c1, h->Tf + R.toff, R.ldt, R.a0, nd.c1, h->tmp2b, R.ldt, st, nz, zs);
     if (h->tq_on && nd.id < (int)h->ev_T.size()) HIPQ(h, hipEventRecord(h->ev_T[nd.id], st));
+    if (pid < (int)h->wq_ready.size()) h->wq_ready[pid] = 0;      // (a new T: the W of an earlier pass no longer matches)
     if (!h->defer_pair_w) pair_w(h, pid, st);
 }
 
@@ -1212,6 +1214,7 @@ static void pair_w(mpqr_handle_t h, int pid, hipStream_t st) {
         w.M = h->m_pad - rlo; w.N = nd.ldt; w.K = nd.ldt; w.alpha = 1.f; w.in_scale = 1.f; w.nsplit = 1; w.tri = 2;
         w.cscale = h->Tf + nd.toff; w.cscale_ld = (long)nd.tld + 1;
         gemm_dispatch(A_H16, E_STORE_H16, w, st);
+        h->wq_ready[pid] = 1;
     }
 }
 
@@ -1662,7 +1665,7 @@ static int plan_common(mpqr_handle_t h, int m, int n, int r, const mpqr_opts* op
             // X = Q2^T V and Q2 -= W X^T, without the Y = X T^T GEMM between them (0.8 ms of the 7.2 at 16384^2)
             static const int wq_on = []() { const char* e = getenv("MPQR_QW"); return e ? atoi(e) : 1; }();
             if (wq_on && world == 1) {
-                h->wq_off.assign(h->nodes.size(), -1);
+                h->wq_off.assign(h->nodes.size(), -1); h->wq_ready.assign(h->nodes.size(), 0);
                 size_t tot = 0;
                 for (int pid : h->qpair) if (pid >= 0) {
                     const Node& pr = h->nodes[pid];
@@ -1907,7 +1910,7 @@ static int run_block_loop(mpqr_handle_t h, int start = 0) {
                 // odd block: the pair (t-1, t) onto everything neither of them has reached yet
                 flush_half_b();                             // (cannot be pending here: the even block between took it)
                 merge_pair(h, h->qpair[t], h->s1); pair_merged = true;
-                flush_w(); pending_w = h->qpair[t];
+                flush_w(); if (t + 1 < nt) pending_w = h->qpair[t];
                 h->at_read = t >= 3;                        // the first pair's columns have not been written by a far update yet
                 // first half: at least everything the next block's far update touches (its part (a) and extra columns end at cfirst[t + 4])
                 int mid = h->n;
@@ -1925,7 +1928,9 @@ static int run_block_loop(mpqr_handle_t h, int start = 0) {
         if ((t % 2) == 0 || t + 1 >= nt) flush_half_b();       // (an even block that took another branch; the last block)
         if ((t % 2) == 0 || t + 1 >= nt) flush_w();
         // Q formation works on pairs of blocks: the pair's T behind this block's far update, beside the next panels
-        if (h->opts.form_q && h->qpair[t] >= 0 && h->S2 && !pair_merged) { merge_pair(h, h->qpair[t], h->s1); flush_w(); pending_w = h->qpair[t]; if (t + 1 >= nt) flush_w(); }
+        // (the LAST pair gets no W: its product would sit between the chain's end and Q formation's first apply, where Y = X T^T of a
+        //  2048-column apply is cheaper -- and a matrix of one pair keeps the arithmetic of rounds 1 - 4)
+        if (h->opts.form_q && h->qpair[t] >= 0 && h->S2 && !pair_merged) { merge_pair(h, h->qpair[t], h->s1); flush_w(); if (t + 1 < nt) pending_w = h->qpair[t]; }
         pair_merged = false;
         if (h->opts.form_q && h->qroot >= 0) for (int id : h->qmerge_after[t]) merge_prefix(h, id, h->s1);   // ... or the T of all blocks so far
         return MPQR_OK;
