@@ -135,6 +135,12 @@ struct mpqr_handle_s {
     half_t* Wq = nullptr;         // Q formation: W = V T of every block pair ([rows from the pair's first 64-aligned row][K], fp16), left by merge_pair
     std::vector<long> wq_off;     // ... offset by node id, -1: none
     std::vector<char> wq_ready;   // ... W of this node matches its current T (set by pair_w, cleared by merge_pair)
+    // drop-in call (mpqr_block_qr_f32): finished rows of the packed factor go to the caller's buffer while the factorisation is still running
+    float* stream_out = nullptr;  // host (m+1) x n image, or nullptr
+    std::vector<hipEvent_t> ev_rows;   // per top-level block t: recorded on the far stream behind far update t
+    std::vector<char> rows_rec;        // ... recorded in this pass
+    int rows_streamed = 0;             // packed rows [0, rows_streamed) are in the caller's buffer ...
+    bool rows_valid = false;           // ... and still describe the result (single pass, no retry)
     bool defer_pair_w = false;    // merge_pair leaves W = V T to its caller (run_block_loop: a block later, where the far stream has room)
     bool q_all_ident = false;     // apply_node, Q formation: the matrix the node is applied to is still the identity (the first apply)
     int lane2_twait = 0;          // apply_node, lane 2: wait for this value of the chain's T word in front of Y = X T (0: nothing to wait for)
@@ -1435,6 +1441,7 @@ int mpqr_destroy(mpqr_handle_t h) {
     if (h->dscalar) MPQR_IGNORE(hipFree(h->dscalar));
     for (int i = 0; i < 4; i++) if (h->ev[i]) MPQR_IGNORE(hipEventDestroy(h->ev[i]));
     for (hipEvent_t e : h->ev_T) MPQR_IGNORE(hipEventDestroy(e));
+    for (hipEvent_t e : h->ev_rows) MPQR_IGNORE(hipEventDestroy(e));
     if (h->ev_v) MPQR_IGNORE(hipEventDestroy(h->ev_v));
     if (h->ev_join) MPQR_IGNORE(hipEventDestroy(h->ev_join));
     if (h->sD) MPQR_IGNORE(hipStreamDestroy(h->sD));
@@ -1781,6 +1788,7 @@ static int run_block_loop(mpqr_handle_t h, int start = 0) {
     h->v8_node = -1;
     h->gram_ready_c0 = -1; h->lane2_twait = 0; h->rest_pending = false; h->rest_in_solve = false; h->rest_split = false; h->next_block_flat = false;
     if (start <= 0) h->n_fused_leaves = 0;
+    if (h->stream_out) { h->rows_rec.assign(h->tops.size(), 0); if (start > 0) h->rows_valid = false; }
     h->pairs_ready = false; h->q_first = (size_t)-1;
     const auto host_t0 = std::chrono::steady_clock::now();  // host time to enqueue the block loop (ms_host_enqueue)
     if (start > 0 && (size_t)start < h->far_mark.size()) {
@@ -1933,6 +1941,10 @@ static int run_block_loop(mpqr_handle_t h, int start = 0) {
         if (h->opts.form_q && h->qpair[t] >= 0 && h->S2 && !pair_merged) { merge_pair(h, h->qpair[t], h->s1); flush_w(); if (t + 1 < nt) pending_w = h->qpair[t]; }
         pair_merged = false;
         if (h->opts.form_q && h->qroot >= 0) for (int id : h->qmerge_after[t]) merge_prefix(h, id, h->s1);   // ... or the T of all blocks so far
+        if (h->stream_out && start == 0 && t < h->ev_rows.size()) {              // (the rows of block t-2 are final behind this: stream_rows)
+            HIPCHK(h, hipEventRecord(h->ev_rows[t], h->s1));
+            h->rows_rec[t] = 1;
+        }
         return MPQR_OK;
     };
     for (size_t t = (size_t)start; t < nt; t++) {
@@ -1998,6 +2010,44 @@ static int run_block_loop(mpqr_handle_t h, int start = 0) {
     return MPQR_OK;                                         // nothing is synchronised here: mpqr_factor waits for ev[1] AFTER it has enqueued Q formation
 }
 
+// Drop-in call: packed rows of finished blocks to the caller's buffer while the rest of the factorisation and Q formation run.  Called by
+// mpqr_factor's first pass when everything is enqueued and the host would only wait.  The rows of block b are final behind far update b + 2
+// (its own pair's second half goes out with that one; later blocks touch later rows only); behind the block loop everything is.  A D2H copy
+// to pageable memory blocks this thread, which has nothing else to do.  If the pass turns out flagged or timed out, the repair passes change
+// far columns of finished rows at rounding level: rows_valid is dropped and the caller copies everything again.
+static int stream_rows(mpqr_handle_t h) {
+    const int nt = (int)h->tops.size();
+    h->rows_streamed = 0; h->rows_valid = false;
+    if (!h->sD || !h->dstage || h->pass_aborted || h->stage_elems < (size_t)(h->m + 1) * h->n) return MPQR_OK;
+    auto rows_out = [&](int r1) -> int {
+        const int r0 = h->rows_streamed;
+        if (r1 <= r0) return MPQR_OK;
+        launch_pack_factor_rows(h->dA, h->lda, h->vdiag, h->dstage, h->m, h->n, r0, r1, h->sD);
+        HIPCHK(h, hipMemcpyAsync(h->stream_out + (size_t)r0 * h->n, h->dstage + (size_t)r0 * h->n, (size_t)(r1 - r0) * h->n * sizeof(float),
+                                 hipMemcpyDeviceToHost, h->sD));
+        HIPCHK(h, hipStreamSynchronize(h->sD));
+        h->rows_streamed = r1;
+        return MPQR_OK;
+    };
+    auto pass_unusable = [&]() {                           // leaf flags, or the T stream's time-out word (not the deflated-columns count)
+        return flag_words_set(h, h->flag_words - 2) ||
+               (h->hflag_host && h->flag_words > 0 && __atomic_load_n(h->hflag_host + h->flag_words - 1, __ATOMIC_RELAXED) != 0);
+    };
+    int rc;
+    for (int b = 0; b + 2 < nt; b++) {
+        if (!h->rows_rec[b + 2]) break;
+        HIPCHK(h, hipEventSynchronize(h->ev_rows[b + 2]));
+        if (pass_unusable()) return MPQR_OK;                         // a flagged leaf or a timed-out wait: this pass will not be kept
+        // (packed row r holds row r of R and row r - 1 of the reflectors: up to the block's last row)
+        if ((rc = rows_out(std::min(h->nodes[h->tops[b]].c1, h->m)))) return rc;
+    }
+    HIPCHK(h, hipEventSynchronize(h->ev[1]));              // the block loop is done (Q formation goes on)
+    if (pass_unusable()) return MPQR_OK;
+    if ((rc = rows_out(h->m + 1))) return rc;
+    h->rows_valid = true;
+    return MPQR_OK;
+}
+
 int mpqr_factor(mpqr_handle_t h) {
     int rc = need_plan(h); if (rc) return rc;
     if (!h->have_input) return fail(h, MPQR_ERR_STATE, "no input matrix has been set");
@@ -2030,6 +2080,7 @@ int mpqr_factor(mpqr_handle_t h) {
         h->factored = true;
         if (h->opts.form_q && !h->pass_aborted) { if ((rc = form_q(h))) return rc; }
         HIPCHK(h, hipEventRecord(h->ev[2], h->s0));
+        if (h->stream_out) { if (pass == 0) { if ((rc = stream_rows(h))) return rc; } else h->rows_valid = false; }
         HIPCHK(h, hipEventSynchronize(h->ev[1]));           // the block loop (not Q formation) is done: the flag word is final
         HIPCHK(h, hipGetLastError());
         if (h->hflag_host && h->flag_words > 0 && __atomic_load_n(h->hflag_host + h->flag_words - 1, __ATOMIC_RELAXED) != 0) {
@@ -2507,8 +2558,27 @@ int mpqr_block_qr_f32(mpqr_handle_t h, float* A, float* Q, int m, int n, int r, 
     if (o.form_q && !Q) return fail(h, MPQR_ERR_INVALID, "Q is NULL but form_q is set");
     if ((rc = mpqr_plan(h, m, n, r, &o))) return rc;
     if ((rc = mpqr_set_matrix_host(h, A, n))) return rc;
-    if ((rc = mpqr_factor(h))) return rc;
-    if (!o.form_q) return mpqr_get_factor_host(h, A);
+    // R and the reflectors leave for the caller's buffer block row by block row while the factorisation runs (stream_rows; the input has
+    // been copied to the device, A is free to be overwritten).  MPQR_STREAM_OUT=0: one copy behind the block loop, as in round 4.
+    static const int stream_env = []() { const char* e = getenv("MPQR_STREAM_OUT"); return e ? atoi(e) : 1; }();
+    const size_t el_out = (size_t)(h->m + 1) * h->n;
+    if (stream_env && h->world == 1) {
+        if (!h->sD) HIPCHK(h, hipStreamCreateWithFlags(&h->sD, hipStreamNonBlocking));
+        if ((rc = ensure_stage(h, el_out))) return rc;
+        if (h->ev_rows.size() < h->tops.size()) {
+            const size_t have = h->ev_rows.size();
+            h->ev_rows.resize(h->tops.size());
+            for (size_t i = have; i < h->ev_rows.size(); i++) HIPCHK(h, hipEventCreateWithFlags(&h->ev_rows[i], hipEventDisableTiming));
+        }
+        h->stream_out = A; h->rows_valid = false; h->rows_streamed = 0;
+    }
+    rc = mpqr_factor(h);
+    h->stream_out = nullptr;
+    if (rc) return rc;
+    const bool streamed = h->rows_valid && h->rows_streamed == h->m + 1 && h->n_passes == 1 && h->n_tpoll_retries == 0;
+    h->rows_valid = false;
+    if (!o.form_q) return streamed ? MPQR_OK : mpqr_get_factor_host(h, A);
+    if (streamed) return mpqr_get_q_host(h, Q);
     // mpqr_factor has enqueued Q formation and returned: R and the reflectors are final since the event behind the block loop, so
     // their read-back (1 GB at 16384^2, ~19 ms of PCIe) runs on a stream of its own beside Q formation (~9 ms) instead of after it
     if (!h->sD) HIPCHK(h, hipStreamCreateWithFlags(&h->sD, hipStreamNonBlocking));

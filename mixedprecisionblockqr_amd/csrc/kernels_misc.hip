@@ -68,6 +68,22 @@ void launch_pack_factor(const float* A, long lda, const float* vdiag, float* out
     const long tot = (long)(m + 1) * n;
     hipLaunchKernelGGL(pack_factor_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, A, lda, vdiag, out, m, n);
 }
+// rows [r0, r1) of the same (m+1) x n image (the drop-in call streams finished block rows out while the factorisation goes on)
+__global__ void pack_factor_rows_kernel(const float* A, long lda, const float* vdiag, float* out, int m, int n, int r0, int r1) {
+    const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= (long)(r1 - r0) * n) return;
+    const int r = r0 + (int)(e / n), c = (int)(e % n);
+    float v;
+    if (r <= c) v = (r < m) ? A[(long)r * lda + c] : 0.f;
+    else if (r - 1 == c) v = vdiag[c];
+    else v = A[(long)(r - 1) * lda + c];
+    out[(long)r * n + c] = v;
+}
+void launch_pack_factor_rows(const float* A, long lda, const float* vdiag, float* out, int m, int n, int r0, int r1, hipStream_t s) {
+    const long tot = (long)(r1 - r0) * n;
+    if (tot <= 0) return;
+    hipLaunchKernelGGL(pack_factor_rows_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, A, lda, vdiag, out, m, n, r0, r1);
+}
 
 // boundary -> internal for columns [c0,c1) that already hold reflectors; other columns are copied as plain data
 __global__ void unpack_factor_kernel(const float* in, int m, int n, int c0, int c1, float* A, long lda, float* vdiag,

@@ -202,6 +202,7 @@ void launch_set_identity(float* Q, long ldq, int rows, int cols, hipStream_t s);
 void launch_set_identity_h16(half_t* Q, long ldq, int n, hipStream_t s);   // diagonal of a zeroed fp16 matrix
 void launch_identity_cyclic_h16(half_t* Qt, long ldqt, int m, int qloc, int block, int world, int rank, hipStream_t s);
 void launch_pack_factor(const float* A, long lda, const float* vdiag, float* out, int m, int n, hipStream_t s);
+void launch_pack_factor_rows(const float* A, long lda, const float* vdiag, float* out, int m, int n, int r0, int r1, hipStream_t s);
 void launch_unpack_factor(const float* in, int m, int n, int c0, int c1, float* A, long lda, float* vdiag,
                           half_t* Vh, long ldvh, half_t* Vt, long ldvt, hipStream_t s);
 void launch_strip_r(const float* A, long lda, float* R, int m, int n, hipStream_t s);

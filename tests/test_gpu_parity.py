@@ -997,6 +997,24 @@ def test_opt_in_schedules_and_kernels():
 
 
 @pytest.mark.gpu
+def test_drop_in_call_streams_finished_rows_and_returns_the_same_bits(tmp_path):
+    """mpqr_block_qr_f32 copies the packed rows of finished blocks to the caller's buffer while the factorisation is still running
+    (driver.hip stream_rows; MPQR_STREAM_OUT=0: one copy behind the block loop).  Both ways must return the same bits for R, the
+    reflectors and Q: six 512-column blocks, so that four block rows leave early and two behind the loop."""
+    import os, subprocess, sys
+    child = os.path.join(os.path.dirname(os.path.abspath(__file__)), "optin_child.py")
+    outs = []
+    for k, extra in enumerate(({"MPQR_STREAM_OUT": "0"}, {})):
+        env = dict(os.environ); env.update(extra)
+        dump = str(tmp_path / f"stream{k}.npz")
+        p = subprocess.run([sys.executable, child, "3328", "3072", "128", "512", "77", dump], env=env, capture_output=True, text=True, timeout=600)
+        assert p.returncode == 0, (extra, p.stderr[-2000:])
+        outs.append(np.load(dump))
+    assert np.array_equal(outs[0]["Ab"], outs[1]["Ab"])
+    assert np.array_equal(outs[0]["Q"], outs[1]["Q"])
+
+
+@pytest.mark.gpu
 def test_large_pair_update_in_two_halves_gives_the_same_factorisation():
     """A long pairwise far update is enqueued in two column halves, the second one a block later behind that block's urgent updates
     (driver.hip run_block_loop, `half_b`; by default only from 12000 columns on).  A child process lowers the threshold so that a
