@@ -592,8 +592,6 @@ __global__ __launch_bounds__(256) void gh_reduce_f32_kernel(const float* __restr
 // blocks of 64 rows per gh_apply workgroup: tall leaves take 2 / 4, which still leaves >= 256 workgroups
 static int gh_apply_iters(const LeafArgs& a) {
     const int rows = a.mrows - a.c1;
-    static const int it_env = []() { const char* e = getenv("MPQR_APPLY_ITERS"); return e ? atoi(e) : 0; }();   // A/B hook (row blocks per workgroup of gh_apply / leaf_a)
-    if (it_env > 0 && rows >= 64 * it_env * 8) return it_env;
     return rows >= 49152 ? 4 : rows >= 24576 ? 2 : 1;
 }
 int gh_num_partials(const LeafArgs& a) {
