@@ -282,11 +282,19 @@ def bench_main(args, m, n, r, world, rank, local_rank, cpu_baseline_fn=None):
     """bench.py leg for N > 1 (launched by torch.distributed.run, one rank per GPU, RCCL); MPQR_FORCE_DIST=1 runs it at N = 1."""
     import torch
     import torch.distributed as dist
+    # MPQR_DIST_REHEARSE=gloo: every rank on GPU 0 with gloo as the transport -- a one-GPU box runs the real multi-process schedule
+    # (ownership, broadcast / unpack ordering against the library's streams, sharded Q) where no second GPU exists for RCCL
+    rehearse = os.environ.get("MPQR_DIST_REHEARSE", "") == "gloo"
+    if rehearse:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     own_pg = not dist.is_initialized()
     if world > 1 and own_pg:
-        dist.init_process_group(backend="nccl", device_id=dev)
+        if rehearse:
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=dev)
     comm = TorchComm(device=dev) if world > 1 else NullComm()
     # distribution unit = the far update's aggregation width; with many ranks keep at least two blocks per rank so that
     # every rank still owns trailing columns late in the factorisation (config 5: 8192 columns on 8 GPUs -> 512)

@@ -880,6 +880,31 @@ def test_distributed_schedule_on_one_gpu(mp, po, m, n, r, ko, world, la):
         assert relF(V[:, :first], V0[:, :first]) <= 3e-3
 
 
+@pytest.mark.parametrize("world", [2, 3])
+def test_multi_process_schedule_rehearsed_on_one_gpu(world):
+    """bench.py --gpus N as the driver launches it (torch.distributed.run, one process per rank), rehearsed on ONE GPU: every rank
+    computes on GPU 0 and gloo carries the broadcasts (MPQR_DIST_REHEARSE=gloo; RCCL needs one GPU per rank).  What it covers that
+    the in-process tests cannot: separate processes and handles, the ordering of every broadcast / unpack against the library's own
+    streams, block ownership and the column-sharded Q across processes.  2048 x 2048, r = 64; the line must carry the north-star
+    error estimate inside the tolerance."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ); env["MPQR_DIST_REHEARSE"] = "gloo"; env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    port = 29500 + (os.getpid() % 400) + world
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", str(world), "--steps", "2", "--warmup", "1",
+           "--config", "c2", "--no-cpu-baseline"]
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=root)
+    assert p.returncode == 0, p.stderr[-3000:]
+    line = [l for l in p.stdout.splitlines() if l.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == world and d["comm"]["world_size"] == world and d["comm"]["backend"] == "gloo", d["comm"]
+    assert d["ranks_reporting"] == world
+    assert d["error"]["backward_error_est"] <= 1e-3, d["error"]          # north_star tolerance (Gaussian probing, dist.residual_check)
+    assert d["value"] > 0 and d["metric"]
+
+
+@pytest.mark.gpu
 def test_distributed_path_repeats_a_flagged_factorisation_on_the_robust_kernels(mp, po):
     """The distributed block loop never synchronises its host per block (round 4): an ill-conditioned tall leaf raises its mapped flag
     word, the flags are asked once after the loop and the factorisation is repeated with every tall leaf on the column-by-column
