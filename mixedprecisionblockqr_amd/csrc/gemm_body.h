@@ -40,12 +40,16 @@ __device__ __forceinline__ void gemm_f16_body(const GemmArgs& g, half_t* lds, in
     const int kt0 = z * per;
     const int kt1 = min(ktiles, kt0 + per);
 
-    // ---- staging registers
-    U4 ra16[4];        // A_H16 / A_F32 (after conversion)
-    float4 raT[8];     // A_F32T
-    U4 rb[4];
+    // ---- staging registers: TWO sets for the fp16 / fp32-slab forms (round 5).  The K loop of this kernel is latency bound wherever it is
+    // used (K tiles of 64 with 16 MFMAs each: part (a)'s X = A2^T V at 16384 rows ran at 170 TFLOP/s, its Y = X T' 53 us for 2 GFLOP):
+    // the loads of tile kt + 2 are issued before tile kt is multiplied, so two load latencies overlap.  The A_F32T form keeps one set:
+    // with two it needs 212 VGPRs, one workgroup per CU, and it is the T stream's X GEMM of every leaf.
+    constexpr bool DEEP = (AM != A_F32T);
+    U4 ra16_[2][4];        // A_H16 / A_F32 (after conversion)
+    float4 raT_[2][8];     // A_F32T
+    U4 rb_[2][4];
 
-    auto load_tile = [&](int kt) {
+    auto load_tile = [&](int kt, U4 (&ra16)[4], float4 (&raT)[8], U4 (&rb)[4]) {
         const int k = kt * BK;
         if (AM == A_H16) {
             const half_t* A = (const half_t*)g.A;
@@ -103,7 +107,7 @@ __device__ __forceinline__ void gemm_f16_body(const GemmArgs& g, half_t* lds, in
         }
     };
 
-    auto store_tile = [&]() {
+    auto store_tile = [&](const U4 (&ra16)[4], const float4 (&raT)[8], const U4 (&rb)[4]) {
         if (AM == A_F32T) {
             const float sc = g.in_scale;
 #pragma unroll
@@ -141,30 +145,57 @@ __device__ __forceinline__ void gemm_f16_body(const GemmArgs& g, half_t* lds, in
 
     const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
 
-    if (kt0 < kt1) {
-        load_tile(kt0);
-        store_tile();
-        __syncthreads();
-        for (int kt = kt0; kt < kt1; kt++) {
-            const bool more = (kt + 1 < kt1);
-            if (more) load_tile(kt + 1);
+    auto mma_tile = [&]() {
 #pragma unroll
-            for (int ks = 0; ks < BK / 16; ks++) {
-                half8 a[2], b[2];
+        for (int ks = 0; ks < BK / 16; ks++) {
+            half8 a[2], b[2];
 #pragma unroll
-                for (int i = 0; i < 2; i++) a[i] = *(const half8*)(As + (wm + i * 32 + r) * LDSP + ks * 16 + h * 8);
+            for (int i = 0; i < 2; i++) a[i] = *(const half8*)(As + (wm + i * 32 + r) * LDSP + ks * 16 + h * 8);
 #pragma unroll
-                for (int j = 0; j < 2; j++) b[j] = *(const half8*)(Bs + (wn + j * 32 + r) * LDSP + ks * 16 + h * 8);
+            for (int j = 0; j < 2; j++) b[j] = *(const half8*)(Bs + (wn + j * 32 + r) * LDSP + ks * 16 + h * 8);
 #pragma unroll
-                for (int i = 0; i < 2; i++)
+            for (int i = 0; i < 2; i++)
 #pragma unroll
-                    for (int j = 0; j < 2; j++)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i], b[j], acc[i][j], 0, 0, 0);
-            }
+                for (int j = 0; j < 2; j++)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+    };
+    if (!DEEP) {
+        if (kt0 < kt1) {
+            load_tile(kt0, ra16_[0], raT_[0], rb_[0]);
+            store_tile(ra16_[0], raT_[0], rb_[0]);
             __syncthreads();
-            if (more) {
-                store_tile();
+            for (int kt = kt0; kt < kt1; kt++) {
+                const bool more = (kt + 1 < kt1);
+                if (more) load_tile(kt + 1, ra16_[0], raT_[0], rb_[0]);
+                mma_tile();
                 __syncthreads();
+                if (more) {
+                    store_tile(ra16_[0], raT_[0], rb_[0]);
+                    __syncthreads();
+                }
+            }
+        }
+    } else if (kt0 < kt1) {
+        load_tile(kt0, ra16_[0], raT_[0], rb_[0]);
+        if (kt0 + 1 < kt1) load_tile(kt0 + 1, ra16_[1], raT_[1], rb_[1]);
+        store_tile(ra16_[0], raT_[0], rb_[0]);
+        __syncthreads();
+        // two K tiles per trip so that the register sets are compile-time constants: set 0 holds the even tiles (from kt0), set 1 the odd ones
+        for (int kt = kt0; kt < kt1; kt += 2) {
+            if (kt + 2 < kt1) load_tile(kt + 2, ra16_[0], raT_[0], rb_[0]);       // (set 0 went to LDS before tile kt was multiplied)
+            mma_tile();                                                            // tile kt
+            __syncthreads();
+            if (kt + 1 < kt1) {
+                store_tile(ra16_[1], raT_[1], rb_[1]);
+                __syncthreads();
+                if (kt + 3 < kt1) load_tile(kt + 3, ra16_[1], raT_[1], rb_[1]);
+                mma_tile();                                                        // tile kt + 1
+                __syncthreads();
+                if (kt + 2 < kt1) {
+                    store_tile(ra16_[0], raT_[0], rb_[0]);
+                    __syncthreads();
+                }
             }
         }
     }
